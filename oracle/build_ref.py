@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE ONLY -- builds the *reference's own* Cython kernels into oracle/_ref/.
+
+The three hot-path modules of mlaprise/mfrec are Cython (.pyx -> C -> extension
+module).  This recipe compiles them *from the sources where they lie* under
+/root/reference (nothing is copied into the repository):
+
+    cython -2 <ref>/mfrec/lib/X.pyx -o oracle/_ref/X.c
+    gcc -O2 -fPIC -shared -ffp-contract=off oracle/_ref/X.c -o oracle/_ref/X.so
+    rm oracle/_ref/X.c                       # only the binary stays
+
+oracle/_ref/ is git-ignored (binaries only, never history).  The resulting
+modules are used to
+  * pin oracle/mfx_oracle.c (our plain-C restatement) bit-for-bit, and
+  * generate tests/golden/*.npz via oracle/make_golden.py,
+  * optionally serve as cpu_baseline.kind == "reference" in bench.py.
+
+It is a no-op (returns False) when /root/reference is absent (GPU box).
+"""
+import os
+import subprocess
+import sys
+import sysconfig
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "_ref")
+REF = os.environ.get("MFX_REFERENCE_ROOT", "/root/reference")
+MODULES = ("kmf_train", "gd_estimator", "als_implicit")
+
+
+def build(force=False, verbose=True):
+    src_dir = os.path.join(REF, "mfrec", "lib")
+    if not os.path.isdir(src_dir):
+        return False
+    import numpy as np
+    os.makedirs(OUT, exist_ok=True)
+    inc_py = sysconfig.get_paths()["include"]
+    inc_np = np.get_include()
+    ext = ".so"
+    for m in MODULES:
+        pyx = os.path.join(src_dir, m + ".pyx")
+        so = os.path.join(OUT, m + ext)
+        if (not force and os.path.exists(so)
+                and os.path.getmtime(so) >= os.path.getmtime(pyx)):
+            continue
+        c = os.path.join(OUT, m + ".c")
+        cmd = [sys.executable, "-m", "cython", "-2", pyx, "-o", c]
+        if verbose:
+            print("[build_ref]", " ".join(cmd))
+        subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        cmd = ["gcc", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-w",
+               "-DNPY_NO_DEPRECATED_API=NPY_1_7_API_VERSION",
+               "-I", inc_py, "-I", inc_np, c, "-o", so]
+        if verbose:
+            print("[build_ref]", " ".join(cmd))
+        subprocess.check_call(cmd)
+        os.remove(c)
+    return True
+
+
+def load():
+    """Import the built reference modules; returns dict name->module or None."""
+    import importlib.util
+    mods = {}
+    for m in MODULES:
+        so = os.path.join(OUT, m + ".so")
+        if not os.path.exists(so):
+            return None
+        spec = importlib.util.spec_from_file_location(m, so)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mods[m] = mod
+    return mods
+
+
+if __name__ == "__main__":
+    ok = build(force="--force" in sys.argv)
+    print("[build_ref] built" if ok else "[build_ref] reference not present; skipped")

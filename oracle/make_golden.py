@@ -1,0 +1,344 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE ONLY -- generates tests/golden/*.npz from the REFERENCE.
+
+Runs the reference's own Cython kernels (compiled from /root/reference by
+oracle/build_ref.py into oracle/_ref/) on seeded inputs and stores inputs AND
+outputs.  While doing so it also checks oracle/mfx_oracle.c (the plain-C
+restatement) against the reference -- bit-for-bit for the SGD families,
+1e-9 relative for ALS (LAPACK inverse) -- and refuses to write fixtures if
+that fails.  Only runs in the build container (the reference does not exist
+on the GPU box); the committed fixtures are what travels.
+
+Fixture key convention: p_* scalars/params, in_* inputs, out_* reference outputs.
+"""
+import contextlib
+import importlib.util
+import io
+import os
+import re
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+from oracle import build_ref, oracle as O  # noqa: E402
+from mfrec_amd import synth  # noqa: E402
+
+
+def level_order(idx):
+    """Dependency-level order (SURVEY section 7 'Hard parts'): stable level-major permutation."""
+    nu = int(idx[:, 0].max()) + 1
+    ni = int(idx[:, 1].max()) + 1
+    lu = np.zeros(nu, dtype=np.int64)
+    li = np.zeros(ni, dtype=np.int64)
+    lev = np.empty(idx.shape[0], dtype=np.int64)
+    for t in range(idx.shape[0]):
+        a, b = idx[t]
+        L = 1 + max(lu[a], li[b])
+        lev[t] = L
+        lu[a] = L
+        li[b] = L
+    return np.argsort(lev, kind="stable").astype(np.int64), lev
+
+
+def small_problem(seed, nu=60, ni=40, nnz=600, k=8, lo=1, hi=5):
+    rs = np.random.RandomState(seed)
+    idx = np.stack([rs.randint(0, nu, nnz), rs.randint(0, ni, nnz)], axis=1).astype(np.int32)
+    r = rs.randint(lo, hi + 1, nnz).astype(np.float64)
+    u0 = rs.normal(0.0, 0.1, (k, ni))
+    v0 = rs.normal(0.0, 0.1, (k, nu))
+    return idx, r, u0, v0
+
+
+def captured_rmse(fn, *args):
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        fn(*args)
+    return np.array([float(x) for x in re.findall(r"RMSE: ([0-9.eE+-]+|nan|inf)", buf.getvalue())])
+
+
+def same(a, b, what):
+    if not (a.shape == b.shape and np.array_equal(a, b, equal_nan=True)):
+        d = np.abs(a - b).max() if a.shape == b.shape else "shape"
+        raise SystemExit("restatement != reference for %s (max abs diff %s)" % (what, d))
+
+
+def main():
+    if not build_ref.build():
+        raise SystemExit("reference not present: cannot generate golden vectors here")
+    ref = build_ref.load()
+    kmf, gd, als = ref["kmf_train"], ref["gd_estimator"], ref["als_implicit"]
+    spec = importlib.util.spec_from_file_location(
+        "ref_datasets", os.path.join(build_ref.REF, "mfrec", "lib", "datasets.py"))
+    ref_ds = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_ds)
+    os.makedirs(GOLD, exist_ok=True)
+    written = []
+
+    def save(name, **kw):
+        path = os.path.join(GOLD, name + ".npz")
+        np.savez_compressed(path, **kw)
+        written.append((name, os.path.getsize(path)))
+
+    # ---------------- G1 / G2: all-k SGD, linear + logistic, with gates ----------------
+    hp = dict(lr=0.01, Ku=0.1, Ki=0.1, Kb=0.007)
+    for name, fn_name, mode in (("g1_linear", "train_linear_kernel", 0),
+                                ("g2_logistic", "train_logistic_kernel", 1)):
+        idx, r, u0, v0 = small_problem(7)
+        E, k = 3, 8
+        out = {}
+        for gate in ((1, 1), (1, 0), (0, 1)):
+            u, v = u0.copy(), v0.copy()
+            ib, ub = np.zeros(40), np.zeros(60)
+            rm = captured_rmse(getattr(kmf, fn_name), E, k, 0.1, hp["lr"], hp["lr"], hp["lr"],
+                               hp["Ku"], hp["Ki"], hp["Kb"], 0.0, u, v, idx, r, ib, ub,
+                               gate[0], gate[1], 1)
+            u2, v2 = u0.copy(), v0.copy()
+            ib2, ub2 = np.zeros(40), np.zeros(60)
+            rm2 = np.zeros(E)
+            getattr(O, fn_name)(E, k, 0.1, hp["lr"], hp["lr"], hp["lr"], hp["Ku"], hp["Ki"],
+                                hp["Kb"], 0.0, u2, v2, idx, r, ib2, ub2, gate[0], gate[1], 0, rm2)
+            tag = "%d%d" % gate
+            for a, b, w in ((u, u2, "u"), (v, v2, "v"), (ib, ib2, "ib"), (ub, ub2, "ub")):
+                same(a, b, "%s gate %s %s" % (name, tag, w))
+            assert np.allclose(rm, rm2, rtol=1e-10, atol=0), (rm, rm2)
+            out.update({"out_u_" + tag: u, "out_v_" + tag: v, "out_ib_" + tag: ib,
+                        "out_ub_" + tag: ub, "out_rmse_" + tag: rm2})
+        save(name, p_mode=mode, p_epochs=E, p_k=k, p_lr=hp["lr"], p_Ku=hp["Ku"], p_Ki=hp["Ki"],
+             p_Kb=hp["Kb"], in_idx=idx, in_r=r, in_u0=u0, in_v0=v0, **out)
+
+    # ---------------- G3: Funk without bias (+ rmse history, + subloop goldens) ---------
+    idx, r, _, _ = small_problem(11)
+    k, E, lr, K, init = 8, 5, 0.001, 0.05, 0.1
+    u, v = synth.init_const(k, 40), synth.init_const(k, 60)
+    gd.estimator_loop_without_bias(E, E, 1e9, k, init, lr, K, u, v, idx, r, 60, 40, 0)
+    u2, v2 = synth.init_const(k, 40), synth.init_const(k, 60)
+    hist2 = np.zeros(k * E)
+    n = O.estimator_loop_without_bias(E, E, 1e9, k, init, lr, K, u2, v2, idx, r, 60, 40, 0, hist2)
+    assert n == k * E
+    same(u, u2, "g3 u"); same(v, v2, "g3 v")
+    # estimator_loop: dense cache, rmse_hist filled by the reference itself
+    u3, v3 = synth.init_const(k, 40), synth.init_const(k, 60)
+    hist = np.zeros(k * E)
+    gd.estimator_loop(E, E, 1e9, k, init, lr, K, u3, v3, idx, r, 0, hist, 60, 40, 0)
+    u4, v4 = synth.init_const(k, 40), synth.init_const(k, 60)
+    hist4 = np.zeros(k * E)
+    O.estimator_loop(E, E, 1e9, k, init, lr, K, u4, v4, idx, r, 0, hist4, 60, 40, 0)
+    same(u3, u4, "g3 estimator_loop u"); same(hist, hist4, "g3 estimator_loop hist")
+    # subloop / predictor_subloop driven from Python as gradient_descent.py:322-328 does
+    u5, v5 = synth.init_const(k, 40), synth.init_const(k, 60)
+    u6, v6 = synth.init_const(k, 40), synth.init_const(k, 60)
+    c5, c6 = np.zeros(60 * 40), np.zeros(60 * 40)
+    sub, sub2 = [], []
+    for f in range(2):
+        for _ in range(3):
+            sub.append(gd.estimator_subloop(f, 1, 0.0, k, init, lr, K, u5, v5, idx, r, c5, 60, 40, 0))
+            sub2.append(O.estimator_subloop(f, 1, 0.0, k, init, lr, K, u6, v6, idx, r, c6, 60, 40, 0))
+        gd.predictor_subloop(f, 1, k, init, u5, v5, idx, r, c5, 60, 40)
+        O.predictor_subloop(f, 1, k, init, u6, v6, idx, r, c6, 60, 40)
+    same(np.array(sub), np.array(sub2), "g3 subloop rmse"); same(c5, c6, "g3 dense cache")
+    same(u5, u6, "g3 subloop u")
+    # duplicates make the dense-cache variants differ from the sparse-cache one; record both
+    save("g3_funk", p_k=k, p_epochs=E, p_lr=lr, p_K=K, p_init=init, in_idx=idx, in_r=r,
+         out_u=u, out_v=v, out_rmse_hist=hist2, out_dense_u=u3, out_dense_v=v3,
+         out_dense_rmse_hist=hist, out_sub_rmse=np.array(sub), out_sub_u=u5, out_sub_v=v5,
+         out_sub_cache=c5)
+
+    # G3b: data-dependent stopping rule (gd_estimator.pyx:742) with the class defaults' shape
+    u, v = synth.init_const(k, 40), synth.init_const(k, 60)
+    rm = captured_rmse(gd.estimator_loop_without_bias, 2, 2, 1e-4, k, init, 0.01, K, u, v, idx, r,
+                       60, 40, 1)
+    u2, v2 = synth.init_const(k, 40), synth.init_const(k, 60)
+    hist2 = np.zeros(4096)
+    n = O.estimator_loop_without_bias(2, 2, 1e-4, k, init, 0.01, K, u2, v2, idx, r, 60, 40, 0, hist2)
+    same(u, u2, "g3b u"); same(v, v2, "g3b v")
+    save("g3b_funk_stop", p_k=k, p_min_epochs=2, p_min_improvement=1e-4, p_lr=0.01, p_K=K,
+         p_init=init, in_idx=idx, in_r=r, out_u=u, out_v=v, out_n_epochs=n,
+         out_rmse_hist=hist2[:n], out_rmse_last_per_feature=rm)
+
+    # ---------------- G4: Funk with (fixed) biases, and the _dev gates -----------------
+    rs = np.random.RandomState(5)
+    ib, ub = rs.normal(0, 0.3, 40), rs.normal(0, 0.3, 60)
+    mu = 3.1
+    out = {}
+    for tag, fn, gate in (("11", gd.estimator_loop_with_bias, None),
+                          ("10", gd.estimator_loop_with_bias_dev, (1, 0)),
+                          ("01", gd.estimator_loop_with_bias_dev, (0, 1))):
+        u, v = synth.init_const(k, 40), synth.init_const(k, 60)
+        u2, v2 = synth.init_const(k, 40), synth.init_const(k, 60)
+        if gate is None:
+            fn(E, E, 1e9, k, init, lr, lr, lr, K, mu, u, v, idx, r, ib, ub, 60, 40, 0)
+            O.estimator_loop_with_bias(E, E, 1e9, k, init, lr, lr, lr, K, mu, u2, v2, idx, r, ib,
+                                       ub, 60, 40, 0)
+        else:
+            fn(E, E, 1e9, k, init, lr, lr, lr, K, mu, u, v, idx, r, ib, ub, 60, 40, gate[0], gate[1], 0)
+            O.estimator_loop_with_bias_dev(E, E, 1e9, k, init, lr, lr, lr, K, mu, u2, v2, idx, r,
+                                           ib, ub, 60, 40, gate[0], gate[1], 0)
+        same(u, u2, "g4 u " + tag); same(v, v2, "g4 v " + tag)
+        out["out_u_" + tag], out["out_v_" + tag] = u, v
+    save("g4_funk_bias", p_k=k, p_epochs=E, p_lr=lr, p_K=K, p_init=init, p_mu=mu, in_idx=idx,
+         in_r=r, in_ib=ib, in_ub=ub, **out)
+
+    # ---------------- G5: learned bias (full k-dot, single-feature update) -------------
+    u, v = synth.init_const(k, 40), synth.init_const(k, 60)
+    ibr, ubr = ib.copy(), ub.copy()
+    gd.estimator_loop_with_learned_bias(3, 3, 1e9, k, init, 0.005, 0.004, 0.003, 0.05, 0.01, mu,
+                                        u, v, idx, r, ibr, ubr, 60, 40, 0)
+    u2, v2 = synth.init_const(k, 40), synth.init_const(k, 60)
+    ib2, ub2 = ib.copy(), ub.copy()
+    hist2 = np.zeros(3 * k)
+    O.estimator_loop_with_learned_bias(3, 3, 1e9, k, init, 0.005, 0.004, 0.003, 0.05, 0.01, mu,
+                                       u2, v2, idx, r, ib2, ub2, 60, 40, 0, 0, hist2)
+    for a, b, w in ((u, u2, "u"), (v, v2, "v"), (ibr, ib2, "ib"), (ubr, ub2, "ub")):
+        same(a, b, "g5 " + w)
+    save("g5_learned_bias", p_k=k, p_epochs=3, p_lr=0.005, p_lr_users=0.004, p_lr_items=0.003,
+         p_K=0.05, p_Kb=0.01, p_init=init, p_mu=mu, in_idx=idx, in_r=r, in_ib=ib, in_ub=ub,
+         out_u=u, out_v=v, out_ib=ibr, out_ub=ubr, out_rmse_hist=hist2)
+
+    # ---------------- G6: ALS / WRMF --------------------------------------------------
+    import scipy.sparse as sp
+    rs = np.random.RandomState(3)
+    nu, ni, k = 50, 30, 8
+    M = sp.lil_matrix((nu, ni))
+    for _ in range(400):
+        a, b = rs.randint(0, nu - 3), rs.randint(0, ni - 2)   # trailing ids stay unrated
+        if a == 7:
+            continue                                            # a user with zero ratings
+        M[a, b] = float(rs.randint(1, 6))
+    urow, ucol = ref_ds.create_bool_sparse_row(M)
+    irow, icol = ref_ds.create_bool_sparse_col(M)
+    urow, ucol, irow, icol = (np.ascontiguousarray(x, dtype=np.int32) for x in (urow, ucol, irow, icol))
+    coo = M.tocoo()
+    # The class default init (zeros + 0.1, wrmf.py:92-93) makes every factor column parallel to
+    # the all-ones vector: the k x k systems are a*11^T + lambda*I and the components orthogonal
+    # to 1 are pure rounding noise that each half-epoch amplifies by ~a*k/lambda.  The reference's
+    # own output is then a function of LAPACK's rounding, so that case is pinned loosely (1 epoch
+    # 1e-9, 2 epochs 1e-4) and the tight pin (1e-9 relative) uses a seeded N(0, 0.1) init.
+    out = {}
+    rs2 = np.random.RandomState(1)
+    inits = {"rand": (rs2.normal(0, 0.1, (k, ni)), rs2.normal(0, 0.1, (k, nu))),
+             "const": (synth.init_const(k, ni), synth.init_const(k, nu))}
+    for tag, (u0, v0) in inits.items():
+        for E in (1, 2):
+            u, v = u0.copy(), v0.copy()
+            als.als_wrmf(E, k, u, v, np.zeros((k, k)), np.zeros((k, k)), urow, ucol, irow, icol,
+                         nu, ni, 1, 0.015, 0)
+            u2, v2 = u0.copy(), v0.copy()
+            O.als_wrmf(E, k, u2, v2, None, None, urow, ucol, irow, icol, nu, ni, 1, 0.015, 0)
+            tol = 1e-9 if (tag == "rand" or E == 1) else 1e-4
+            assert np.allclose(u, u2, rtol=tol, atol=tol * 1e-2) and \
+                np.allclose(v, v2, rtol=tol, atol=tol * 1e-2), \
+                (tag, E, np.abs(u - u2).max(), np.abs(v - v2).max())
+            out["out_u_%s_e%d" % (tag, E)], out["out_v_%s_e%d" % (tag, E)] = u, v
+    save("g6_als", p_k=k, p_c_pos=1, p_lambda=0.015, p_nu=nu, p_ni=ni,
+         in_coo_row=coo.row.astype(np.int32), in_coo_col=coo.col.astype(np.int32),
+         in_coo_val=coo.data, in_urow=urow, in_ucol=ucol, in_irow=irow, in_icol=icol,
+         in_u0_rand=inits["rand"][0], in_v0_rand=inits["rand"][1], **out)
+
+    # ---------------- G7: cfg-1 shape (ML-100K sized synthetic) -----------------------
+    nu, ni, nnz, k, E = 943, 1682, 100000, 16, 10
+    idx, r = synth.make_ratings(nu, ni, nnz)
+    u0, v0 = synth.init_normal(k, ni, synth.SEED_INIT), synth.init_normal(k, nu, synth.SEED_INIT + 1)
+    u, v, ib, ub = u0.copy(), v0.copy(), np.zeros(ni), np.zeros(nu)
+    rm = captured_rmse(kmf.train_linear_kernel, E, k, 0.1, 0.01, 0.01, 0.01, 0.1, 0.1, 0.007, 0.0,
+                       u, v, idx, r, ib, ub, 1, 1, 1)
+    u2, v2, ib2, ub2 = u0.copy(), v0.copy(), np.zeros(ni), np.zeros(nu)
+    rm2 = np.zeros(E)
+    O.train_linear_kernel(E, k, 0.1, 0.01, 0.01, 0.01, 0.1, 0.1, 0.007, 0.0, u2, v2, idx, r, ib2,
+                          ub2, 1, 1, 0, rm2)
+    for a, b, w in ((u, u2, "u"), (v, v2, "v"), (ib, ib2, "ib"), (ub, ub2, "ub")):
+        same(a, b, "g7 linear " + w)
+    assert np.allclose(rm, rm2, rtol=1e-10)
+    fu, fv = synth.init_const(k, ni), synth.init_const(k, nu)
+    gd.estimator_loop_without_bias(E, E, 1e9, k, 0.1, 0.001, 0.05, fu, fv, idx, r, nu, ni, 0)
+    fu2, fv2 = synth.init_const(k, ni), synth.init_const(k, nu)
+    fh = np.zeros(k * E)
+    O.estimator_loop_without_bias(E, E, 1e9, k, 0.1, 0.001, 0.05, fu2, fv2, idx, r, nu, ni, 0, fh)
+    same(fu, fu2, "g7 funk u"); same(fv, fv2, "g7 funk v")
+    save("g7_cfg1", p_nu=nu, p_ni=ni, p_nnz=nnz, p_k=k, p_epochs=E, p_seed_data=synth.SEED_DATA,
+         p_seed_init=synth.SEED_INIT, in_idx=idx, in_r=r.astype(np.int8),
+         out_lin_u=u, out_lin_v=v, out_lin_ib=ib, out_lin_ub=ub, out_lin_rmse=rm2,
+         out_lin_final_rmse=O.rmse(O.RMSE_KMF_LINEAR, u, v, idx, r, ib, ub),
+         out_funk_u=fu, out_funk_v=fv, out_funk_rmse_hist=fh,
+         out_funk_final_rmse=O.rmse(O.RMSE_GD, fu, fv, idx, r))
+
+    # ---------------- G8: level-major reordering is exact ------------------------------
+    idx, r, u0, v0 = small_problem(7)
+    perm, lev = level_order(idx)
+    g1 = np.load(os.path.join(GOLD, "g1_linear.npz"))
+    u, v, ib, ub = u0.copy(), v0.copy(), np.zeros(40), np.zeros(60)
+    kmf.train_linear_kernel(3, 8, 0.1, 0.01, 0.01, 0.01, 0.1, 0.1, 0.007, 0.0, u, v,
+                            np.ascontiguousarray(idx[perm]), np.ascontiguousarray(r[perm]), ib, ub, 1, 1, 0)
+    same(u, g1["out_u_11"], "g8 level-major linear u"); same(v, g1["out_v_11"], "g8 v")
+    same(ib, g1["out_ib_11"], "g8 ib"); same(ub, g1["out_ub_11"], "g8 ub")
+    idx3, r3, _, _ = small_problem(11)
+    perm3, lev3 = level_order(idx3)
+    g3 = np.load(os.path.join(GOLD, "g3_funk.npz"))
+    u, v = synth.init_const(8, 40), synth.init_const(8, 60)
+    gd.estimator_loop_without_bias(5, 5, 1e9, 8, 0.1, 0.001, 0.05, u, v,
+                                   np.ascontiguousarray(idx3[perm3]), np.ascontiguousarray(r3[perm3]), 60, 40, 0)
+    same(u, g3["out_u"], "g8 level-major funk u"); same(v, g3["out_v"], "g8 funk v")
+    save("g8_levels", in_idx_a=idx, out_perm_a=perm, out_level_a=lev, in_idx_b=idx3,
+         out_perm_b=perm3, out_level_b=lev3)
+
+    # ---------------- G9: edge cases ---------------------------------------------------
+    out = {}
+    # (a) duplicates + out-of-range ratings (clamp paths), k = 1
+    rs = np.random.RandomState(9)
+    idx = np.stack([rs.randint(0, 6, 200), rs.randint(0, 5, 200)], axis=1).astype(np.int32)
+    r = rs.uniform(-2.0, 9.0, 200)
+    for k in (1, 3):
+        u0, v0 = rs.normal(0, 0.5, (k, 5)), rs.normal(0, 0.5, (k, 6))
+        u, v, ib, ub = u0.copy(), v0.copy(), np.zeros(5), np.zeros(6)
+        kmf.train_linear_kernel(4, k, 0.1, 0.05, 0, 0, 0.1, 0.1, 0.007, 0.0, u, v, idx, r, ib, ub, 1, 1, 0)
+        u2, v2, ib2, ub2 = u0.copy(), v0.copy(), np.zeros(5), np.zeros(6)
+        O.train_linear_kernel(4, k, 0.1, 0.05, 0, 0, 0.1, 0.1, 0.007, 0.0, u2, v2, idx, r, ib2, ub2)
+        same(u, u2, "g9 lin k=%d" % k); same(ub, ub2, "g9 lin ub")
+        fu, fv = synth.init_const(k, 5, 0.7), synth.init_const(k, 6, 0.7)
+        gd.estimator_loop_without_bias(4, 4, 1e9, k, 0.7, 0.02, 0.05, fu, fv, idx, r, 6, 5, 0)
+        fu2, fv2 = synth.init_const(k, 5, 0.7), synth.init_const(k, 6, 0.7)
+        O.estimator_loop_without_bias(4, 4, 1e9, k, 0.7, 0.02, 0.05, fu2, fv2, idx, r, 6, 5, 0)
+        same(fu, fu2, "g9 funk k=%d" % k); same(fv, fv2, "g9 funk v")
+        out.update({"in_u0_k%d" % k: u0, "in_v0_k%d" % k: v0, "out_lin_u_k%d" % k: u,
+                    "out_lin_v_k%d" % k: v, "out_lin_ib_k%d" % k: ib, "out_lin_ub_k%d" % k: ub,
+                    "out_funk_u_k%d" % k: fu, "out_funk_v_k%d" % k: fv})
+    # (b) k = 128 and k = 40 (class default) and k = 64 on a slightly larger problem
+    idxb, rb, _, _ = small_problem(21, nu=80, ni=50, nnz=1500)
+    for k in (40, 64, 128):
+        rs = np.random.RandomState(100 + k)
+        u0, v0 = rs.normal(0, 0.1, (k, 50)), rs.normal(0, 0.1, (k, 80))
+        for nm, fn, ofn in (("lin", kmf.train_linear_kernel, O.train_linear_kernel),
+                            ("log", kmf.train_logistic_kernel, O.train_logistic_kernel)):
+            u, v, ib, ub = u0.copy(), v0.copy(), np.zeros(50), np.zeros(80)
+            fn(2, k, 0.1, 0.01, 0, 0, 0.1, 0.1, 0.007, 0.0, u, v, idxb, rb, ib, ub, 1, 1, 0)
+            u2, v2, ib2, ub2 = u0.copy(), v0.copy(), np.zeros(50), np.zeros(80)
+            ofn(2, k, 0.1, 0.01, 0, 0, 0.1, 0.1, 0.007, 0.0, u2, v2, idxb, rb, ib2, ub2)
+            same(u, u2, "g9 %s k=%d" % (nm, k)); same(v, v2, "g9 v"); same(ib, ib2, "g9 ib")
+            out.update({"out_%s_u_k%d" % (nm, k): u, "out_%s_v_k%d" % (nm, k): v,
+                        "out_%s_ib_k%d" % (nm, k): ib, "out_%s_ub_k%d" % (nm, k): ub})
+        out.update({"in_u0_k%d" % k: u0, "in_v0_k%d" % k: v0})
+    save("g9_edges", in_idx_a=idx, in_r_a=r, in_idx_b=idxb, in_r_b=rb, **out)
+
+    # ---------------- G10: datasets.py marshalling ------------------------------------
+    rs = np.random.RandomState(17)
+    M = sp.lil_matrix((12, 9))
+    for _ in range(40):
+        M[rs.randint(0, 11), rs.randint(0, 8)] = float(rs.randint(1, 6))
+    a, b = ref_ds.create_bool_sparse_row(M)
+    c, d = ref_ds.create_bool_sparse_col(M)
+    coo = M.tocoo()
+    save("g10_datasets", p_shape=np.array(M.shape), in_row=coo.row.astype(np.int32),
+         in_col=coo.col.astype(np.int32), in_val=coo.data, out_urow=a, out_ucol=b, out_irow=c,
+         out_icol=d)
+
+    for name, size in written:
+        print("%-18s %8d B" % (name, size))
+    print("restatement == reference on every fixture: OK")
+
+
+if __name__ == "__main__":
+    main()

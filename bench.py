@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- rating-updates/s of the full-k SGD hot path (train_linear_kernel semantics)
+on BASELINE.json configs[1]: synthetic 100K users x 50K items, 10M ratings, k=64, f64.
+
+A "step" is one epoch (one pass of the hot path over all ratings of this rank's shard).
+Inputs (ratings in level-major order, schedule, factors) are resident in HBM when the
+timed region starts.  At N > 1 (one process per GPU, torchrun) every rank holds a cfg-2
+sized user shard (weak scaling) and the item factors are all-reduced over RCCL each epoch.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
+LR, KU, KI, KB = 0.01, 0.1, 0.1, 0.007        # kmf.py:51-56 defaults
+
+
+def algorithmic_bytes(k, nnz, nu, s=8, rec=16):
+    """B_read = R + k*s + s + (k*s+s)/d_u, B_total adds the writes."""
+    d_u = nnz / float(nu)
+    b_read = rec + k * s + s + (k * s + s) / d_u
+    b_total = b_read + k * s + s + (k * s + s) / d_u
+    return b_read, b_total
+
+
+def cpu_baseline(idx, r, nu, ni, k, budget_s=15.0):
+    """The oracle (plain-C port of the reference loop) timed on this host, 1 thread, on a
+    bounded prefix of the same workload with the full-size factor arrays allocated."""
+    from oracle import oracle as O
+    from mfrec_amd import synth
+    u, v = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
+    ib, ub = np.zeros(ni), np.zeros(nu)
+    n = min(idx.shape[0], 200000)
+    t0 = time.perf_counter()
+    O.train_linear_kernel(1, k, 0.1, LR, 0, 0, KU, KI, KB, 0.0, u, v, idx[:n], r[:n], ib, ub)
+    dt = time.perf_counter() - t0
+    rate = n / dt
+    n2 = int(min(idx.shape[0], max(n, rate * budget_s)))
+    t0 = time.perf_counter()
+    O.train_linear_kernel(1, k, 0.1, LR, 0, 0, KU, KI, KB, 0.0, u, v, idx[:n2], r[:n2], ib, ub)
+    dt = time.perf_counter() - t0
+    out = {"value": n2 / dt, "unit": "rating-updates/s", "cores": 1, "kind": "port",
+           "sample": "first %d of %d ratings (shuffled order), 1 epoch, full-size factors, "
+                     "oracle/mfx_oracle.c single thread, %.1f s" % (n2, idx.shape[0], dt)}
+    # the reference's own Cython kernel, when its build travelled with the snapshot
+    try:
+        from oracle import build_ref
+        ref = build_ref.load()
+        if ref is not None:
+            n3 = int(min(n2, max(n, rate * 5.0)))
+            t0 = time.perf_counter()
+            ref["kmf_train"].train_linear_kernel(1, k, 0.1, LR, 0.0, 0.0, KU, KI, KB, 0.0, u, v,
+                                                 idx[:n3], r[:n3], ib, ub, 1, 1, 0)
+            out["reference_cython_value"] = n3 / (time.perf_counter() - t0)
+    except Exception as e:      # never let the optional extra break the bench line
+        out["reference_cython_error"] = repr(e)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--users", type=int, default=100000, help="users per GPU")
+    ap.add_argument("--items", type=int, default=50000)
+    ap.add_argument("--nnz", type=int, default=10000000, help="ratings per GPU")
+    ap.add_argument("--k", type=int, default=64)
+    ap.add_argument("--order", choices=["shuffled", "user-major"], default="shuffled")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus %d needs torchrun (one process per GPU)" % a.gpus)
+        a.gpus = world
+
+    from mfrec_amd import _shim as S
+    from mfrec_amd import build as B
+    from mfrec_amd import synth
+    from mfrec_amd.plan import SgdPlan, Timer, LINEAR
+    B.build(verbose=False)
+    S.init(local)
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import ctypes as C
+        idbuf = C.create_string_buffer(S.UNIQUE_ID_BYTES)
+        if rank == 0:
+            S.check(S.lib().mfx_comm_unique_id(idbuf))
+        obj = [idbuf.raw]
+        dist.broadcast_object_list(obj, src=0)
+        S.check(S.lib().mfx_comm_init(rank, world, obj[0]))
+
+    nu, ni, nnz, k = a.users, a.items, a.nnz, a.k
+    # this rank's shard: its own users (local ids 0..nu-1), the shared item catalogue
+    idx, r = synth.make_ratings(nu, ni, nnz, t0=rank * nnz, user_base=0)
+    if a.order == "user-major":
+        idx, r = synth.user_major(idx, r)
+    u0 = synth.init_normal(k, ni, synth.SEED_INIT)
+    v0 = synth.init_normal(k, nu, synth.SEED_INIT + 1 + rank)
+    plan = SgdPlan(idx, r, nu, ni, k)
+    plan.set_factors(u0, v0, np.zeros(ni), np.zeros(nu))
+    info = plan.info()
+
+    def run(n):
+        if world > 1:
+            plan.run_kmf_sharded(LINEAR, n, LR, KU, KI, KB, 1.0 / world)
+        else:
+            plan.run_kmf(LINEAR, n, LR, KU, KI, KB, want_rmse=False)
+
+    def barrier():
+        S.sync()
+        if world > 1:
+            S.check(S.lib().mfx_comm_barrier())
+            dist.barrier()
+
+    run(max(a.warmup, 0))
+    barrier()
+    t0 = time.perf_counter()
+    with Timer() as tm:
+        run(a.steps)
+    barrier()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        import torch
+        t = torch.tensor([wall], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t[0])
+
+    # dominant kernel: one instrumented epoch, HIP events around every level launch
+    kern_ms, launches = plan.profile_kmf(LINEAR, LR, KU, KI, KB)
+    b_read, b_total = algorithmic_bytes(k, nnz, nu)
+    avg_launch_s = kern_ms * 1e-3 / launches
+    achieved = (b_read * nnz / launches) / avg_launch_s
+
+    if rank == 0:
+        value = world * nnz * a.steps / wall
+        line = {
+            "metric": "rating-updates/s per epoch at k=%d" % k, "value": value,
+            "unit": "rating-updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": wall * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "cfg2: synthetic %dK users x %dK items, %dM ratings per GPU, "
+                                   "k=%d, full-k SGD (train_linear_kernel), %s order, "
+                                   "exact level schedule" % (nu // 1000, ni // 1000,
+                                                             nnz // 1000000, k, a.order),
+                       "users_per_gpu": nu, "items": ni, "ratings_per_gpu": nnz, "k": k,
+                       "levels": info["n_levels"], "launches_per_epoch": info["launches_per_epoch"],
+                       "sharding": "users x%d, item-delta all-reduce (RCCL)" % world if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+                         "kernel": "k1_level<64,1,16,linear>",
+                         "bytes_per_update_read": b_read, "bytes_per_update_total": b_total,
+                         "avg_launch_us": avg_launch_s * 1e6, "launches": launches,
+                         "frac_total_bytes": (b_total * nnz / launches) / avg_launch_s / HBM_PEAK},
+            "device_ms_per_step": tm.ms / a.steps,
+            "schedule_build_ms": info["schedule_us"] / 1e3,
+        }
+        if not a.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(idx, r, nu, ni, k)
+        print(json.dumps(line), flush=True)
+    plan.close()
+    if world > 1:
+        S.check(S.lib().mfx_comm_destroy())
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,181 @@
+/*
+ * mfx.h -- C ABI of libmfx.so: MI355X (gfx950) latent-factor training hot path.
+ *
+ * This is the drop-in boundary for the three Cython extension modules of
+ * mlaprise/mfrec (mfrec/lib/kmf_train.pyx, gd_estimator.pyx, als_implicit.pyx).
+ * Every entry point takes plain pointers and sizes; no Python, numpy or torch
+ * types appear.  Host arrays use the REFERENCE's layouts:
+ *
+ *   u  f64 [k, ni]  item factors, feature-major C-contiguous (gd_estimator.pyx:23,
+ *   v  f64 [k, nu]  user factors                              gradient_descent.py:524-525)
+ *   ratings_index int32 [nnz, 2]  column 0 = user, column 1 = item (base.py:1121-1124)
+ *   ratings       f64   [nnz]
+ *   items_bias f64 [ni], users_bias f64 [nu]
+ *
+ * Arrays are caller-owned and updated IN PLACE, as the reference does.  All
+ * functions return 0 on success or a negative MFX_E_* code; mfx_last_error()
+ * gives the message.  The library is one-call-at-a-time per process (the
+ * reference holds the GIL for the whole call); ctypes releases the GIL.
+ *
+ * There is NO CPU fallback: without a usable HIP device every compute entry
+ * point fails with MFX_E_HIP.
+ */
+#ifndef MFX_H
+#define MFX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFX_OK 0
+#define MFX_E_ARG (-1)      /* bad argument (NULL, negative size, k < 1, ...)            */
+#define MFX_E_RANGE (-2)    /* user/item index outside [0,nu) / [0,ni)                   */
+#define MFX_E_NOMEM (-3)    /* host or device allocation failed                          */
+#define MFX_E_HIP (-4)      /* HIP runtime error / no device                             */
+#define MFX_E_RCCL (-5)     /* RCCL error                                                */
+#define MFX_E_SINGULAR (-6) /* ALS: k x k system not positive definite                   */
+#define MFX_E_STATE (-7)    /* call sequence error (e.g. plan used before set_factors)   */
+
+/* kernel families of the resident (plan) API */
+#define MFX_MODE_LINEAR 0   /* train_linear_kernel    kmf_train.pyx:195-277 */
+#define MFX_MODE_LOGISTIC 1 /* train_logistic_kernel  kmf_train.pyx:103-189 */
+
+/* ------------------------------------------------------------------ runtime */
+int mfx_version(void);
+const char *mfx_last_error(void);
+int mfx_device_count(void);                 /* hipGetDeviceCount; 0 if none / error        */
+int mfx_init(int device);                   /* bind this process to `device`, create stream */
+int mfx_sync(void);                         /* hipStreamSynchronize on the library stream  */
+int mfx_device_name(char *buf, int buflen); /* gcnArchName of the bound device             */
+/* HIP-event stopwatch on the library's stream (the stream every kernel is launched on). */
+int mfx_timer_start(void);
+int mfx_timer_stop(double *elapsed_ms);
+
+/* ----------------------------------------------------- host-side scheduling
+ * Dependency-level schedule of a rating sequence (pure host code, no GPU).
+ * level[t] = 1 + max(level of the previous rating with the same user,
+ *                    level of the previous rating with the same item)
+ * Ratings of one level touch pairwise-distinct users and items, so they can be
+ * applied in parallel and, levels taken in order, the result is bit-identical
+ * to the reference's sequential loop (kmf_train.pyx:243, gd_estimator.pyx:745).
+ * perm is the stable level-major permutation; level_off has n_levels+1 entries.
+ */
+int mfx_schedule_levels(const int32_t *ratings_index, int64_t nnz, int nu, int ni,
+                        int32_t *level_out, int64_t *n_levels_out);
+int mfx_schedule_permutation(const int32_t *level, int64_t nnz, int64_t n_levels,
+                             int64_t *perm_out, int64_t *level_off_out);
+
+/* ------------------------------------------- one-shot drop-ins (host arrays)
+ * Replace, argument for argument, the Cython `def` functions.  Arguments the
+ * reference accepts but never reads (f_init, learning_rate_users/items and
+ * overall_avg of the kmf kernels; max_epochs of the Funk loops) are dropped
+ * here and swallowed by the Python wrappers.
+ */
+
+/* train_linear_kernel (kmf_train.pyx:195-213) / train_logistic_kernel (:103-121).
+ * rmse_out: NULL or f64[nbr_epochs], the per-epoch online RMSE the reference prints. */
+int mfx_kmf_train(int mode, int nbr_epochs, int dim, double learning_rate, double K_users,
+                  double K_items, double K_bias, double *u, double *v,
+                  const int32_t *ratings_index, const double *ratings, double *items_bias,
+                  double *users_bias, int64_t nnz, int nu, int ni, int update_users,
+                  int update_items, double *rmse_out);
+
+/* estimator_loop_without_bias (gd_estimator.pyx:691-704; items_bias = users_bias = NULL,
+ * overall_avg = 1.0), estimator_loop_with_bias (:489-507), estimator_loop_with_bias_dev
+ * (:588-608, update gates).  epoch_cap > 0 bounds the epochs per feature (the reference's
+ * `while` at :742 ignores max_epochs); 0 = unbounded.  rmse_hist: NULL or f64[hist_cap];
+ * *n_hist (nullable) = epochs run over all features. */
+int mfx_funk(int min_epochs, double min_improvement, int dim, double f_init, double learning_rate,
+             double K, double overall_avg, double *u, double *v, const int32_t *ratings_index,
+             const double *ratings, const double *items_bias, const double *users_bias,
+             int64_t nnz, int nu, int ni, int update_users, int update_items, int epoch_cap,
+             double *rmse_hist, int64_t hist_cap, int64_t *n_hist);
+
+/* estimator_loop_with_learned_bias (gd_estimator.pyx:401-421). */
+int mfx_learned_bias(int min_epochs, double min_improvement, int dim, double f_init,
+                     double learning_rate, double learning_rate_users, double learning_rate_items,
+                     double K_feature, double K_bias, double overall_avg, double *u, double *v,
+                     const int32_t *ratings_index, const double *ratings, double *items_bias,
+                     double *users_bias, int64_t nnz, int nu, int ni, int epoch_cap,
+                     double *rmse_hist, int64_t hist_cap, int64_t *n_hist);
+
+/* als_wrmf (als_implicit.pyx:211-225).  *_row are the run-length arrays of
+ * mfrec/lib/datasets.py:13-32 ([0, count_0, count_1, ...], n_*row entries). */
+int mfx_als_wrmf(int nbr_epochs, int dim, double *u, double *v, const int32_t *ratings_users_row,
+                 int64_t n_urow, const int32_t *ratings_users_col,
+                 const int32_t *ratings_items_row, int64_t n_irow,
+                 const int32_t *ratings_items_col, int nu, int ni, int c_pos, double lambda);
+
+/* Batched predict / RMSE over triples (metrics.py:51-82 with the family's predict(),
+ * kind: 0 GD dot+1 (gradient_descent.py:621-631), 1 KMF linear (kmf.py:88-94),
+ * 2 KMF logistic (kmf.py:79-85), 3 GD with bias (gradient_descent.py:637-648), 4 WRMF dot).
+ * pred_out: NULL or f64[nnz]. */
+int mfx_predict_rmse(int kind, int dim, const double *u, const double *v,
+                     const int32_t *ratings_index, const double *ratings, const double *items_bias,
+                     const double *users_bias, double overall_avg, int64_t nnz, int nu, int ni,
+                     double *pred_out, double *rmse_out);
+
+/* ------------------------------------------------ resident (plan) API
+ * Same kernels, but ratings, schedule and factors stay in HBM between calls:
+ * create (schedule + upload) -> set_factors -> run_* ... -> get_factors.
+ * bench.py times run_* only (inputs resident in HBM).
+ */
+typedef struct mfx_sgd_plan mfx_sgd_plan;
+
+mfx_sgd_plan *mfx_sgd_plan_create(const int32_t *ratings_index, const double *ratings,
+                                  int64_t nnz, int nu, int ni, int dim);
+void mfx_sgd_plan_destroy(mfx_sgd_plan *p);
+/* info[0]=n_levels, [1]=max level size, [2]=launches per epoch (full-k), [3]=tail launches,
+ * [4]=ratings per wave batch, [5]=device bytes held, [6]=schedule build microseconds,
+ * [7]=launches per epoch (Funk) */
+int mfx_sgd_plan_info(const mfx_sgd_plan *p, int64_t info[8]);
+int mfx_sgd_set_factors(mfx_sgd_plan *p, const double *u, const double *v,
+                        const double *items_bias, const double *users_bias);
+int mfx_sgd_get_factors(mfx_sgd_plan *p, double *u, double *v, double *items_bias,
+                        double *users_bias);
+/* Asynchronous on the library stream; rmse_out (nullable, f64[nbr_epochs]) is filled
+ * after an internal sync at the end of the call. */
+int mfx_sgd_run_kmf(mfx_sgd_plan *p, int mode, int nbr_epochs, double learning_rate,
+                    double K_users, double K_items, double K_bias, int update_users,
+                    int update_items, double *rmse_out);
+/* One instrumented epoch: a HIP event pair around every kernel launch.
+ * kernel_ms = sum of the per-launch durations, n_launches = their number. */
+int mfx_sgd_profile_kmf(mfx_sgd_plan *p, int mode, double learning_rate, double K_users,
+                        double K_items, double K_bias, double *kernel_ms, int64_t *n_launches);
+int mfx_sgd_run_funk(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_init,
+                     double learning_rate, double K, double overall_avg, int use_bias,
+                     int update_users, int update_items, int epoch_cap, double *rmse_hist,
+                     int64_t hist_cap, int64_t *n_hist);
+int mfx_sgd_run_learned_bias(mfx_sgd_plan *p, int min_epochs, double min_improvement,
+                             double f_init, double learning_rate, double learning_rate_users,
+                             double learning_rate_items, double K_feature, double K_bias,
+                             double overall_avg, int epoch_cap, double *rmse_hist,
+                             int64_t hist_cap, int64_t *n_hist);
+
+/* ------------------------------------------------ multi-GPU (RCCL over xGMI)
+ * One process per GPU.  Rank 0 calls mfx_comm_unique_id and ships the 128
+ * bytes to the other ranks by any out-of-band channel; every rank then calls
+ * mfx_comm_init.  Users are sharded across ranks; every rank holds a full
+ * replica of the item factors.  After each local epoch:
+ *     U <- U_start + scale * allreduce_sum(U_local - U_start)   (same for items_bias)
+ * scale = 1/world (parameter averaging, the scheme of the reference's own
+ * prototype gradient_descent.py:124-211) or 1 (delta sum).
+ */
+#define MFX_UNIQUE_ID_BYTES 128
+int mfx_comm_unique_id(void *id_out);
+int mfx_comm_init(int rank, int world, const void *id);
+int mfx_comm_destroy(void);
+int mfx_comm_barrier(void);
+/* full-k SGD with the per-epoch item-delta all-reduce; the plan holds this rank's shard
+ * (its users' ratings, user ids local to the shard). */
+int mfx_sgd_run_kmf_sharded(mfx_sgd_plan *p, int mode, int nbr_epochs, double learning_rate,
+                            double K_users, double K_items, double K_bias, double scale,
+                            double *rmse_out /* local shard's online RMSE */,
+                            double *se_out /* nullable: f64[nbr_epochs] local sum of squared errors */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFX_H */

@@ -1,0 +1,199 @@
+// Multi-GPU path: one process per GPU, RCCL over xGMI (include/mfx.h "multi-GPU").
+//
+// The reference has no communication layer at all; its only precedent is the two-"machine"
+// parameter-averaging prototype (gradient_descent.py:124-211).  Here users are sharded
+// across ranks (each rank's plan holds only its users' ratings), item factors and item
+// biases are replicated, and after every local epoch
+//     U <- U_start + scale * allreduce_sum(U_local - U_start)
+// RCCL is loaded lazily (dlopen) so single-GPU users never pay for it.
+#include <dlfcn.h>
+#include <string.h>
+#include "mfx_common.h"
+
+struct mfx_sgd_plan;
+namespace mfx {
+int sgd_run_k1_hooked(mfx_sgd_plan *p, int mode, int epochs, double lr, double Ku, double Ki,
+                      double Kb, int (*hook)(mfx_sgd_plan *, int, void *), void *ctx,
+                      double *rmse_out, double *se_out);
+double *plan_U(mfx_sgd_plan *p);
+double *plan_ib(mfx_sgd_plan *p);
+int plan_ni(mfx_sgd_plan *p);
+int plan_k(mfx_sgd_plan *p);
+int plan_start_buffers(mfx_sgd_plan *p, double **U_start, double **ib_start);
+int plan_prepare_nk(mfx_sgd_plan *p);
+}  // namespace mfx
+
+namespace {
+
+// minimal slice of the RCCL (NCCL-compatible) ABI
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef void *ncclComm_t;
+enum { ncclSuccess = 0 };
+enum { ncclFloat64 = 8 };
+enum { ncclSum = 0 };
+
+struct Rccl {
+    void *h = nullptr;
+    int (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+} R;
+
+ncclComm_t g_comm = nullptr;
+int g_rank = 0, g_world = 1;
+double *g_token = nullptr;
+
+int load_rccl()
+{
+    if (R.h) return MFX_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+        R.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (R.h) break;
+    }
+    if (!R.h) return mfx::fail(MFX_E_RCCL, "cannot dlopen librccl: %s", dlerror());
+    R.GetUniqueId = (decltype(R.GetUniqueId))dlsym(R.h, "ncclGetUniqueId");
+    R.CommInitRank = (decltype(R.CommInitRank))dlsym(R.h, "ncclCommInitRank");
+    R.CommDestroy = (decltype(R.CommDestroy))dlsym(R.h, "ncclCommDestroy");
+    R.AllReduce = (decltype(R.AllReduce))dlsym(R.h, "ncclAllReduce");
+    R.GetErrorString = (decltype(R.GetErrorString))dlsym(R.h, "ncclGetErrorString");
+    if (!R.GetUniqueId || !R.CommInitRank || !R.CommDestroy || !R.AllReduce) {
+        dlclose(R.h);
+        R.h = nullptr;
+        return mfx::fail(MFX_E_RCCL, "librccl lacks a required symbol");
+    }
+    return MFX_OK;
+}
+
+#define MFX_NCCL(call)                                                                    \
+    do {                                                                                  \
+        int r_ = (call);                                                                  \
+        if (r_ != ncclSuccess)                                                            \
+            return mfx::fail(MFX_E_RCCL, "%s:%d: %s -> %s", __FILE__, __LINE__, #call,    \
+                             R.GetErrorString ? R.GetErrorString(r_) : "rccl error");     \
+    } while (0)
+
+// a <- a - b
+__global__ __launch_bounds__(256) void k_sub(double *a, const double *b, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        a[i] = a[i] - b[i];
+}
+// a <- b + scale * a ; b <- that value too (next epoch's start)
+__global__ __launch_bounds__(256) void k_combine(double *a, double *b, double scale, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const double x = b[i] + scale * a[i];
+        a[i] = x;
+        b[i] = x;
+    }
+}
+
+int grid_for(size_t n) { return (int)(n / 256 + 1 < 4096 ? n / 256 + 1 : 4096); }
+
+struct ShardCtx {
+    double scale;
+    double *U_start, *ib_start;
+};
+
+int shard_hook(mfx_sgd_plan *p, int, void *vctx)
+{
+    if (g_world <= 1) return MFX_OK;      // a single shard is the sequential algorithm itself
+    ShardCtx *c = (ShardCtx *)vctx;
+    const size_t nU = (size_t)mfx::plan_ni(p) * mfx::plan_k(p), nb = (size_t)mfx::plan_ni(p);
+    double *U = mfx::plan_U(p), *ib = mfx::plan_ib(p);
+    hipStream_t s = mfx::stream();
+    hipLaunchKernelGGL(k_sub, dim3(grid_for(nU)), dim3(256), 0, s, U, c->U_start, nU);
+    hipLaunchKernelGGL(k_sub, dim3(grid_for(nb)), dim3(256), 0, s, ib, c->ib_start, nb);
+    MFX_NCCL(R.AllReduce(U, U, nU, ncclFloat64, ncclSum, g_comm, s));
+    MFX_NCCL(R.AllReduce(ib, ib, nb, ncclFloat64, ncclSum, g_comm, s));
+    hipLaunchKernelGGL(k_combine, dim3(grid_for(nU)), dim3(256), 0, s, U, c->U_start, c->scale, nU);
+    hipLaunchKernelGGL(k_combine, dim3(grid_for(nb)), dim3(256), 0, s, ib, c->ib_start, c->scale, nb);
+    MFX_HIP(hipGetLastError());
+    return MFX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mfx_comm_unique_id(void *id_out)
+{
+    if (!id_out) return mfx::fail(MFX_E_ARG, "mfx_comm_unique_id: NULL");
+    int rc = load_rccl();
+    if (rc) return rc;
+    ncclUniqueId id;
+    MFX_NCCL(R.GetUniqueId(&id));
+    static_assert(sizeof(id) == MFX_UNIQUE_ID_BYTES, "unique id size");
+    memcpy(id_out, &id, sizeof(id));
+    return MFX_OK;
+}
+
+int mfx_comm_init(int rank, int world, const void *id)
+{
+    if (world < 1 || rank < 0 || rank >= world || (world > 1 && !id))
+        return mfx::fail(MFX_E_ARG, "mfx_comm_init: rank %d / world %d", rank, world);
+    int rc = mfx::ensure_init();
+    if (rc) return rc;
+    g_rank = rank;
+    g_world = world;
+    if (world == 1) return MFX_OK;
+    rc = load_rccl();
+    if (rc) return rc;
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof(uid));
+    MFX_NCCL(R.CommInitRank(&g_comm, world, uid, rank));
+    if (!g_token) MFX_HIP(hipMalloc((void **)&g_token, sizeof(double)));
+    return MFX_OK;
+}
+
+int mfx_comm_destroy(void)
+{
+    if (g_comm) {
+        (void)hipStreamSynchronize(mfx::stream());
+        R.CommDestroy(g_comm);
+        g_comm = nullptr;
+    }
+    if (g_token) {
+        (void)hipFree(g_token);
+        g_token = nullptr;
+    }
+    g_world = 1;
+    g_rank = 0;
+    return MFX_OK;
+}
+
+int mfx_comm_barrier(void)
+{
+    if (!mfx::ready()) return MFX_OK;
+    if (g_world > 1 && g_comm) {
+        MFX_HIP(hipMemsetAsync(g_token, 0, sizeof(double), mfx::stream()));
+        MFX_NCCL(R.AllReduce(g_token, g_token, 1, ncclFloat64, ncclSum, g_comm, mfx::stream()));
+    }
+    MFX_HIP(hipStreamSynchronize(mfx::stream()));
+    return MFX_OK;
+}
+
+int mfx_sgd_run_kmf_sharded(mfx_sgd_plan *p, int mode, int nbr_epochs, double lr, double Ku,
+                            double Ki, double Kb, double scale, double *rmse_out, double *se_out)
+{
+    if (!p) return mfx::fail(MFX_E_ARG, "mfx_sgd_run_kmf_sharded: NULL plan");
+    if (g_world > 1 && !g_comm) return mfx::fail(MFX_E_STATE, "mfx_comm_init has not been called");
+    ShardCtx c{scale, nullptr, nullptr};
+    if (g_world > 1) {
+        int rc = mfx::plan_prepare_nk(p);
+        if (!rc) rc = mfx::plan_start_buffers(p, &c.U_start, &c.ib_start);
+        if (rc) return rc;
+        const size_t nU = (size_t)mfx::plan_ni(p) * mfx::plan_k(p), nb = (size_t)mfx::plan_ni(p);
+        MFX_HIP(hipMemcpyAsync(c.U_start, mfx::plan_U(p), nU * sizeof(double),
+                               hipMemcpyDeviceToDevice, mfx::stream()));
+        MFX_HIP(hipMemcpyAsync(c.ib_start, mfx::plan_ib(p), nb * sizeof(double),
+                               hipMemcpyDeviceToDevice, mfx::stream()));
+    }
+    return mfx::sgd_run_k1_hooked(p, mode, nbr_epochs, lr, Ku, Ki, Kb, shard_hook, &c, rmse_out,
+                                  se_out);
+}
+
+}  // extern "C"

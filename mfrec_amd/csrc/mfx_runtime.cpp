@@ -1,0 +1,112 @@
+// Runtime plumbing of libmfx.so: error string, device binding, stream, event stopwatch.
+#include <string.h>
+#include "mfx_common.h"
+
+namespace {
+char g_err[1024] = "";
+int g_code = 0;
+hipStream_t g_stream = nullptr;
+bool g_ready = false;
+int g_device = -1;
+hipEvent_t g_t0 = nullptr, g_t1 = nullptr;
+}  // namespace
+
+namespace mfx {
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    g_code = code;
+    return code;
+}
+int last_code() { return g_code; }
+hipStream_t stream() { return g_stream; }
+bool ready() { return g_ready; }
+int ensure_init() { return g_ready ? MFX_OK : mfx_init(0); }
+}  // namespace mfx
+
+extern "C" {
+
+int mfx_version(void) { return 100; }
+const char *mfx_last_error(void) { return g_err; }
+
+int mfx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int mfx_init(int device)
+{
+    if (g_ready && device == g_device) return MFX_OK;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        return mfx::fail(MFX_E_HIP,
+                         "mfx_init: no HIP device available (%s); libmfx has no CPU fallback",
+                         e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    }
+    if (device < 0 || device >= n) {
+        return mfx::fail(MFX_E_ARG, "mfx_init: device %d outside [0,%d)", device, n);
+    }
+    MFX_HIP(hipSetDevice(device));
+    if (g_stream) {
+        (void)hipStreamDestroy(g_stream);
+        g_stream = nullptr;
+    }
+    MFX_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    if (!g_t0) MFX_HIP(hipEventCreate(&g_t0));
+    if (!g_t1) MFX_HIP(hipEventCreate(&g_t1));
+    g_device = device;
+    g_ready = true;
+    return MFX_OK;
+}
+
+int mfx_sync(void)
+{
+    if (!g_ready) return MFX_OK;
+    MFX_HIP(hipStreamSynchronize(g_stream));
+    return MFX_OK;
+}
+
+int mfx_device_name(char *buf, int buflen)
+{
+    if (!buf || buflen <= 0) return MFX_E_ARG;
+    int rc = mfx::ensure_init();
+    if (rc) return rc;
+    hipDeviceProp_t p;
+    MFX_HIP(hipGetDeviceProperties(&p, g_device));
+    snprintf(buf, buflen, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    return MFX_OK;
+}
+
+int mfx_timer_start(void)
+{
+    int rc = mfx::ensure_init();
+    if (rc) return rc;
+    MFX_HIP(hipEventRecord(g_t0, g_stream));
+    return MFX_OK;
+}
+
+int mfx_timer_stop(double *elapsed_ms)
+{
+    if (!g_ready || !elapsed_ms) return MFX_E_ARG;
+    MFX_HIP(hipEventRecord(g_t1, g_stream));
+    MFX_HIP(hipEventSynchronize(g_t1));
+    float ms = 0.f;
+    MFX_HIP(hipEventElapsedTime(&ms, g_t0, g_t1));
+    *elapsed_ms = (double)ms;
+    return MFX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,70 @@
+// Host-side dependency-level schedule (include/mfx.h "host-side scheduling").
+//
+// The reference applies ratings strictly in array order (kmf_train.pyx:243,
+// gd_estimator.pyx:745).  Two updates commute bit-for-bit iff they share
+// neither user nor item, so the rating sequence is a DAG whose longest-path
+// layering ("levels") is a conflict-free parallel schedule that reproduces the
+// sequential result exactly ("Hard parts").
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "mfx_common.h"
+
+extern "C" int mfx_schedule_levels(const int32_t *idx, int64_t nnz, int nu, int ni,
+                                   int32_t *level_out, int64_t *n_levels_out)
+{
+    if (!idx || !level_out || nnz < 0 || nu < 0 || ni < 0) {
+        return mfx::fail(MFX_E_ARG, "mfx_schedule_levels: bad argument");
+    }
+    std::vector<int32_t> lu, li;
+    try {
+        lu.assign((size_t)nu, 0);
+        li.assign((size_t)ni, 0);
+    } catch (...) {
+        return mfx::fail(MFX_E_NOMEM, "mfx_schedule_levels: out of host memory");
+    }
+    int32_t top = 0;
+    for (int64_t t = 0; t < nnz; ++t) {
+        const int32_t a = idx[2 * t], b = idx[2 * t + 1];
+        if (a < 0 || a >= nu || b < 0 || b >= ni) {
+            return mfx::fail(MFX_E_RANGE, "rating %lld: (user %d, item %d) outside [0,%d) x [0,%d)",
+                           (long long)t, a, b, nu, ni);
+        }
+        const int32_t L = 1 + (lu[a] > li[b] ? lu[a] : li[b]);
+        level_out[t] = L;
+        lu[a] = L;
+        li[b] = L;
+        if (L > top) top = L;
+    }
+    if (n_levels_out) *n_levels_out = top;
+    return MFX_OK;
+}
+
+// Stable counting sort by level: perm[j] = original position of the j-th rating in
+// level-major order; level_off[l] .. level_off[l+1] is level l+1's slice.
+extern "C" int mfx_schedule_permutation(const int32_t *level, int64_t nnz, int64_t n_levels,
+                                        int64_t *perm_out, int64_t *level_off_out)
+{
+    if (!level || !perm_out || !level_off_out || nnz < 0 || n_levels < 0) {
+        return mfx::fail(MFX_E_ARG, "mfx_schedule_permutation: bad argument");
+    }
+    for (int64_t l = 0; l <= n_levels; ++l) level_off_out[l] = 0;
+    for (int64_t t = 0; t < nnz; ++t) {
+        const int32_t L = level[t];
+        if (L < 1 || L > n_levels) {
+            return mfx::fail(MFX_E_RANGE, "mfx_schedule_permutation: level %d outside [1,%lld]", L,
+                           (long long)n_levels);
+        }
+        ++level_off_out[L];
+    }
+    for (int64_t l = 0; l < n_levels; ++l) level_off_out[l + 1] += level_off_out[l];
+    // level_off_out[l] now = end of level l (1-based) = start of level l+1
+    std::vector<int64_t> cur;
+    try {
+        cur.assign(level_off_out, level_off_out + n_levels + 1);
+    } catch (...) {
+        return mfx::fail(MFX_E_NOMEM, "mfx_schedule_permutation: out of host memory");
+    }
+    for (int64_t t = 0; t < nnz; ++t) perm_out[cur[level[t] - 1]++] = t;
+    return MFX_OK;
+}

@@ -1,0 +1,664 @@
+// Host side of the SGD families: plan (schedule + HBM-resident data), launches, drop-ins.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <chrono>
+#include <vector>
+#include "mfx_sgd_kernels.h"
+
+using namespace mfx;
+
+// ------------------------------------------------------------------------------------
+// plan
+// ------------------------------------------------------------------------------------
+struct mfx_sgd_plan {
+    int64_t nnz = 0;
+    int nu = 0, ni = 0, k = 0;
+    int64_t n_levels = 0, max_level = 0;
+    std::vector<int64_t> level_off;      // n_levels + 1
+    std::vector<int64_t> k1_wave_off;    // per level: first se_partial slot (full-k kernels)
+    std::vector<int64_t> k2_wave_off;    // per level (Funk kernels)
+    int64_t k1_waves = 0, k2_waves = 0;
+    int64_t sched_us = 0;
+    size_t dev_bytes = 0;
+
+    Rec *d_recs = nullptr;               // level-major
+    double *d_U_km = nullptr, *d_V_km = nullptr;   // feature-major [k][n] (host layout, Funk)
+    double *d_U_nk = nullptr, *d_V_nk = nullptr;   // row-major [n][k] (full-k kernels)
+    double *d_ib = nullptr, *d_ub = nullptr;
+    double *d_cache = nullptr;           // Funk residual cache (lazy)
+    double *d_se_partial = nullptr;
+    double *d_se_epoch = nullptr;        // per-epoch sums (capacity se_cap)
+    int *d_counter = nullptr;
+    int64_t se_cap = 0;
+    double *d_U_start = nullptr, *d_ib_start = nullptr;   // sharded mode (lazy)
+    bool have_factors = false;
+    bool nk_current = false, km_current = false;
+
+    // cached hipGraph of one full-k epoch
+    hipGraphExec_t graph = nullptr;
+    K1Params graph_params{};
+    int graph_mode = -1;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(mfx_sgd_plan *p, T **ptr, size_t n)
+{
+    *ptr = nullptr;
+    const size_t bytes = (n ? n : 1) * sizeof(T);
+    hipError_t e = hipMalloc((void **)ptr, bytes);
+    if (e != hipSuccess) {
+        return fail(MFX_E_NOMEM, "hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
+    }
+    if (p) p->dev_bytes += bytes;
+    return MFX_OK;
+}
+
+int ensure_se_cap(mfx_sgd_plan *p, int64_t epochs)
+{
+    if (epochs <= p->se_cap) return MFX_OK;
+    if (p->d_se_epoch) (void)hipFree(p->d_se_epoch);
+    p->d_se_epoch = nullptr;
+    int64_t cap = epochs < 64 ? 64 : epochs;
+    int rc = dev_alloc(p, &p->d_se_epoch, (size_t)cap);
+    if (rc) return rc;
+    p->se_cap = cap;
+    return MFX_OK;
+}
+
+void drop_graph(mfx_sgd_plan *p)
+{
+    if (p->graph) (void)hipGraphExecDestroy(p->graph);
+    p->graph = nullptr;
+    p->graph_mode = -1;
+}
+
+int transpose(const double *in, double *out, int rows, int cols)
+{
+    if (rows == 0 || cols == 0) return MFX_OK;
+    dim3 grid(ceil_div(cols, 32), ceil_div(rows, 32));
+    hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, stream(), in, out, rows, cols);
+    MFX_HIP(hipGetLastError());
+    return MFX_OK;
+}
+
+int to_nk(mfx_sgd_plan *p)
+{
+    if (p->nk_current) return MFX_OK;
+    int rc = transpose(p->d_U_km, p->d_U_nk, p->k, p->ni);
+    if (!rc) rc = transpose(p->d_V_km, p->d_V_nk, p->k, p->nu);
+    if (!rc) p->nk_current = true;
+    return rc;
+}
+
+int to_km(mfx_sgd_plan *p)
+{
+    if (p->km_current) return MFX_OK;
+    int rc = transpose(p->d_U_nk, p->d_U_km, p->ni, p->k);
+    if (!rc) rc = transpose(p->d_V_nk, p->d_V_km, p->nu, p->k);
+    if (!rc) p->km_current = true;
+    return rc;
+}
+
+size_t k1_lds_bytes(int k)
+{
+    return (size_t)kWaves * k1_batch(k) * (size_t)(k | 1) * sizeof(double);
+}
+
+// pick the kernel instantiation for (k, mode)
+template <int MODE>
+void *k1_pick(int k)
+{
+    // must agree with k1_batch(k)
+    if (k <= 8) return (void *)k1_level<8, 1, 16, MODE>;
+    if (k <= 16) return (void *)k1_level<16, 1, 16, MODE>;
+    if (k <= 32) return (void *)k1_level<32, 1, 16, MODE>;
+    if (k <= 64) return (void *)k1_level<64, 1, 16, MODE>;
+    if (k <= 128) return (void *)k1_level<64, 2, 8, MODE>;
+    if (k <= 256) return (void *)k1_level<64, 4, 4, MODE>;
+    return (void *)k1_level<64, 8, 2, MODE>;
+}
+
+void *k1_kernel(int k, int mode)
+{
+    switch (mode) {
+    case K1_LINEAR: return k1_pick<K1_LINEAR>(k);
+    case K1_LOGISTIC: return k1_pick<K1_LOGISTIC>(k);
+    default: return k1_pick<K1_LEARNED>(k);
+    }
+}
+
+constexpr int kMaxK = 512;
+
+// enqueue one full-k epoch (all levels + the SE reduction) on the library stream.
+// ev != nullptr: record an event pair around every level launch (profiling epoch).
+int enqueue_k1_epoch(mfx_sgd_plan *p, int mode, const K1Params &P, std::vector<hipEvent_t> *ev)
+{
+    void *fn = k1_kernel(p->k, mode);
+    const size_t lds = k1_lds_bytes(p->k);
+    const int batch = k1_batch(p->k);
+    size_t e = 0;
+    for (int64_t l = 0; l < p->n_levels; ++l) {
+        const int64_t start = p->level_off[l];
+        const int count = (int)(p->level_off[l + 1] - start);
+        if (count <= 0) continue;
+        const int waves = ceil_div(count, batch);
+        const int blocks = ceil_div(waves, kWaves);
+        int64_t woff = p->k1_wave_off[l];
+        K1Params Pl = P;
+        int cnt = count;
+        int64_t st = start;
+        void *args[] = {&Pl, &st, &cnt, &woff};
+        if (ev) MFX_HIP(hipEventRecord((*ev)[e++], stream()));
+        MFX_HIP(hipLaunchKernel(fn, dim3(blocks), dim3(kWaves * 64), args, lds, stream()));
+        if (ev) MFX_HIP(hipEventRecord((*ev)[e++], stream()));
+    }
+    hipLaunchKernelGGL(k_reduce_se, dim3(1), dim3(1024), 0, stream(), p->d_se_partial, p->k1_waves,
+                       p->d_se_epoch, p->d_counter);
+    MFX_HIP(hipGetLastError());
+    return MFX_OK;
+}
+
+bool same_params(const K1Params &a, const K1Params &b)
+{
+    return memcmp(&a, &b, sizeof(K1Params)) == 0;
+}
+
+int use_graph()
+{
+    const char *e = getenv("MFX_GRAPH");
+    return !(e && e[0] == '0');
+}
+
+int check_plan(const mfx_sgd_plan *p, const char *who)
+{
+    if (!p) {
+        return fail(MFX_E_ARG, "%s: NULL plan", who);
+    }
+    if (!p->have_factors) {
+        return fail(MFX_E_STATE, "%s: mfx_sgd_set_factors has not been called", who);
+    }
+    return MFX_OK;
+}
+
+K1Params k1_params(mfx_sgd_plan *p, double lr, double Ku, double Ki, double Kb, int upd_u,
+                   int upd_i)
+{
+    K1Params P;
+    memset(&P, 0, sizeof(P));
+    P.recs = p->d_recs;
+    P.U = p->d_U_nk;
+    P.V = p->d_V_nk;
+    P.ib = p->d_ib;
+    P.ub = p->d_ub;
+    P.se_partial = p->d_se_partial;
+    P.k = p->k;
+    P.upd_u = upd_u ? 1 : 0;
+    P.upd_i = upd_i ? 1 : 0;
+    P.lr = lr;
+    P.Ku = Ku;
+    P.Ki = Ki;
+    P.Kb = Kb;
+    P.f = -1;
+    return P;
+}
+
+// run `epochs` full-k epochs; hook (nullable) is called after each epoch's launches have
+// been enqueued (sharded mode enqueues its all-reduce there).
+template <typename Hook>
+int run_k1_epochs(mfx_sgd_plan *p, int mode, int epochs, const K1Params &P, Hook &&hook)
+{
+    int rc = ensure_se_cap(p, epochs);
+    if (rc) return rc;
+    rc = to_nk(p);
+    if (rc) return rc;
+    p->km_current = false;
+    MFX_HIP(hipMemsetAsync(p->d_counter, 0, sizeof(int), stream()));
+    const bool graph = use_graph();
+    if (graph && !(p->graph && p->graph_mode == mode && same_params(p->graph_params, P))) {
+        drop_graph(p);
+        hipGraph_t g = nullptr;
+        MFX_HIP(hipStreamBeginCapture(stream(), hipStreamCaptureModeThreadLocal));
+        rc = enqueue_k1_epoch(p, mode, P, nullptr);
+        hipError_t e = hipStreamEndCapture(stream(), &g);
+        if (rc) {
+            if (g) (void)hipGraphDestroy(g);
+            return rc;
+        }
+        if (e != hipSuccess) {
+            return fail(MFX_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+        }
+        e = hipGraphInstantiate(&p->graph, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e != hipSuccess) {
+            p->graph = nullptr;
+            return fail(MFX_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+        }
+        p->graph_mode = mode;
+        p->graph_params = P;
+    }
+    for (int ep = 0; ep < epochs; ++ep) {
+        if (graph) MFX_HIP(hipGraphLaunch(p->graph, stream()));
+        else {
+            rc = enqueue_k1_epoch(p, mode, P, nullptr);
+            if (rc) return rc;
+        }
+        rc = hook(ep);
+        if (rc) return rc;
+    }
+    return MFX_OK;
+}
+
+int fetch_rmse(mfx_sgd_plan *p, int64_t n, double *rmse_out, double *se_out)
+{
+    MFX_HIP(hipStreamSynchronize(stream()));
+    if ((!rmse_out && !se_out) || n <= 0) return MFX_OK;
+    std::vector<double> se((size_t)n);
+    MFX_HIP(hipMemcpy(se.data(), p->d_se_epoch, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n; ++i) {
+        if (se_out) se_out[i] = se[i];
+        if (rmse_out) rmse_out[i] = sqrt(se[i] / (double)p->nnz);
+    }
+    return MFX_OK;
+}
+
+}  // namespace
+
+// exposed to mfx_comm.hip (sharded mode)
+namespace mfx {
+int sgd_run_k1_hooked(mfx_sgd_plan *p, int mode, int epochs, double lr, double Ku, double Ki,
+                      double Kb, int (*hook)(mfx_sgd_plan *, int, void *), void *ctx,
+                      double *rmse_out, double *se_out)
+{
+    int rc = check_plan(p, "mfx_sgd_run_kmf_sharded");
+    if (rc) return rc;
+    K1Params P = k1_params(p, lr, Ku, Ki, Kb, 1, 1);
+    rc = run_k1_epochs(p, mode, epochs, P, [&](int ep) { return hook ? hook(p, ep, ctx) : MFX_OK; });
+    if (rc) return rc;
+    return fetch_rmse(p, epochs, rmse_out, se_out);
+}
+double *plan_U(mfx_sgd_plan *p) { return p->d_U_nk; }
+double *plan_ib(mfx_sgd_plan *p) { return p->d_ib; }
+int plan_ni(mfx_sgd_plan *p) { return p->ni; }
+int plan_k(mfx_sgd_plan *p) { return p->k; }
+int plan_start_buffers(mfx_sgd_plan *p, double **U_start, double **ib_start)
+{
+    if (!p->d_U_start) {
+        int rc = dev_alloc(p, &p->d_U_start, (size_t)p->ni * p->k);
+        if (!rc) rc = dev_alloc(p, &p->d_ib_start, (size_t)p->ni);
+        if (rc) return rc;
+    }
+    *U_start = p->d_U_start;
+    *ib_start = p->d_ib_start;
+    return MFX_OK;
+}
+int plan_prepare_nk(mfx_sgd_plan *p) { return to_nk(p); }
+}  // namespace mfx
+
+extern "C" {
+
+mfx_sgd_plan *mfx_sgd_plan_create(const int32_t *idx, const double *r, int64_t nnz, int nu, int ni,
+                                  int dim)
+{
+    if (!idx || !r || nnz < 0 || nu <= 0 || ni <= 0 || dim < 1 || dim > kMaxK) {
+        fail(MFX_E_ARG, "mfx_sgd_plan_create: bad argument (nnz=%lld nu=%d ni=%d k=%d; 1 <= k <= %d)",
+             (long long)nnz, nu, ni, dim, kMaxK);
+        return nullptr;
+    }
+    if (ensure_init()) return nullptr;
+    mfx_sgd_plan *p = new (std::nothrow) mfx_sgd_plan();
+    if (!p) {
+        fail(MFX_E_NOMEM, "mfx_sgd_plan_create: out of host memory");
+        return nullptr;
+    }
+    p->nnz = nnz;
+    p->nu = nu;
+    p->ni = ni;
+    p->k = dim;
+    auto bail = [&]() -> mfx_sgd_plan * {
+        mfx_sgd_plan_destroy(p);
+        return nullptr;
+    };
+    try {
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<int32_t> level((size_t)(nnz ? nnz : 1));
+        if (mfx_schedule_levels(idx, nnz, nu, ni, level.data(), &p->n_levels)) return bail();
+        std::vector<int64_t> perm((size_t)(nnz ? nnz : 1));
+        p->level_off.assign((size_t)p->n_levels + 1, 0);
+        if (mfx_schedule_permutation(level.data(), nnz, p->n_levels, perm.data(),
+                                     p->level_off.data()))
+            return bail();
+        std::vector<Rec> recs((size_t)(nnz ? nnz : 1));
+        for (int64_t j = 0; j < nnz; ++j) {
+            const int64_t t = perm[j];
+            recs[j].user = idx[2 * t];
+            recs[j].item = idx[2 * t + 1];
+            recs[j].r = r[t];
+        }
+        p->k1_wave_off.assign((size_t)p->n_levels + 1, 0);
+        p->k2_wave_off.assign((size_t)p->n_levels + 1, 0);
+        for (int64_t l = 0; l < p->n_levels; ++l) {
+            const int64_t c = p->level_off[l + 1] - p->level_off[l];
+            if (c > p->max_level) p->max_level = c;
+            // slots are per launched wave (blocks are whole)
+            p->k1_wave_off[l + 1] = p->k1_wave_off[l] +
+                                    ceil_div(ceil_div(c, (int64_t)k1_batch(dim)), (int64_t)kWaves) * kWaves;
+            p->k2_wave_off[l + 1] = p->k2_wave_off[l] + ceil_div(c, (int64_t)256) * 4;
+        }
+        p->k1_waves = p->k1_wave_off[p->n_levels];
+        p->k2_waves = p->k2_wave_off[p->n_levels];
+        p->sched_us = std::chrono::duration_cast<std::chrono::microseconds>(
+                          std::chrono::steady_clock::now() - t0).count();
+
+        if (dev_alloc(p, &p->d_recs, (size_t)nnz)) return bail();
+        if (dev_alloc(p, &p->d_U_km, (size_t)ni * dim) || dev_alloc(p, &p->d_V_km, (size_t)nu * dim) ||
+            dev_alloc(p, &p->d_U_nk, (size_t)ni * dim) || dev_alloc(p, &p->d_V_nk, (size_t)nu * dim) ||
+            dev_alloc(p, &p->d_ib, (size_t)ni) || dev_alloc(p, &p->d_ub, (size_t)nu) ||
+            dev_alloc(p, &p->d_counter, 1))
+            return bail();
+        const int64_t np = p->k1_waves > p->k2_waves ? p->k1_waves : p->k2_waves;
+        if (dev_alloc(p, &p->d_se_partial, (size_t)np)) return bail();
+        // slots of waves that exit early (block padding) must read as 0
+        if (hipMemset(p->d_se_partial, 0, (size_t)(np ? np : 1) * sizeof(double)) != hipSuccess ||
+            hipMemcpy(p->d_recs, recs.data(), (size_t)nnz * sizeof(Rec), hipMemcpyHostToDevice) != hipSuccess) {
+            fail(MFX_E_HIP, "mfx_sgd_plan_create: upload failed: %s", hipGetErrorString(hipGetLastError()));
+            return bail();
+        }
+        if (ensure_se_cap(p, 64)) return bail();
+    } catch (const std::bad_alloc &) {
+        mfx::fail(MFX_E_NOMEM, "mfx_sgd_plan_create: out of host memory");
+        return bail();
+    }
+    return p;
+}
+
+void mfx_sgd_plan_destroy(mfx_sgd_plan *p)
+{
+    if (!p) return;
+    if (ready()) (void)hipStreamSynchronize(stream());
+    drop_graph(p);
+    void *ptrs[] = {p->d_recs, p->d_U_km, p->d_V_km, p->d_U_nk, p->d_V_nk, p->d_ib, p->d_ub,
+                    p->d_cache, p->d_se_partial, p->d_se_epoch, p->d_counter, p->d_U_start,
+                    p->d_ib_start};
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    delete p;
+}
+
+int mfx_sgd_plan_info(const mfx_sgd_plan *p, int64_t info[8])
+{
+    if (!p || !info) return MFX_E_ARG;
+    int64_t launches = 0;
+    for (int64_t l = 0; l < p->n_levels; ++l)
+        if (p->level_off[l + 1] > p->level_off[l]) ++launches;
+    info[0] = p->n_levels;
+    info[1] = p->max_level;
+    info[2] = launches;
+    info[3] = 0;
+    info[4] = k1_batch(p->k);
+    info[5] = (int64_t)p->dev_bytes;
+    info[6] = p->sched_us;
+    info[7] = launches;
+    return MFX_OK;
+}
+
+int mfx_sgd_set_factors(mfx_sgd_plan *p, const double *u, const double *v, const double *ib,
+                        const double *ub)
+{
+    if (!p || !u || !v) {
+        return fail(MFX_E_ARG, "mfx_sgd_set_factors: NULL argument");
+    }
+    const size_t ku = (size_t)p->k * p->ni * sizeof(double), kv = (size_t)p->k * p->nu * sizeof(double);
+    MFX_HIP(hipStreamSynchronize(stream()));
+    MFX_HIP(hipMemcpy(p->d_U_km, u, ku, hipMemcpyHostToDevice));
+    MFX_HIP(hipMemcpy(p->d_V_km, v, kv, hipMemcpyHostToDevice));
+    if (ib) MFX_HIP(hipMemcpy(p->d_ib, ib, (size_t)p->ni * sizeof(double), hipMemcpyHostToDevice));
+    else MFX_HIP(hipMemset(p->d_ib, 0, (size_t)p->ni * sizeof(double)));
+    if (ub) MFX_HIP(hipMemcpy(p->d_ub, ub, (size_t)p->nu * sizeof(double), hipMemcpyHostToDevice));
+    else MFX_HIP(hipMemset(p->d_ub, 0, (size_t)p->nu * sizeof(double)));
+    p->km_current = true;
+    p->nk_current = false;
+    p->have_factors = true;
+    return MFX_OK;
+}
+
+int mfx_sgd_get_factors(mfx_sgd_plan *p, double *u, double *v, double *ib, double *ub)
+{
+    int rc = check_plan(p, "mfx_sgd_get_factors");
+    if (rc) return rc;
+    rc = to_km(p);
+    if (rc) return rc;
+    MFX_HIP(hipStreamSynchronize(stream()));
+    if (u) MFX_HIP(hipMemcpy(u, p->d_U_km, (size_t)p->k * p->ni * sizeof(double), hipMemcpyDeviceToHost));
+    if (v) MFX_HIP(hipMemcpy(v, p->d_V_km, (size_t)p->k * p->nu * sizeof(double), hipMemcpyDeviceToHost));
+    if (ib) MFX_HIP(hipMemcpy(ib, p->d_ib, (size_t)p->ni * sizeof(double), hipMemcpyDeviceToHost));
+    if (ub) MFX_HIP(hipMemcpy(ub, p->d_ub, (size_t)p->nu * sizeof(double), hipMemcpyDeviceToHost));
+    return MFX_OK;
+}
+
+int mfx_sgd_run_kmf(mfx_sgd_plan *p, int mode, int nbr_epochs, double lr, double Ku, double Ki,
+                    double Kb, int upd_u, int upd_i, double *rmse_out)
+{
+    int rc = check_plan(p, "mfx_sgd_run_kmf");
+    if (rc) return rc;
+    if (mode != MFX_MODE_LINEAR && mode != MFX_MODE_LOGISTIC) {
+        return fail(MFX_E_ARG, "mfx_sgd_run_kmf: mode %d", mode);
+    }
+    if (nbr_epochs <= 0) return MFX_OK;
+    K1Params P = k1_params(p, lr, Ku, Ki, Kb, upd_u, upd_i);
+    rc = run_k1_epochs(p, mode, nbr_epochs, P, [](int) { return MFX_OK; });
+    if (rc) return rc;
+    return fetch_rmse(p, nbr_epochs, rmse_out, nullptr);
+}
+
+int mfx_sgd_profile_kmf(mfx_sgd_plan *p, int mode, double lr, double Ku, double Ki, double Kb,
+                        double *kernel_ms, int64_t *n_launches)
+{
+    int rc = check_plan(p, "mfx_sgd_profile_kmf");
+    if (rc) return rc;
+    rc = ensure_se_cap(p, 1);
+    if (!rc) rc = to_nk(p);
+    if (rc) return rc;
+    p->km_current = false;
+    K1Params P = k1_params(p, lr, Ku, Ki, Kb, 1, 1);
+    int64_t launches = 0;
+    for (int64_t l = 0; l < p->n_levels; ++l)
+        if (p->level_off[l + 1] > p->level_off[l]) ++launches;
+    std::vector<hipEvent_t> ev((size_t)launches * 2, nullptr);
+    for (auto &e : ev) MFX_HIP(hipEventCreate(&e));
+    MFX_HIP(hipMemsetAsync(p->d_counter, 0, sizeof(int), stream()));
+    rc = enqueue_k1_epoch(p, mode, P, &ev);
+    if (!rc) {
+        MFX_HIP(hipStreamSynchronize(stream()));
+        double tot = 0.0;
+        for (int64_t i = 0; i < launches; ++i) {
+            float ms = 0.f;
+            MFX_HIP(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+            tot += ms;
+        }
+        if (kernel_ms) *kernel_ms = tot;
+        if (n_launches) *n_launches = launches;
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    return rc;
+}
+
+// ---- Funk: per-feature passes with the data-dependent stopping rule (host-driven) ----
+int mfx_sgd_run_funk(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_init,
+                     double lr, double K, double mu, int use_bias, int upd_u, int upd_i,
+                     int epoch_cap, double *rmse_hist, int64_t hist_cap, int64_t *n_hist)
+{
+    int rc = check_plan(p, "mfx_sgd_run_funk");
+    if (rc) return rc;
+    rc = to_km(p);
+    if (rc) return rc;
+    p->nk_current = false;
+    if (!p->d_cache) {
+        rc = dev_alloc(p, &p->d_cache, (size_t)p->nnz);
+        if (rc) return rc;
+    }
+    MFX_HIP(hipMemsetAsync(p->d_cache, 0, (size_t)(p->nnz ? p->nnz : 1) * sizeof(double), stream()));
+    double rmse = 2.0, rmse_last = 0.0;
+    int64_t nh = 0;
+    K2Params P;
+    memset(&P, 0, sizeof(P));
+    P.recs = p->d_recs;
+    P.cache = p->d_cache;
+    P.ib = use_bias ? p->d_ib : nullptr;
+    P.ub = use_bias ? p->d_ub : nullptr;
+    P.se_partial = p->d_se_partial;
+    P.lr = lr;
+    P.K = K;
+    P.mu = mu;
+    P.upd_u = upd_u ? 1 : 0;
+    P.upd_i = upd_i ? 1 : 0;
+    const int commit_blocks = (int)(p->nnz ? (ceil_div(p->nnz, (int64_t)256) < 4096 ? ceil_div(p->nnz, (int64_t)256) : 4096) : 1);
+    for (int f = 0; f < p->k; ++f) {
+        P.uf = p->d_U_km + (size_t)f * p->ni;
+        P.vf = p->d_V_km + (size_t)f * p->nu;
+        P.trail = (p->k - f - 1) * f_init * f_init;          // gd_estimator.pyx:70
+        int epoch = 0;
+        while (epoch < min_epochs || rmse <= rmse_last - min_improvement) {
+            if (epoch_cap > 0 && epoch >= epoch_cap) break;
+            rmse_last = rmse;
+            MFX_HIP(hipMemsetAsync(p->d_counter, 0, sizeof(int), stream()));
+            for (int64_t l = 0; l < p->n_levels; ++l) {
+                const int64_t start = p->level_off[l];
+                const int count = (int)(p->level_off[l + 1] - start);
+                if (count <= 0) continue;
+                hipLaunchKernelGGL(k2_level, dim3(ceil_div(count, 256)), dim3(256), 0, stream(), P,
+                                   start, count, p->k2_wave_off[l]);
+            }
+            hipLaunchKernelGGL(k_reduce_se, dim3(1), dim3(1024), 0, stream(), p->d_se_partial,
+                               p->k2_waves, p->d_se_epoch, p->d_counter);
+            MFX_HIP(hipGetLastError());
+            double se = 0.0;
+            MFX_HIP(hipMemcpyAsync(&se, p->d_se_epoch, sizeof(double), hipMemcpyDeviceToHost, stream()));
+            MFX_HIP(hipStreamSynchronize(stream()));
+            rmse = sqrt(se / (double)p->nnz);
+            if (rmse_hist && nh < hist_cap) rmse_hist[nh] = rmse;
+            ++nh;
+            ++epoch;
+        }
+        K2Params Pc = P;
+        Pc.trail = 0.0;
+        hipLaunchKernelGGL(k2_commit, dim3(commit_blocks), dim3(256), 0, stream(), Pc, p->nnz);
+        MFX_HIP(hipGetLastError());
+    }
+    MFX_HIP(hipStreamSynchronize(stream()));
+    if (n_hist) *n_hist = nh;
+    return MFX_OK;
+}
+
+int mfx_sgd_run_learned_bias(mfx_sgd_plan *p, int min_epochs, double min_improvement,
+                             double f_init, double lr, double lr_users, double lr_items,
+                             double K_feature, double K_bias, double mu, int epoch_cap,
+                             double *rmse_hist, int64_t hist_cap, int64_t *n_hist)
+{
+    int rc = check_plan(p, "mfx_sgd_run_learned_bias");
+    if (rc) return rc;
+    rc = to_nk(p);
+    if (rc) return rc;
+    p->km_current = false;
+    double rmse = 2.0, rmse_last = 0.0;
+    int64_t nh = 0;
+    K1Params P = k1_params(p, lr, K_feature, K_feature, K_bias, 1, 1);
+    P.lr_u = lr_users;
+    P.lr_i = lr_items;
+    P.mu = mu;
+    for (int f = 0; f < p->k; ++f) {
+        P.f = f;
+        P.trail = (p->k - f - 1) * f_init * f_init;
+        int epoch = 0;
+        while (epoch < min_epochs || rmse <= rmse_last - min_improvement) {
+            if (epoch_cap > 0 && epoch >= epoch_cap) break;
+            rmse_last = rmse;
+            MFX_HIP(hipMemsetAsync(p->d_counter, 0, sizeof(int), stream()));
+            rc = enqueue_k1_epoch(p, K1_LEARNED, P, nullptr);
+            if (rc) return rc;
+            double se = 0.0;
+            MFX_HIP(hipMemcpyAsync(&se, p->d_se_epoch, sizeof(double), hipMemcpyDeviceToHost, stream()));
+            MFX_HIP(hipStreamSynchronize(stream()));
+            rmse = sqrt(se / (double)p->nnz);
+            if (rmse_hist && nh < hist_cap) rmse_hist[nh] = rmse;
+            ++nh;
+            ++epoch;
+        }
+    }
+    if (n_hist) *n_hist = nh;
+    return MFX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// one-shot drop-ins: create plan, upload, run, download, destroy
+// ------------------------------------------------------------------------------------
+int mfx_kmf_train(int mode, int nbr_epochs, int dim, double lr, double Ku, double Ki, double Kb,
+                  double *u, double *v, const int32_t *idx, const double *r, double *ib, double *ub,
+                  int64_t nnz, int nu, int ni, int upd_u, int upd_i, double *rmse_out)
+{
+    if (!u || !v || !ib || !ub || (nnz > 0 && (!idx || !r))) {
+        return fail(MFX_E_ARG, "mfx_kmf_train: NULL argument");
+    }
+    if (nnz == 0 || nbr_epochs <= 0) {
+        // the reference divides 0/0 for the rmse and changes nothing
+        if (rmse_out) for (int e = 0; e < nbr_epochs; ++e) rmse_out[e] = NAN;
+        return MFX_OK;
+    }
+    mfx_sgd_plan *p = mfx_sgd_plan_create(idx, r, nnz, nu, ni, dim);
+    if (!p) return last_code();
+    int rc = mfx_sgd_set_factors(p, u, v, ib, ub);
+    if (!rc) rc = mfx_sgd_run_kmf(p, mode, nbr_epochs, lr, Ku, Ki, Kb, upd_u, upd_i, rmse_out);
+    if (!rc) rc = mfx_sgd_get_factors(p, u, v, ib, ub);
+    mfx_sgd_plan_destroy(p);
+    return rc;
+}
+
+int mfx_funk(int min_epochs, double min_improvement, int dim, double f_init, double lr, double K,
+             double mu, double *u, double *v, const int32_t *idx, const double *r, const double *ib,
+             const double *ub, int64_t nnz, int nu, int ni, int upd_u, int upd_i, int epoch_cap,
+             double *rmse_hist, int64_t hist_cap, int64_t *n_hist)
+{
+    if (!u || !v || (nnz > 0 && (!idx || !r)) || ((ib == nullptr) != (ub == nullptr))) {
+        return fail(MFX_E_ARG, "mfx_funk: NULL argument");
+    }
+    if (n_hist) *n_hist = 0;
+    if (nnz == 0) {
+        return fail(MFX_E_ARG, "mfx_funk: no ratings (the reference's stopping rule would divide 0/0)");
+    }
+    mfx_sgd_plan *p = mfx_sgd_plan_create(idx, r, nnz, nu, ni, dim);
+    if (!p) return last_code();
+    int rc = mfx_sgd_set_factors(p, u, v, ib, ub);
+    if (!rc) rc = mfx_sgd_run_funk(p, min_epochs, min_improvement, f_init, lr, K, mu, ib != nullptr,
+                                   upd_u, upd_i, epoch_cap, rmse_hist, hist_cap, n_hist);
+    if (!rc) rc = mfx_sgd_get_factors(p, u, v, nullptr, nullptr);
+    mfx_sgd_plan_destroy(p);
+    return rc;
+}
+
+int mfx_learned_bias(int min_epochs, double min_improvement, int dim, double f_init, double lr,
+                     double lr_users, double lr_items, double K_feature, double K_bias, double mu,
+                     double *u, double *v, const int32_t *idx, const double *r, double *ib,
+                     double *ub, int64_t nnz, int nu, int ni, int epoch_cap, double *rmse_hist,
+                     int64_t hist_cap, int64_t *n_hist)
+{
+    if (!u || !v || !ib || !ub || (nnz > 0 && (!idx || !r))) {
+        return fail(MFX_E_ARG, "mfx_learned_bias: NULL argument");
+    }
+    if (n_hist) *n_hist = 0;
+    if (nnz == 0) {
+        return fail(MFX_E_ARG, "mfx_learned_bias: no ratings");
+    }
+    mfx_sgd_plan *p = mfx_sgd_plan_create(idx, r, nnz, nu, ni, dim);
+    if (!p) return last_code();
+    int rc = mfx_sgd_set_factors(p, u, v, ib, ub);
+    if (!rc) rc = mfx_sgd_run_learned_bias(p, min_epochs, min_improvement, f_init, lr, lr_users,
+                                           lr_items, K_feature, K_bias, mu, epoch_cap, rmse_hist,
+                                           hist_cap, n_hist);
+    if (!rc) rc = mfx_sgd_get_factors(p, u, v, ib, ub);
+    mfx_sgd_plan_destroy(p);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,331 @@
+// Device kernels of the SGD families (gfx950 / wave64 only).
+//
+// K1  full-k update  : train_linear_kernel / train_logistic_kernel (kmf_train.pyx:195-277,
+//                      :103-189) and estimator_loop_with_learned_bias (gd_estimator.pyx:401-483)
+// K2  Funk pass      : estimator_loop_without_bias / _with_bias / _with_bias_dev
+//                      (gd_estimator.pyx:691-779, :489-582, :588-685) + cache-commit pass
+//
+// Exactness contract: one launch processes one dependency level (ratings with pairwise
+// distinct users and items), every floating-point operation is the reference's operation
+// in the reference's order (no FMA contraction: built with -ffp-contract=off), and the
+// k-term dot product is summed strictly left to right by ONE lane per rating.  The factor
+// arrays therefore come out bit-identical to the sequential C loop.
+#pragma once
+#include "mfx_common.h"
+
+namespace mfx {
+
+struct Rec {        // one rating in level-major order: 16 B, one dwordx4 load
+    int32_t user;
+    int32_t item;
+    double r;
+};
+
+enum { K1_LINEAR = 0, K1_LOGISTIC = 1, K1_LEARNED = 2 };
+
+struct K1Params {
+    const Rec *recs;
+    double *U;           // [ni][k] row-major
+    double *V;           // [nu][k]
+    double *ib;          // [ni]
+    double *ub;          // [nu]
+    double *se_partial;  // one slot per wave per epoch
+    int k;
+    int upd_u, upd_i;
+    double lr, Ku, Ki, Kb;
+    // learned-bias family only
+    double lr_u, lr_i, mu, trail;
+    int f;               // the single feature that is updated
+};
+
+static constexpr int kWaves = 4;         // waves per block
+// ratings per wave for rank k: 16 * ceil(k/64) features stay in registers per lane pair of
+// rows, and the product tile stays at ~8 KB per wave for every k
+static inline int k1_batch(int k) { return k <= 64 ? 16 : (k <= 128 ? 8 : (k <= 256 ? 4 : 2)); }
+
+__device__ __forceinline__ double clamp15(double x)
+{
+    // gd_estimator.pyx:26-35 -- two separate compares, NaN passes through
+    if (x > 5.0) x = 5.0;
+    if (x < 1.0) x = 1.0;
+    return x;
+}
+
+__device__ __forceinline__ double shfl_f64(double x, int src)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __shfl(lo, src, 64);
+    hi = __shfl(hi, src, 64);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum_fixed(double x)
+{
+    // fixed butterfly: the same association on every run (deterministic RMSE)
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        int lo = __double2loint(x), hi = __double2hiint(x);
+        lo = __shfl_xor(lo, m, 64);
+        hi = __shfl_xor(hi, m, 64);
+        x = x + __hiloint2double(hi, lo);
+    }
+    return x;
+}
+
+// KP  lanes per rating slot (8/16/32/64), SPW = 64/KP slots side by side
+// FPL features per lane (f = j*KP + q), NR ratings per slot in flight; SPW*NR == BATCH
+template <int KP, int FPL, int BATCH, int MODE>
+__global__ __launch_bounds__(kWaves * 64) void k1_level(K1Params P, int64_t start, int count,
+                                                       int64_t wave_off)
+{
+    constexpr int SPW = 64 / KP;
+    constexpr int NR = BATCH / SPW;
+    constexpr int kBatch = BATCH;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    const int64_t wave_g = (int64_t)blockIdx.x * kWaves + wid;
+    const int64_t base = wave_g * kBatch;
+    if (base >= count) {                             // wave-uniform; padding wave of the last block
+        if (lane == 0) P.se_partial[wave_off + wave_g] = 0.0;
+        return;
+    }
+    const int cnt = (count - base) < kBatch ? (int)(count - base) : kBatch;
+
+    const int k = P.k;
+    const int stride = k | 1;                        // odd row stride: conflict-free column walk
+    double *prod = lds + (size_t)wid * kBatch * stride;
+
+    const int g = lane / KP;                         // slot
+    const int q = lane % KP;                         // lane in slot
+
+    // ---- the rating owned by this lane (lanes 0..cnt-1) -------------------------------
+    Rec rec;
+    rec.user = 0; rec.item = 0; rec.r = 0.0;
+    if (lane < cnt) rec = P.recs[start + base + lane];
+
+    // ---- gather both factor rows of every rating of the batch -------------------------
+    double uval[NR][FPL], vval[NR][FPL];
+    int usr[NR], itm[NR];
+#pragma unroll
+    for (int s = 0; s < NR; ++s) {
+        const int n = s * SPW + g;                   // rating number inside the batch
+        if constexpr (KP == 64) {
+            usr[s] = __builtin_amdgcn_readlane(rec.user, s);
+            itm[s] = __builtin_amdgcn_readlane(rec.item, s);
+        } else {
+            usr[s] = __shfl(rec.user, n, 64);
+            itm[s] = __shfl(rec.item, n, 64);
+        }
+        const double *ur = P.U + (size_t)itm[s] * k;
+        const double *vr = P.V + (size_t)usr[s] * k;
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) {
+            const int f = j * KP + q;
+            const bool on = (n < cnt) && (f < k);
+            uval[s][j] = on ? ur[f] : 0.0;
+            vval[s][j] = on ? vr[f] : 0.0;
+        }
+    }
+    double ibv = 0.0, ubv = 0.0;
+    if (lane < cnt) {
+        ibv = P.ib[rec.item];
+        ubv = P.ub[rec.user];
+    }
+
+    // ---- products to LDS: prod[n][f] -------------------------------------------------
+#pragma unroll
+    for (int s = 0; s < NR; ++s) {
+        const int n = s * SPW + g;
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) {
+            const int f = j * KP + q;
+            if (f < k) prod[n * stride + f] = uval[s][j] * vval[s][j];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+    // ---- lane n: strictly sequential k-term sum, error, gradient, bias update ---------
+    double grad = 0.0, e2 = 0.0;
+    if (lane < cnt) {
+        double sum;
+        if constexpr (MODE == K1_LEARNED) sum = P.mu + ibv + ubv;     // gd_estimator.pyx:138
+        else sum = 0.0 + ibv + ubv;                                   // kmf_train.pyx:92
+        const double *row = prod + lane * stride;
+        for (int f = 0; f < k; ++f) sum += row[f];
+        double err;
+        if constexpr (MODE == K1_LINEAR) {
+            err = rec.r - sum;                                        // kmf_train.pyx:251-256
+            grad = err;
+        } else if constexpr (MODE == K1_LOGISTIC) {
+            const double sig = 1.0 / (1.0 + exp(-sum));               // kmf_train.pyx:159-165
+            const double p = 1.0 + sig * 4.0;
+            err = rec.r - p;
+            grad = err * sig * (1.0 - sig) * 4.0;
+        } else {
+            sum = clamp15(sum);                                       // gd_estimator.pyx:142-146
+            sum += P.trail;
+            sum = clamp15(sum);
+            err = rec.r - sum;
+            grad = err;
+        }
+        e2 = err * err;
+        if constexpr (MODE == K1_LEARNED) {
+            P.ub[rec.user] = ubv + P.lr_u * (err - P.Kb * ubv);       // gd_estimator.pyx:473-474
+            P.ib[rec.item] = ibv + P.lr_i * (err - P.Kb * ibv);
+        } else {
+            // linear: unconditional (kmf_train.pyx:259-260); logistic: gated (:168-171)
+            if (MODE == K1_LINEAR || P.upd_u) P.ub[rec.user] = ubv + P.lr * (grad - P.Kb * ubv);
+            if (MODE == K1_LINEAR || P.upd_i) P.ib[rec.item] = ibv + P.lr * (grad - P.Kb * ibv);
+        }
+    }
+
+    // ---- row updates ------------------------------------------------------------------
+#pragma unroll
+    for (int s = 0; s < NR; ++s) {
+        const int n = s * SPW + g;
+        double gr;
+        if constexpr (KP == 64) {
+            const int lo = __builtin_amdgcn_readlane(__double2loint(grad), s);
+            const int hi = __builtin_amdgcn_readlane(__double2hiint(grad), s);
+            gr = __hiloint2double(hi, lo);
+        } else {
+            gr = shfl_f64(grad, n);
+        }
+        if (n < cnt) {
+            double *ur = P.U + (size_t)itm[s] * k;
+            double *vr = P.V + (size_t)usr[s] * k;
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) {
+                const int f = j * KP + q;
+                if (f < k) {
+                    const double mf = uval[s][j], cf = vval[s][j];
+                    if constexpr (MODE == K1_LEARNED) {
+                        if (f == P.f) {                               // gd_estimator.pyx:476-477
+                            ur[f] = mf + P.lr * (gr * cf - P.Ki * mf);
+                            vr[f] = cf + P.lr * (gr * mf - P.Ku * cf);
+                        }
+                    } else {
+                        if (P.upd_i) ur[f] = mf + P.lr * (gr * cf - P.Ki * mf);   // kmf_train.pyx:267-270
+                        if (P.upd_u) vr[f] = cf + P.lr * (gr * mf - P.Ku * cf);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- squared-error partial of this wave (deterministic) ---------------------------
+    const double wsum = wave_sum_fixed(e2);
+    if (lane == 0) P.se_partial[wave_off + wave_g] = wsum;
+}
+
+// ------------------------------------------------------------------------------------
+// K2: Funk per-feature pass.  One lane per rating of one level; the feature vectors
+// uf = U[f, :], vf = V[f, :] are feature-major slices (L2 resident).
+// ------------------------------------------------------------------------------------
+struct K2Params {
+    const Rec *recs;
+    double *uf;           // U + f*ni
+    double *vf;           // V + f*nu
+    double *cache;        // level-major, one per rating
+    const double *ib;     // nullable (without_bias)
+    const double *ub;
+    double *se_partial;
+    double lr, K, mu, trail;
+    int upd_u, upd_i;
+};
+
+__device__ __forceinline__ double funk_estimate(double uf, double vf, double cache, double base,
+                                                double trail, bool trailing)
+{
+    // gd_estimator.pyx:38-73
+    double sum = (cache > 0) ? cache : base;
+    sum += uf * vf;
+    sum = clamp15(sum);
+    if (trailing) {
+        sum += trail;
+        sum = clamp15(sum);
+    }
+    return sum;
+}
+
+__global__ __launch_bounds__(256) void k2_level(K2Params P, int64_t start, int count,
+                                                int64_t wave_off)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    double e2 = 0.0;
+    if (t < count) {
+        const Rec rec = P.recs[start + t];
+        const double c = P.cache[start + t];
+        double base;
+        if (P.ib) base = P.mu + P.ib[rec.item] + P.ub[rec.user];
+        else base = P.mu + 0.0 + 0.0;
+        const double mf = P.uf[rec.item], cf = P.vf[rec.user];
+        const double p = funk_estimate(mf, cf, c, base, P.trail, true);
+        const double err = rec.r - p;
+        e2 = err * err;
+        if (P.upd_i) P.uf[rec.item] = mf + P.lr * (err * cf - P.K * mf);
+        if (P.upd_u) P.vf[rec.user] = cf + P.lr * (err * mf - P.K * cf);
+    }
+    const double wsum = wave_sum_fixed(e2);
+    if ((threadIdx.x & 63) == 0)
+        P.se_partial[wave_off + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)] = wsum;
+}
+
+// cache-commit pass (gd_estimator.pyx:771-777): embarrassingly parallel over all ratings
+__global__ __launch_bounds__(256) void k2_commit(K2Params P, int64_t nnz)
+{
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < nnz;
+         t += (int64_t)gridDim.x * 256) {
+        const Rec rec = P.recs[t];
+        double base;
+        if (P.ib) base = P.mu + P.ib[rec.item] + P.ub[rec.user];
+        else base = P.mu + 0.0 + 0.0;
+        P.cache[t] = funk_estimate(P.uf[rec.item], P.vf[rec.user], P.cache[t], base, 0.0, false);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------
+// sum n partials in a fixed order; out[*counter] = sum; ++*counter
+__global__ __launch_bounds__(1024) void k_reduce_se(const double *partial, int64_t n, double *out,
+                                                    int *counter)
+{
+    __shared__ double sh[1024];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) s += partial[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 512; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[*counter] = sh[0];
+        *counter = *counter + 1;
+    }
+}
+
+// out[c][r] = in[r][c]; in is rows x cols row-major
+__global__ __launch_bounds__(256) void k_transpose(const double *in, double *out, int rows,
+                                                   int cols)
+{
+    __shared__ double tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int r = by + i, c = bx + tx;
+        if (r < rows && c < cols) tile[i][tx] = in[(size_t)r * cols + c];
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = bx + i, r = by + tx;
+        if (r < rows && c < cols) out[(size_t)c * rows + r] = tile[tx][i];
+    }
+}
+
+}  // namespace mfx

@@ -1,0 +1,111 @@
+"""CPU: the C-ABI library loads, exports every symbol include/mfx.h declares, fails loudly
+without a GPU, and its host-side scheduler matches the golden level order."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from mfrec_amd import _shim as S
+from mfrec_amd import build as B
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    B.build(verbose=False)
+    return S.lib()
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "mfx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mfx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = header_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), "libmfx.so does not export %s" % n
+    # and the binding table covers exactly the header
+    assert sorted(S.SIGNATURES) == names
+
+
+def test_fails_loudly_without_gpu(lib):
+    if S.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(S.MfxError, match="no CPU fallback"):
+        S.init(0)
+    from mfrec_amd.lib import kmf_train
+    u, v = np.zeros((4, 3)), np.zeros((4, 5))
+    idx = np.array([[0, 0], [1, 2]], dtype=np.int32)
+    with pytest.raises(S.MfxError):
+        kmf_train.train_linear_kernel(1, 4, 0.1, 0.01, 0, 0, 0.1, 0.1, 0.007, 0.0, u, v, idx,
+                                      np.array([3.0, 4.0]), np.zeros(3), np.zeros(5))
+
+
+def test_buffer_validation_mimics_cython(lib):
+    from mfrec_amd.lib import kmf_train
+    u, v = np.zeros((4, 3)), np.zeros((4, 5))
+    idx = np.array([[0, 0], [1, 2]], dtype=np.int32)
+    r, ib, ub = np.array([3.0, 4.0]), np.zeros(3), np.zeros(5)
+    a = (1, 4, 0.1, 0.01, 0, 0, 0.1, 0.1, 0.007, 0.0)
+    with pytest.raises(ValueError, match="dtype mismatch"):
+        kmf_train.train_linear_kernel(*a, u.astype(np.float32), v, idx, r, ib, ub)
+    with pytest.raises(ValueError, match="dtype mismatch"):
+        kmf_train.train_linear_kernel(*a, u, v, idx.astype(np.int64), r, ib, ub)
+    with pytest.raises(ValueError, match="dimensions"):
+        kmf_train.train_linear_kernel(*a, u, v, idx, r.reshape(2, 1), ib, ub)
+    with pytest.raises(ValueError, match="contiguous"):
+        kmf_train.train_linear_kernel(*a, np.zeros((3, 4)).T, v, idx, r, ib, ub)
+    with pytest.raises(TypeError):
+        kmf_train.train_linear_kernel(*a, [[0.0]], v, idx, r, ib, ub)
+
+
+def _levels(lib, idx, nu, ni):
+    lev = np.empty(idx.shape[0], dtype=np.int32)
+    n = C.c_int64(0)
+    S.check(lib.mfx_schedule_levels(S.i32(idx, "idx", 2), idx.shape[0], nu, ni,
+                                    lev.ctypes.data_as(S._ip), C.byref(n)))
+    perm = np.empty(idx.shape[0], dtype=np.int64)
+    off = np.empty(n.value + 1, dtype=np.int64)
+    S.check(lib.mfx_schedule_permutation(lev.ctypes.data_as(S._ip), idx.shape[0], n.value,
+                                         perm.ctypes.data_as(S._lp), off.ctypes.data_as(S._lp)))
+    return lev, perm, off
+
+
+def test_scheduler_matches_golden_level_order(lib, golden):
+    g = golden("g8_levels")
+    for tag in ("a", "b"):
+        idx = g["in_idx_" + tag]
+        lev, perm, off = _levels(lib, idx, 60, 40)
+        assert np.array_equal(lev, g["out_level_" + tag])
+        assert np.array_equal(perm, g["out_perm_" + tag])
+        assert off[0] == 0 and off[-1] == idx.shape[0]
+        # inside a level no user and no item repeats
+        for l in range(len(off) - 1):
+            s = idx[perm[off[l]:off[l + 1]]]
+            assert len(set(s[:, 0])) == len(s) and len(set(s[:, 1])) == len(s)
+
+
+def test_scheduler_properties_random(lib):
+    rs = np.random.RandomState(0)
+    idx = np.stack([rs.randint(0, 300, 20000), rs.randint(0, 200, 20000)], 1).astype(np.int32)
+    lev, perm, off = _levels(lib, idx, 300, 200)
+    assert sorted(perm.tolist()) == list(range(20000))
+    # order is preserved inside every user chain and every item chain
+    pos = np.empty(20000, dtype=np.int64); pos[perm] = np.arange(20000)
+    for col in (0, 1):
+        order = np.lexsort((np.arange(20000), idx[:, col]))
+        same = idx[order[1:], col] == idx[order[:-1], col]
+        assert np.all(lev[order[1:]][same] > lev[order[:-1]][same])
+    # empty input and range errors
+    e = np.zeros((0, 2), dtype=np.int32)
+    lev, perm, off = _levels(lib, e, 3, 3)
+    assert off.tolist() == [0]
+    bad = np.array([[0, 5]], dtype=np.int32)
+    with pytest.raises(ValueError, match="outside"):
+        _levels(lib, bad, 3, 3)

@@ -1,0 +1,194 @@
+"""GPU: the HIP path, called through the C-ABI, against the golden vectors and the oracle.
+
+Tolerances: linear full-k SGD, Funk and learned-bias families -> BIT-EXACT factors (the level
+schedule + in-order summation reproduce the sequential loop); logistic -> 1e-12 relative
+(device exp() differs from libm in the last ulp); online RMSE -> 1e-12 relative (parallel
+sum of squared errors)."""
+import numpy as np
+import pytest
+
+from mfrec_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    from mfrec_amd import _shim as S
+    from mfrec_amd import build as B
+    B.build(verbose=False)
+    S.init(0)            # raises if the HIP library or the GPU is missing: no fallback
+    yield
+
+
+def eq(a, b):
+    assert a.shape == b.shape and np.array_equal(a, b, equal_nan=True), \
+        "max abs diff %g" % np.abs(a - b).max()
+
+
+def test_linear_golden_bitexact(golden):
+    from mfrec_amd.lib import kmf_train as K
+    g = golden("g1_linear")
+    E, k = int(g["p_epochs"]), int(g["p_k"])
+    for gate in ((1, 1), (1, 0), (0, 1)):
+        tag = "%d%d" % gate
+        u, v = g["in_u0"].copy(), g["in_v0"].copy()
+        ib, ub = np.zeros(40), np.zeros(60)
+        rm = K.train_kernel_rmse(0, E, k, float(g["p_lr"]), float(g["p_Ku"]), float(g["p_Ki"]),
+                                 float(g["p_Kb"]), u, v, g["in_idx"], g["in_r"], ib, ub, *gate)
+        eq(u, g["out_u_" + tag]); eq(v, g["out_v_" + tag])
+        eq(ib, g["out_ib_" + tag]); eq(ub, g["out_ub_" + tag])
+        np.testing.assert_allclose(rm, g["out_rmse_" + tag], rtol=1e-12)
+
+
+def test_logistic_golden(golden):
+    from mfrec_amd.lib import kmf_train as K
+    g = golden("g2_logistic")
+    E, k = int(g["p_epochs"]), int(g["p_k"])
+    for gate in ((1, 1), (1, 0), (0, 1)):
+        tag = "%d%d" % gate
+        u, v = g["in_u0"].copy(), g["in_v0"].copy()
+        ib, ub = np.zeros(40), np.zeros(60)
+        rm = K.train_kernel_rmse(1, E, k, float(g["p_lr"]), float(g["p_Ku"]), float(g["p_Ki"]),
+                                 float(g["p_Kb"]), u, v, g["in_idx"], g["in_r"], ib, ub, *gate)
+        for a, b in ((u, g["out_u_" + tag]), (v, g["out_v_" + tag]), (ib, g["out_ib_" + tag]),
+                     (ub, g["out_ub_" + tag]), (rm, g["out_rmse_" + tag])):
+            np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-15)
+
+
+@pytest.mark.parametrize("k", [1, 3, 40, 64, 128])
+def test_linear_edges_bitexact(golden, k):
+    from mfrec_amd.lib import kmf_train as K
+    g = golden("g9_edges")
+    if k in (1, 3):      # duplicates, ratings outside [1,5]
+        u, v, ib, ub = g["in_u0_k%d" % k].copy(), g["in_v0_k%d" % k].copy(), np.zeros(5), np.zeros(6)
+        K.train_linear_kernel(4, k, 0.1, 0.05, 0, 0, 0.1, 0.1, 0.007, 0.0, u, v, g["in_idx_a"],
+                              g["in_r_a"], ib, ub)
+    else:
+        u, v, ib, ub = g["in_u0_k%d" % k].copy(), g["in_v0_k%d" % k].copy(), np.zeros(50), np.zeros(80)
+        K.train_linear_kernel(2, k, 0.1, 0.01, 0, 0, 0.1, 0.1, 0.007, 0.0, u, v, g["in_idx_b"],
+                              g["in_r_b"], ib, ub)
+    eq(u, g["out_lin_u_k%d" % k]); eq(v, g["out_lin_v_k%d" % k])
+    eq(ib, g["out_lin_ib_k%d" % k]); eq(ub, g["out_lin_ub_k%d" % k])
+
+
+@pytest.mark.parametrize("k", [40, 64, 128])
+def test_logistic_edges(golden, k):
+    from mfrec_amd.lib import kmf_train as K
+    g = golden("g9_edges")
+    u, v, ib, ub = g["in_u0_k%d" % k].copy(), g["in_v0_k%d" % k].copy(), np.zeros(50), np.zeros(80)
+    K.train_logistic_kernel(2, k, 0.1, 0.01, 0, 0, 0.1, 0.1, 0.007, 0.0, u, v, g["in_idx_b"],
+                            g["in_r_b"], ib, ub)
+    np.testing.assert_allclose(u, g["out_log_u_k%d" % k], rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(v, g["out_log_v_k%d" % k], rtol=1e-12, atol=1e-15)
+
+
+def test_funk_golden_bitexact(golden):
+    from mfrec_amd.lib import gd_estimator as G
+    g = golden("g3_funk")
+    k, E = int(g["p_k"]), int(g["p_epochs"])
+    u, v = synth.init_const(k, 40), synth.init_const(k, 60)
+    hist = G.funk_rmse_history(E, 1e9, k, float(g["p_init"]), float(g["p_lr"]), float(g["p_K"]),
+                               u, v, g["in_idx"], g["in_r"])
+    eq(u, g["out_u"]); eq(v, g["out_v"])
+    np.testing.assert_allclose(hist, g["out_rmse_hist"], rtol=1e-12)
+    # the drop-in name
+    u, v = synth.init_const(k, 40), synth.init_const(k, 60)
+    G.estimator_loop_without_bias(E, E, 1e9, k, float(g["p_init"]), float(g["p_lr"]),
+                                  float(g["p_K"]), u, v, g["in_idx"], g["in_r"], 60, 40, 0)
+    eq(u, g["out_u"]); eq(v, g["out_v"])
+
+
+def test_funk_stopping_rule(golden):
+    from mfrec_amd.lib import gd_estimator as G
+    g = golden("g3b_funk_stop")
+    k = int(g["p_k"])
+    u, v = synth.init_const(k, 40), synth.init_const(k, 60)
+    hist = G.funk_rmse_history(int(g["p_min_epochs"]), float(g["p_min_improvement"]), k,
+                               float(g["p_init"]), float(g["p_lr"]), float(g["p_K"]), u, v,
+                               g["in_idx"], g["in_r"])
+    assert len(hist) == int(g["out_n_epochs"])
+    eq(u, g["out_u"]); eq(v, g["out_v"])
+
+
+def test_funk_bias_and_gates(golden):
+    from mfrec_amd.lib import gd_estimator as G
+    g = golden("g4_funk_bias")
+    k, E = int(g["p_k"]), int(g["p_epochs"])
+    a = (E, E, 1e9, k, float(g["p_init"]), float(g["p_lr"]), 0, 0, float(g["p_K"]), float(g["p_mu"]))
+    for tag, gate in (("11", None), ("10", (1, 0)), ("01", (0, 1))):
+        u, v = synth.init_const(k, 40), synth.init_const(k, 60)
+        ib, ub = g["in_ib"].copy(), g["in_ub"].copy()
+        if gate is None:
+            G.estimator_loop_with_bias(*a, u, v, g["in_idx"], g["in_r"], ib, ub, 60, 40)
+        else:
+            G.estimator_loop_with_bias_dev(*a, u, v, g["in_idx"], g["in_r"], ib, ub, 60, 40, *gate)
+        eq(u, g["out_u_" + tag]); eq(v, g["out_v_" + tag])
+        eq(ib, g["in_ib"]); eq(ub, g["in_ub"])               # biases are inputs only
+
+
+def test_learned_bias_bitexact(golden):
+    from mfrec_amd.lib import gd_estimator as G
+    g = golden("g5_learned_bias")
+    k, E = int(g["p_k"]), int(g["p_epochs"])
+    u, v = synth.init_const(k, 40), synth.init_const(k, 60)
+    ib, ub = g["in_ib"].copy(), g["in_ub"].copy()
+    G.estimator_loop_with_learned_bias(E, E, 1e9, k, float(g["p_init"]), float(g["p_lr"]),
+                                       float(g["p_lr_users"]), float(g["p_lr_items"]),
+                                       float(g["p_K"]), float(g["p_Kb"]), float(g["p_mu"]), u, v,
+                                       g["in_idx"], g["in_r"], ib, ub, 60, 40)
+    eq(u, g["out_u"]); eq(v, g["out_v"]); eq(ib, g["out_ib"]); eq(ub, g["out_ub"])
+
+
+def test_cfg1_shape_linear_and_funk(golden):
+    """BASELINE configs[0] shape (943 x 1682, 100k ratings, k=16, 10 epochs)."""
+    from mfrec_amd.lib import gd_estimator as G
+    from mfrec_amd.lib import kmf_train as K
+    from oracle import oracle as O
+    g = golden("g7_cfg1")
+    nu, ni, k, E = int(g["p_nu"]), int(g["p_ni"]), int(g["p_k"]), int(g["p_epochs"])
+    idx, r = g["in_idx"], g["in_r"].astype(np.float64)
+    seed = int(g["p_seed_init"])
+    u, v = synth.init_normal(k, ni, seed), synth.init_normal(k, nu, seed + 1)
+    ib, ub = np.zeros(ni), np.zeros(nu)
+    rm = K.train_kernel_rmse(0, E, k, 0.01, 0.1, 0.1, 0.007, u, v, idx, r, ib, ub)
+    eq(u, g["out_lin_u"]); eq(v, g["out_lin_v"]); eq(ib, g["out_lin_ib"]); eq(ub, g["out_lin_ub"])
+    np.testing.assert_allclose(rm, g["out_lin_rmse"], rtol=1e-12)
+    assert abs(O.rmse(O.RMSE_KMF_LINEAR, u, v, idx, r, ib, ub) - float(g["out_lin_final_rmse"])) <= 1e-5
+    fu, fv = synth.init_const(k, ni), synth.init_const(k, nu)
+    G.estimator_loop_without_bias(E, E, 1e9, k, 0.1, 0.001, 0.05, fu, fv, idx, r, nu, ni, 0)
+    eq(fu, g["out_funk_u"]); eq(fv, g["out_funk_v"])
+
+
+def test_medium_vs_oracle_k64():
+    """A problem big enough for multi-block levels (k = 64, 200k ratings), vs the oracle."""
+    from mfrec_amd.lib import kmf_train as K
+    from oracle import oracle as O
+    nu, ni, nnz, k, E = 4000, 3000, 200000, 64, 3
+    idx, r = synth.make_ratings(nu, ni, nnz, seed=5)
+    u0, v0 = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
+    for mode, fn, ofn in ((0, K.train_linear_kernel, O.train_linear_kernel),
+                          (1, K.train_logistic_kernel, O.train_logistic_kernel)):
+        u, v, ib, ub = u0.copy(), v0.copy(), np.zeros(ni), np.zeros(nu)
+        fn(E, k, 0.1, 0.01, 0, 0, 0.1, 0.1, 0.007, 0.0, u, v, idx, r, ib, ub)
+        u2, v2, ib2, ub2 = u0.copy(), v0.copy(), np.zeros(ni), np.zeros(nu)
+        ofn(E, k, 0.1, 0.01, 0, 0, 0.1, 0.1, 0.007, 0.0, u2, v2, idx, r, ib2, ub2)
+        if mode == 0:
+            eq(u, u2); eq(v, v2); eq(ib, ib2); eq(ub, ub2)
+        else:
+            np.testing.assert_allclose(u, u2, rtol=1e-11, atol=1e-14)
+            np.testing.assert_allclose(v, v2, rtol=1e-11, atol=1e-14)
+        kind = O.RMSE_KMF_LINEAR if mode == 0 else O.RMSE_KMF_LOGISTIC
+        assert abs(O.rmse(kind, u, v, idx, r, ib, ub) - O.rmse(kind, u2, v2, idx, r, ib2, ub2)) <= 1e-5
+
+
+def test_empty_and_errors():
+    from mfrec_amd.lib import kmf_train as K
+    u, v = np.ones((4, 3)), np.ones((4, 5))
+    ib, ub = np.zeros(3), np.zeros(5)
+    K.train_linear_kernel(2, 4, 0.1, 0.01, 0, 0, 0.1, 0.1, 0.007, 0.0, u, v,
+                          np.zeros((0, 2), dtype=np.int32), np.zeros(0), ib, ub)
+    assert np.all(u == 1.0) and np.all(v == 1.0)          # empty input changes nothing
+    with pytest.raises(ValueError, match="outside"):       # the reference would corrupt memory
+        K.train_linear_kernel(1, 4, 0.1, 0.01, 0, 0, 0.1, 0.1, 0.007, 0.0, u, v,
+                              np.array([[0, 3]], dtype=np.int32), np.array([3.0]), ib, ub)

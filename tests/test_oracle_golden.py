@@ -1,0 +1,150 @@
+"""CPU: the plain-C restatement (oracle/) against the golden vectors captured from the
+reference's own Cython kernels (tests/golden/*.npz, generator oracle/make_golden.py)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from mfrec_amd import synth
+
+
+def eq(a, b):
+    assert a.shape == b.shape and np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize("name,fn", [("g1_linear", O.train_linear_kernel),
+                                     ("g2_logistic", O.train_logistic_kernel)])
+def test_kmf_kernels_bitexact(golden, name, fn):
+    g = golden(name)
+    E, k = int(g["p_epochs"]), int(g["p_k"])
+    for gate in ((1, 1), (1, 0), (0, 1)):
+        tag = "%d%d" % gate
+        u, v = g["in_u0"].copy(), g["in_v0"].copy()
+        ib, ub = np.zeros(u.shape[1]), np.zeros(v.shape[1])
+        rm = np.zeros(E)
+        fn(E, k, 0.1, float(g["p_lr"]), 0, 0, float(g["p_Ku"]), float(g["p_Ki"]), float(g["p_Kb"]),
+           0.0, u, v, g["in_idx"], g["in_r"], ib, ub, gate[0], gate[1], 0, rm)
+        eq(u, g["out_u_" + tag]); eq(v, g["out_v_" + tag])
+        eq(ib, g["out_ib_" + tag]); eq(ub, g["out_ub_" + tag])
+        np.testing.assert_allclose(rm, g["out_rmse_" + tag], rtol=1e-12)
+
+
+def test_funk_without_bias_bitexact(golden):
+    g = golden("g3_funk")
+    k, E = int(g["p_k"]), int(g["p_epochs"])
+    u, v = synth.init_const(k, 40), synth.init_const(k, 60)
+    hist = np.zeros(k * E)
+    n = O.estimator_loop_without_bias(E, E, 1e9, k, float(g["p_init"]), float(g["p_lr"]),
+                                      float(g["p_K"]), u, v, g["in_idx"], g["in_r"], 60, 40, 0, hist)
+    assert n == k * E
+    eq(u, g["out_u"]); eq(v, g["out_v"]); eq(hist, g["out_rmse_hist"])
+
+
+def test_funk_dense_cache_variants(golden):
+    g = golden("g3_funk")
+    k, E = int(g["p_k"]), int(g["p_epochs"])
+    init, lr, K = float(g["p_init"]), float(g["p_lr"]), float(g["p_K"])
+    u, v = synth.init_const(k, 40), synth.init_const(k, 60)
+    hist = np.zeros(k * E)
+    O.estimator_loop(E, E, 1e9, k, init, lr, K, u, v, g["in_idx"], g["in_r"], 0, hist, 60, 40, 0)
+    eq(u, g["out_dense_u"]); eq(v, g["out_dense_v"]); eq(hist, g["out_dense_rmse_hist"])
+    u, v = synth.init_const(k, 40), synth.init_const(k, 60)
+    O.estimator_loop2(E, E, 1e9, k, init, lr, K, u, v, g["in_idx"], g["in_r"], np.zeros(40), 60, 40)
+    eq(u, g["out_dense_u"]); eq(v, g["out_dense_v"])
+    u, v, c, sub = synth.init_const(k, 40), synth.init_const(k, 60), np.zeros(2400), []
+    for f in range(2):
+        for _ in range(3):
+            sub.append(O.estimator_subloop(f, 1, 0.0, k, init, lr, K, u, v, g["in_idx"], g["in_r"], c, 60, 40))
+        O.predictor_subloop(f, 1, k, init, u, v, g["in_idx"], g["in_r"], c, 60, 40)
+    eq(np.array(sub), g["out_sub_rmse"]); eq(u, g["out_sub_u"]); eq(c, g["out_sub_cache"])
+
+
+def test_funk_stopping_rule(golden):
+    g = golden("g3b_funk_stop")
+    k = int(g["p_k"])
+    u, v = synth.init_const(k, 40), synth.init_const(k, 60)
+    hist = np.zeros(4096)
+    n = O.estimator_loop_without_bias(int(g["p_min_epochs"]), 0, float(g["p_min_improvement"]), k,
+                                      float(g["p_init"]), float(g["p_lr"]), float(g["p_K"]), u, v,
+                                      g["in_idx"], g["in_r"], 60, 40, 0, hist)
+    assert n == int(g["out_n_epochs"]) and n > 2 * k        # the rule did extend some features
+    eq(u, g["out_u"]); eq(v, g["out_v"]); eq(hist[:n], g["out_rmse_hist"])
+
+
+def test_funk_with_bias_and_gates(golden):
+    g = golden("g4_funk_bias")
+    k, E = int(g["p_k"]), int(g["p_epochs"])
+    a = (E, E, 1e9, k, float(g["p_init"]), float(g["p_lr"]), 0, 0, float(g["p_K"]), float(g["p_mu"]))
+    for tag, gate in (("11", None), ("10", (1, 0)), ("01", (0, 1))):
+        u, v = synth.init_const(k, 40), synth.init_const(k, 60)
+        if gate is None:
+            O.estimator_loop_with_bias(*a, u, v, g["in_idx"], g["in_r"], g["in_ib"], g["in_ub"], 60, 40)
+        else:
+            O.estimator_loop_with_bias_dev(*a, u, v, g["in_idx"], g["in_r"], g["in_ib"], g["in_ub"],
+                                           60, 40, gate[0], gate[1])
+        eq(u, g["out_u_" + tag]); eq(v, g["out_v_" + tag])
+
+
+def test_learned_bias(golden):
+    g = golden("g5_learned_bias")
+    k, E = int(g["p_k"]), int(g["p_epochs"])
+    u, v = synth.init_const(k, 40), synth.init_const(k, 60)
+    ib, ub = g["in_ib"].copy(), g["in_ub"].copy()
+    hist = np.zeros(k * E)
+    O.estimator_loop_with_learned_bias(E, E, 1e9, k, float(g["p_init"]), float(g["p_lr"]),
+                                       float(g["p_lr_users"]), float(g["p_lr_items"]),
+                                       float(g["p_K"]), float(g["p_Kb"]), float(g["p_mu"]), u, v,
+                                       g["in_idx"], g["in_r"], ib, ub, 60, 40, 0, 0, hist)
+    eq(u, g["out_u"]); eq(v, g["out_v"]); eq(ib, g["out_ib"]); eq(ub, g["out_ub"])
+    eq(hist, g["out_rmse_hist"])
+
+
+def test_als(golden):
+    g = golden("g6_als")
+    k, nu, ni = int(g["p_k"]), int(g["p_nu"]), int(g["p_ni"])
+    for tag, u0, v0 in (("rand", g["in_u0_rand"], g["in_v0_rand"]),
+                        ("const", synth.init_const(k, ni), synth.init_const(k, nu))):
+        for E in (1, 2):
+            u, v = u0.copy(), v0.copy()
+            O.als_wrmf(E, k, u, v, None, None, g["in_urow"], g["in_ucol"], g["in_irow"],
+                       g["in_icol"], nu, ni, int(g["p_c_pos"]), float(g["p_lambda"]))
+            # const init is rounding-chaotic beyond one epoch: see oracle/make_golden.py
+            tol = 1e-9 if (tag == "rand" or E == 1) else 1e-4
+            np.testing.assert_allclose(u, g["out_u_%s_e%d" % (tag, E)], rtol=tol, atol=tol * 1e-2)
+            np.testing.assert_allclose(v, g["out_v_%s_e%d" % (tag, E)], rtol=tol, atol=tol * 1e-2)
+    # a user without ratings is solved to 0, trailing unrated ids are untouched
+    assert np.all(g["out_v_rand_e1"][:, 7] == 0.0)
+    eq(g["out_v_rand_e1"][:, -1], g["in_v0_rand"][:, -1])
+
+
+def test_cfg1_shape(golden):
+    g = golden("g7_cfg1")
+    nu, ni, nnz, k, E = (int(g[x]) for x in ("p_nu", "p_ni", "p_nnz", "p_k", "p_epochs"))
+    idx, r = synth.make_ratings(nu, ni, nnz, int(g["p_seed_data"]))
+    eq(idx, g["in_idx"]); eq(r, g["in_r"].astype(np.float64))       # generator is reproducible
+    seed = int(g["p_seed_init"])
+    u, v = synth.init_normal(k, ni, seed), synth.init_normal(k, nu, seed + 1)
+    ib, ub, rm = np.zeros(ni), np.zeros(nu), np.zeros(E)
+    O.train_linear_kernel(E, k, 0.1, 0.01, 0, 0, 0.1, 0.1, 0.007, 0.0, u, v, idx, r, ib, ub, 1, 1, 0, rm)
+    eq(u, g["out_lin_u"]); eq(v, g["out_lin_v"]); eq(ib, g["out_lin_ib"]); eq(ub, g["out_lin_ub"])
+    eq(rm, g["out_lin_rmse"])
+    assert abs(O.rmse(O.RMSE_KMF_LINEAR, u, v, idx, r, ib, ub) - float(g["out_lin_final_rmse"])) < 1e-15
+    fu, fv, fh = synth.init_const(k, ni), synth.init_const(k, nu), np.zeros(k * E)
+    O.estimator_loop_without_bias(E, E, 1e9, k, 0.1, 0.001, 0.05, fu, fv, idx, r, nu, ni, 0, fh)
+    eq(fu, g["out_funk_u"]); eq(fv, g["out_funk_v"]); eq(fh, g["out_funk_rmse_hist"])
+
+
+def test_edges(golden):
+    g = golden("g9_edges")
+    for k in (1, 3):
+        u, v, ib, ub = g["in_u0_k%d" % k].copy(), g["in_v0_k%d" % k].copy(), np.zeros(5), np.zeros(6)
+        O.train_linear_kernel(4, k, 0.1, 0.05, 0, 0, 0.1, 0.1, 0.007, 0.0, u, v, g["in_idx_a"], g["in_r_a"], ib, ub)
+        eq(u, g["out_lin_u_k%d" % k]); eq(v, g["out_lin_v_k%d" % k]); eq(ub, g["out_lin_ub_k%d" % k])
+        fu, fv = synth.init_const(k, 5, 0.7), synth.init_const(k, 6, 0.7)
+        O.estimator_loop_without_bias(4, 4, 1e9, k, 0.7, 0.02, 0.05, fu, fv, g["in_idx_a"], g["in_r_a"], 6, 5)
+        eq(fu, g["out_funk_u_k%d" % k]); eq(fv, g["out_funk_v_k%d" % k])
+    for k in (40, 64, 128):
+        for nm, fn in (("lin", O.train_linear_kernel), ("log", O.train_logistic_kernel)):
+            u, v, ib, ub = g["in_u0_k%d" % k].copy(), g["in_v0_k%d" % k].copy(), np.zeros(50), np.zeros(80)
+            fn(2, k, 0.1, 0.01, 0, 0, 0.1, 0.1, 0.007, 0.0, u, v, g["in_idx_b"], g["in_r_b"], ib, ub)
+            eq(u, g["out_%s_u_k%d" % (nm, k)]); eq(v, g["out_%s_v_k%d" % (nm, k)])
+            eq(ib, g["out_%s_ib_k%d" % (nm, k)]); eq(ub, g["out_%s_ub_k%d" % (nm, k)])

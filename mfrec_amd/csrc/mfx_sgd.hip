@@ -15,6 +15,7 @@ struct mfx_sgd_plan {
     int64_t nnz = 0;
     int nu = 0, ni = 0, k = 0;
     int64_t n_levels = 0, max_level = 0;
+    int batch = 16, nt = 0;              // full-k kernel: ratings per wave, non-temporal row stores
     std::vector<int64_t> level_off;      // n_levels + 1
     std::vector<int64_t> k1_wave_off;    // per level: first se_partial slot (full-k kernels)
     std::vector<int64_t> k2_wave_off;    // per level (Funk kernels)
@@ -28,6 +29,7 @@ struct mfx_sgd_plan {
     double *d_ib = nullptr, *d_ub = nullptr;
     double *d_cache = nullptr;           // Funk residual cache (lazy)
     double *d_se_partial = nullptr;
+    double *d_se_tmp = nullptr;          // stage-1 sums of the SE reduction
     double *d_se_epoch = nullptr;        // per-epoch sums (capacity se_cap)
     int *d_counter = nullptr;
     int64_t se_cap = 0;
@@ -102,43 +104,76 @@ int to_km(mfx_sgd_plan *p)
     return rc;
 }
 
-size_t k1_lds_bytes(int k)
+size_t k1_lds_bytes(int k, int batch)
 {
-    return (size_t)kWaves * k1_batch(k) * (size_t)(k | 1) * sizeof(double);
+    return (size_t)kWaves * batch * (size_t)k1_stride(k) * sizeof(double);
 }
 
-// pick the kernel instantiation for (k, mode)
-template <int MODE>
-void *k1_pick(int k)
+// pick the kernel instantiation for (k, mode, batch, nt)
+template <int MODE, int NT>
+void *k1_pick(int k, int batch)
 {
-    // must agree with k1_batch(k)
-    if (k <= 8) return (void *)k1_level<8, 1, 16, MODE>;
-    if (k <= 16) return (void *)k1_level<16, 1, 16, MODE>;
-    if (k <= 32) return (void *)k1_level<32, 1, 16, MODE>;
-    if (k <= 64) return (void *)k1_level<64, 1, 16, MODE>;
-    if (k <= 128) return (void *)k1_level<64, 2, 8, MODE>;
-    if (k <= 256) return (void *)k1_level<64, 4, 4, MODE>;
-    return (void *)k1_level<64, 8, 2, MODE>;
+    if (k <= 8) return (void *)k1_level<8, 1, 16, MODE, NT>;
+    if (k <= 16) return (void *)k1_level<16, 1, 16, MODE, NT>;
+    if (k <= 32) return (void *)k1_level<32, 1, 16, MODE, NT>;
+    if (k <= 64) {
+        if (batch == 16) return (void *)k1_level<64, 1, 16, MODE, NT>;
+        if (batch == 4) return (void *)k1_level<64, 1, 4, MODE, NT>;
+        return (void *)k1_level<64, 1, 8, MODE, NT>;
+    }
+    if (k <= 128) return (void *)k1_level<64, 2, 8, MODE, NT>;
+    if (k <= 256) return (void *)k1_level<64, 4, 4, MODE, NT>;
+    return (void *)k1_level<64, 8, 2, MODE, NT>;
 }
 
-void *k1_kernel(int k, int mode)
+void *k1_kernel(int k, int mode, int batch, int nt)
 {
-    switch (mode) {
-    case K1_LINEAR: return k1_pick<K1_LINEAR>(k);
-    case K1_LOGISTIC: return k1_pick<K1_LOGISTIC>(k);
-    default: return k1_pick<K1_LEARNED>(k);
+    switch (mode * 2 + (nt ? 1 : 0)) {
+    case 0: return k1_pick<K1_LINEAR, 0>(k, batch);
+    case 1: return k1_pick<K1_LINEAR, 1>(k, batch);
+    case 2: return k1_pick<K1_LOGISTIC, 0>(k, batch);
+    case 3: return k1_pick<K1_LOGISTIC, 1>(k, batch);
+    case 4: return k1_pick<K1_LEARNED, 0>(k, batch);
+    default: return k1_pick<K1_LEARNED, 1>(k, batch);
     }
 }
 
+int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+
+// ratings per wave: k1_batch(k), or the MFX_K1_BATCH tuning override (k in 33..64 only)
+int plan_batch(int k)
+{
+    int b = k1_batch(k);
+    if (k > 32 && k <= 64) {
+        const int o = env_int("MFX_K1_BATCH", b);
+        if (o == 4 || o == 8 || o == 16) b = o;
+    }
+    return b;
+}
+
 constexpr int kMaxK = 512;
+
+int enqueue_reduce(mfx_sgd_plan *p, int64_t n_partials)
+{
+    hipLaunchKernelGGL(k_reduce_se1, dim3(kReduceBlocks), dim3(256), 0, stream(), p->d_se_partial,
+                       n_partials, p->d_se_tmp);
+    hipLaunchKernelGGL(k_reduce_se2, dim3(1), dim3(64), 0, stream(), p->d_se_tmp, p->d_se_epoch,
+                       p->d_counter);
+    MFX_HIP(hipGetLastError());
+    return MFX_OK;
+}
 
 // enqueue one full-k epoch (all levels + the SE reduction) on the library stream.
 // ev != nullptr: record an event pair around every level launch (profiling epoch).
 int enqueue_k1_epoch(mfx_sgd_plan *p, int mode, const K1Params &P, std::vector<hipEvent_t> *ev)
 {
-    void *fn = k1_kernel(p->k, mode);
-    const size_t lds = k1_lds_bytes(p->k);
-    const int batch = k1_batch(p->k);
+    const int batch = p->batch;
+    void *fn = k1_kernel(p->k, mode, batch, p->nt);
+    const size_t lds = k1_lds_bytes(p->k, batch);
     size_t e = 0;
     for (int64_t l = 0; l < p->n_levels; ++l) {
         const int64_t start = p->level_off[l];
@@ -155,10 +190,7 @@ int enqueue_k1_epoch(mfx_sgd_plan *p, int mode, const K1Params &P, std::vector<h
         MFX_HIP(hipLaunchKernel(fn, dim3(blocks), dim3(kWaves * 64), args, lds, stream()));
         if (ev) MFX_HIP(hipEventRecord((*ev)[e++], stream()));
     }
-    hipLaunchKernelGGL(k_reduce_se, dim3(1), dim3(1024), 0, stream(), p->d_se_partial, p->k1_waves,
-                       p->d_se_epoch, p->d_counter);
-    MFX_HIP(hipGetLastError());
-    return MFX_OK;
+    return enqueue_reduce(p, p->k1_waves);
 }
 
 bool same_params(const K1Params &a, const K1Params &b)
@@ -317,6 +349,8 @@ mfx_sgd_plan *mfx_sgd_plan_create(const int32_t *idx, const double *r, int64_t n
     p->nu = nu;
     p->ni = ni;
     p->k = dim;
+    p->batch = plan_batch(dim);
+    p->nt = env_int("MFX_K1_NT", 0) ? 1 : 0;
     auto bail = [&]() -> mfx_sgd_plan * {
         mfx_sgd_plan_destroy(p);
         return nullptr;
@@ -344,7 +378,7 @@ mfx_sgd_plan *mfx_sgd_plan_create(const int32_t *idx, const double *r, int64_t n
             if (c > p->max_level) p->max_level = c;
             // slots are per launched wave (blocks are whole)
             p->k1_wave_off[l + 1] = p->k1_wave_off[l] +
-                                    ceil_div(ceil_div(c, (int64_t)k1_batch(dim)), (int64_t)kWaves) * kWaves;
+                                    ceil_div(ceil_div(c, (int64_t)p->batch), (int64_t)kWaves) * kWaves;
             p->k2_wave_off[l + 1] = p->k2_wave_off[l] + ceil_div(c, (int64_t)256) * 4;
         }
         p->k1_waves = p->k1_wave_off[p->n_levels];
@@ -356,7 +390,7 @@ mfx_sgd_plan *mfx_sgd_plan_create(const int32_t *idx, const double *r, int64_t n
         if (dev_alloc(p, &p->d_U_km, (size_t)ni * dim) || dev_alloc(p, &p->d_V_km, (size_t)nu * dim) ||
             dev_alloc(p, &p->d_U_nk, (size_t)ni * dim) || dev_alloc(p, &p->d_V_nk, (size_t)nu * dim) ||
             dev_alloc(p, &p->d_ib, (size_t)ni) || dev_alloc(p, &p->d_ub, (size_t)nu) ||
-            dev_alloc(p, &p->d_counter, 1))
+            dev_alloc(p, &p->d_counter, 1) || dev_alloc(p, &p->d_se_tmp, (size_t)kReduceBlocks))
             return bail();
         const int64_t np = p->k1_waves > p->k2_waves ? p->k1_waves : p->k2_waves;
         if (dev_alloc(p, &p->d_se_partial, (size_t)np)) return bail();
@@ -380,7 +414,7 @@ void mfx_sgd_plan_destroy(mfx_sgd_plan *p)
     if (ready()) (void)hipStreamSynchronize(stream());
     drop_graph(p);
     void *ptrs[] = {p->d_recs, p->d_U_km, p->d_V_km, p->d_U_nk, p->d_V_nk, p->d_ib, p->d_ub,
-                    p->d_cache, p->d_se_partial, p->d_se_epoch, p->d_counter, p->d_U_start,
+                    p->d_cache, p->d_se_partial, p->d_se_tmp, p->d_se_epoch, p->d_counter, p->d_U_start,
                     p->d_ib_start};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -397,7 +431,7 @@ int mfx_sgd_plan_info(const mfx_sgd_plan *p, int64_t info[8])
     info[1] = p->max_level;
     info[2] = launches;
     info[3] = 0;
-    info[4] = k1_batch(p->k);
+    info[4] = p->batch;
     info[5] = (int64_t)p->dev_bytes;
     info[6] = p->sched_us;
     info[7] = launches;
@@ -531,9 +565,8 @@ int mfx_sgd_run_funk(mfx_sgd_plan *p, int min_epochs, double min_improvement, do
                 hipLaunchKernelGGL(k2_level, dim3(ceil_div(count, 256)), dim3(256), 0, stream(), P,
                                    start, count, p->k2_wave_off[l]);
             }
-            hipLaunchKernelGGL(k_reduce_se, dim3(1), dim3(1024), 0, stream(), p->d_se_partial,
-                               p->k2_waves, p->d_se_epoch, p->d_counter);
-            MFX_HIP(hipGetLastError());
+            rc = enqueue_reduce(p, p->k2_waves);
+            if (rc) return rc;
             double se = 0.0;
             MFX_HIP(hipMemcpyAsync(&se, p->d_se_epoch, sizeof(double), hipMemcpyDeviceToHost, stream()));
             MFX_HIP(hipStreamSynchronize(stream()));

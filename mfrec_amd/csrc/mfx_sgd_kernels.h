@@ -39,9 +39,13 @@ struct K1Params {
 };
 
 static constexpr int kWaves = 4;         // waves per block
-// ratings per wave for rank k: 16 * ceil(k/64) features stay in registers per lane pair of
-// rows, and the product tile stays at ~8 KB per wave for every k
-static inline int k1_batch(int k) { return k <= 64 ? 16 : (k <= 128 ? 8 : (k <= 256 ? 4 : 2)); }
+// ratings per wave for rank k (measured on cfg 2, k = 64: 8 per wave = 2 waves per SIMD beats
+// 16 per wave by 19 %; 4 is no better); the product tile stays at <= 8 KB per wave
+static inline int k1_batch(int k) { return k <= 32 ? 16 : (k <= 128 ? 8 : (k <= 256 ? 4 : 2)); }
+// LDS row stride (doubles) of the product tile: rows 16-B aligned so the summing lanes can
+// read two doubles per ds_read_b128, and stride/2 odd so 16 lanes walking one column pair
+// hit 16 different 4-dword bank groups.
+__host__ __device__ static inline int k1_stride(int k) { return ((k + 1) / 2 * 2) | 2; }
 
 __device__ __forceinline__ double clamp15(double x)
 {
@@ -74,7 +78,7 @@ __device__ __forceinline__ double wave_sum_fixed(double x)
 
 // KP  lanes per rating slot (8/16/32/64), SPW = 64/KP slots side by side
 // FPL features per lane (f = j*KP + q), NR ratings per slot in flight; SPW*NR == BATCH
-template <int KP, int FPL, int BATCH, int MODE>
+template <int KP, int FPL, int BATCH, int MODE, int NT>
 __global__ __launch_bounds__(kWaves * 64) void k1_level(K1Params P, int64_t start, int count,
                                                        int64_t wave_off)
 {
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(kWaves * 64) void k1_level(K1Params P, int64_t star
     const int cnt = (count - base) < kBatch ? (int)(count - base) : kBatch;
 
     const int k = P.k;
-    const int stride = k | 1;                        // odd row stride: conflict-free column walk
+    const int stride = k1_stride(k);                 // even, = 2 mod 4: conflict-free b128 column walk
     double *prod = lds + (size_t)wid * kBatch * stride;
 
     const int g = lane / KP;                         // slot
@@ -155,7 +159,17 @@ __global__ __launch_bounds__(kWaves * 64) void k1_level(K1Params P, int64_t star
         if constexpr (MODE == K1_LEARNED) sum = P.mu + ibv + ubv;     // gd_estimator.pyx:138
         else sum = 0.0 + ibv + ubv;                                   // kmf_train.pyx:92
         const double *row = prod + lane * stride;
-        for (int f = 0; f < k; ++f) sum += row[f];
+        // strictly left-to-right; LDS reads are issued 8 columns ahead of the dependent adds
+        int f = 0;
+        for (; f + 8 <= k; f += 8) {
+            const double2 a = *reinterpret_cast<const double2 *>(row + f);
+            const double2 b = *reinterpret_cast<const double2 *>(row + f + 2);
+            const double2 c = *reinterpret_cast<const double2 *>(row + f + 4);
+            const double2 d = *reinterpret_cast<const double2 *>(row + f + 6);
+            sum += a.x; sum += a.y; sum += b.x; sum += b.y;
+            sum += c.x; sum += c.y; sum += d.x; sum += d.y;
+        }
+        for (; f < k; ++f) sum += row[f];
         double err;
         if constexpr (MODE == K1_LINEAR) {
             err = rec.r - sum;                                        // kmf_train.pyx:251-256
@@ -209,8 +223,15 @@ __global__ __launch_bounds__(kWaves * 64) void k1_level(K1Params P, int64_t star
                             vr[f] = cf + P.lr * (gr * mf - P.Ku * cf);
                         }
                     } else {
-                        if (P.upd_i) ur[f] = mf + P.lr * (gr * cf - P.Ki * mf);   // kmf_train.pyx:267-270
-                        if (P.upd_u) vr[f] = cf + P.lr * (gr * mf - P.Ku * cf);
+                        const double un = mf + P.lr * (gr * cf - P.Ki * mf);      // kmf_train.pyx:267-270
+                        const double vn = cf + P.lr * (gr * mf - P.Ku * cf);
+                        if constexpr (NT) {
+                            if (P.upd_i) __builtin_nontemporal_store(un, ur + f);
+                            if (P.upd_u) __builtin_nontemporal_store(vn, vr + f);
+                        } else {
+                            if (P.upd_i) ur[f] = un;
+                            if (P.upd_u) vr[f] = vn;
+                        }
                     }
                 }
             }
@@ -291,21 +312,32 @@ __global__ __launch_bounds__(256) void k2_commit(K2Params P, int64_t nnz)
 // ------------------------------------------------------------------------------------
 // helpers
 // ------------------------------------------------------------------------------------
-// sum n partials in a fixed order; out[*counter] = sum; ++*counter
-__global__ __launch_bounds__(1024) void k_reduce_se(const double *partial, int64_t n, double *out,
-                                                    int *counter)
+// Deterministic two-stage sum of the per-wave squared-error partials.
+// stage 1: block b sums its contiguous chunk (fixed per-thread stride + fixed LDS tree)
+static constexpr int kReduceBlocks = 128;
+__global__ __launch_bounds__(256) void k_reduce_se1(const double *partial, int64_t n, double *tmp)
 {
-    __shared__ double sh[1024];
+    __shared__ double sh[256];
+    const int64_t chunk = (n + kReduceBlocks - 1) / kReduceBlocks;
+    const int64_t lo = (int64_t)blockIdx.x * chunk;
+    const int64_t hi = lo + chunk < n ? lo + chunk : n;
     double s = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) s += partial[i];
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) s += partial[i];
     sh[threadIdx.x] = s;
     __syncthreads();
-    for (int w = 512; w >= 1; w >>= 1) {
+    for (int w = 128; w >= 1; w >>= 1) {
         if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        out[*counter] = sh[0];
+    if (threadIdx.x == 0) tmp[blockIdx.x] = sh[0];
+}
+// stage 2: out[*counter] = tmp[0] + tmp[1] + ... (in order); ++*counter
+__global__ void k_reduce_se2(const double *tmp, double *out, int *counter)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < kReduceBlocks; ++i) s += tmp[i];
+        out[*counter] = s;
         *counter = *counter + 1;
     }
 }

@@ -1,0 +1,85 @@
+"""The slice of mfrec/recommendation/base.py the training path needs: the ratings
+container, parameter handling, ratings -> kernel-input marshalling, model snapshots.
+Persistence backends, similarity search and KNN predictors are out of scope."""
+import logging
+
+import numpy as np
+from scipy.sparse import lil_matrix
+
+
+class Error(Exception):
+    """Raised for unknown parameter names (base.py:23, :199)."""
+
+
+class BaseRecommender(object):
+    PARAMETERS_INDEX = {}
+    _logger_name = "mfrec.recommender"
+
+    def __init__(self, nbr_users=4, nbr_items=6, parameters=None):
+        self.logger = logging.getLogger(self._logger_name)
+        self.dimensionality = 40                      # base.py:90
+        self.min_rating, self.max_rating = 1.0, 5.0   # base.py:92-93
+        self._nbr_users, self._nbr_items = int(nbr_users), int(nbr_items)
+        self.relationship_matrix = lil_matrix((self._nbr_users, self._nbr_items))
+        self.relationship_matrix_csc = None
+        self.relationship_matrix_csr = None
+        self.svd_u = self.svd_v = self.svd_s = None
+        self.users_bias = self.items_bias = self.overall_bias = None
+
+    @property
+    def nbr_users(self):
+        return self._nbr_users
+
+    @property
+    def nbr_items(self):
+        return self._nbr_items
+
+    def set_parameters(self, parameters):
+        """public name -> attribute through PARAMETERS_INDEX (base.py:180-199)."""
+        for name, value in parameters.items():
+            if name not in self.PARAMETERS_INDEX:
+                raise Error("Wrong parameters")
+            setattr(self, self.PARAMETERS_INDEX[name], value)
+
+    # ---- ratings container ----------------------------------------------------------
+    def set_item_by_id(self, user_index, item_index, value):
+        self.relationship_matrix[user_index, item_index] = float(value)     # base.py:823-828
+
+    def set_ratings(self, ratings_index, ratings):
+        """Bulk load of (user, item) -> rating triples (later duplicates win, as repeated
+        set_item_by_id calls would)."""
+        ratings_index = np.asarray(ratings_index)
+        for (a, b), x in zip(ratings_index, np.asarray(ratings, dtype=np.float64)):
+            self.relationship_matrix[int(a), int(b)] = float(x)
+
+    def get_nbr_ratings(self):
+        return int(self.relationship_matrix.tocoo().nnz)
+
+    def ratings_iterator(self):
+        coo = self.relationship_matrix.tocoo()                               # base.py:284-286
+        return zip(coo.row, coo.col, coo.data)
+
+    def get_ratings(self, randomize_order=False):
+        """-> (int32 [nnz,2] (user,item), f64 [nnz]) in COO order of the lil matrix (users
+        ascending, items ascending); optionally shuffled with the global numpy RNG exactly
+        where the reference shuffles (base.py:1115-1131)."""
+        coo = self.relationship_matrix.tocoo()
+        keep = coo.data != 0
+        ratings_index = np.stack([coo.row[keep], coo.col[keep]], axis=1).astype(np.int32)
+        ratings = coo.data[keep].astype(np.float64)
+        order = np.arange(ratings.shape[0])
+        if randomize_order:
+            np.random.shuffle(order)
+        return np.ascontiguousarray(ratings_index[order]), np.ascontiguousarray(ratings[order])
+
+    def compute_overall_avg(self):
+        data = self.relationship_matrix.tocoo().data                         # base.py:504-508
+        self.overall_bias = float(data[data != 0].astype(float).mean())
+
+    # ---- model snapshots (npz keys as base.py:805-812) -------------------------------
+    def save_model_snapshot(self, filename):
+        np.savez(filename + "_model_snapshot.npz", svd_u=self.svd_u, svd_v=self.svd_v)
+
+    def load_model_snapshot(self, filename):
+        z = np.load(filename + "_model_snapshot.npz")
+        self.svd_u, self.svd_v = z["svd_u"], z["svd_v"]

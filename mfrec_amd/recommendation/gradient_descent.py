@@ -1,0 +1,74 @@
+"""GDRecommender: Funk-style per-feature SGD (reference: mfrec/recommendation/gradient_descent.py)."""
+import numpy as np
+
+from ..lib import gd_estimator as _kernels
+from .mf import MFRecommender
+
+
+class GDRecommender(MFRecommender):
+    PARAMETERS_INDEX = {"min_epochs": "min_epochs", "max_epochs": "max_epochs",       # :60-70
+                        "min_improvement": "min_improvement", "feature_init": "feature_init",
+                        "learning_rate": "learning_rate",
+                        "learning_rate_users": "learning_rate_users",
+                        "learning_rate_items": "learning_rate_items",
+                        "regularization_model": "K", "regularization_users_bias": "K2",
+                        "regularization_items_bias": "K3", "nbr_features": "dimensionality"}
+
+    def __init__(self, nbr_users=4, nbr_items=6, parameters=False, filename=False):
+        MFRecommender.__init__(self, nbr_users, nbr_items)
+        self.min_epochs = self.max_epochs = 275                               # :77-87
+        self.min_improvement = 0.0001
+        self.feature_init = 0.1
+        self.learning_rate = self.learning_rate_users = self.learning_rate_items = 0.001
+        self.K, self.K2, self.K3 = 0.05, 0.01, 0.01
+        self.dimensionality = 40
+        if parameters:
+            self.set_parameters(parameters)
+
+    def feature_training(self, initialize_model=True, handle_bias=False, verbose=False):
+        """gradient_descent.py:506-542."""
+        if initialize_model:
+            self.init_feature_const()
+        ratings_index, ratings = self.get_ratings(randomize_order=True)
+        if handle_bias:
+            self.compute_overall_avg()
+            self.compute_items_bias_bk()
+            self.compute_users_bias_bk()
+            _kernels.estimator_loop_with_bias(
+                self.min_epochs, self.max_epochs, self.min_improvement, self.dimensionality,
+                self.feature_init, self.learning_rate, self.learning_rate_users,
+                self.learning_rate_items, self.K, self.overall_bias, self.svd_u, self.svd_v,
+                ratings_index, ratings, self.items_bias, self.users_bias, self.nbr_users,
+                self.nbr_items, int(verbose))
+        else:
+            _kernels.estimator_loop_without_bias(
+                self.min_epochs, self.max_epochs, self.min_improvement, self.dimensionality,
+                self.feature_init, self.learning_rate, self.K, self.svd_u, self.svd_v,
+                ratings_index, ratings, self.nbr_users, self.nbr_items, int(verbose))
+
+    train = feature_training                                                  # :545
+    fit = feature_training
+
+    def feature_training_bias(self, initialize_model=True, handle_bias=False, verbose=False):
+        """gradient_descent.py:472-503: learned biases, full k-dot per rating."""
+        if initialize_model:
+            self.init_feature_const()
+        ratings_index, ratings = self.get_ratings(randomize_order=True)
+        self.compute_overall_avg()
+        self.compute_items_bias_bk()
+        self.compute_users_bias_bk()
+        _kernels.estimator_loop_with_learned_bias(
+            self.min_epochs, self.max_epochs, self.min_improvement, self.dimensionality,
+            self.feature_init, self.learning_rate, self.learning_rate_users,
+            self.learning_rate_items, self.K, self.K2, self.overall_bias, self.svd_u, self.svd_v,
+            ratings_index, ratings, self.items_bias, self.users_bias, self.nbr_users,
+            self.nbr_items, int(verbose))
+
+    def predict_rating(self, item_index, user_index):                         # :621-631
+        return np.dot(self.svd_u[:, item_index], self.svd_v[:, user_index]) + 1.0
+
+    predict = predict_rating                                                  # :634
+
+    def predict_rating_with_bias(self, item_index, user_index):               # :637-648
+        s = np.dot(self.svd_u[:, item_index], self.svd_v[:, user_index])
+        return s + self.overall_bias + (self.items_bias[item_index] + self.users_bias[user_index])

@@ -1,0 +1,104 @@
+"""GPU: the recommender classes (train / fit / predict surface) against the oracle run on
+the same injected permutation and initial factors (the reference shuffles and initialises
+with the unseeded global numpy RNG: base.py:1128-1129, mf.py:132-133)."""
+import numpy as np
+import pytest
+
+from mfrec_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    from mfrec_amd import _shim as S
+    from mfrec_amd import build as B
+    B.build(verbose=False)
+    S.init(0)
+    yield
+
+
+def _fill(R, nu, ni, nnz, seed):
+    idx, r = synth.make_ratings(nu, ni, nnz, seed=seed)
+    R.set_ratings(idx, r)
+    return R
+
+
+def test_kmf_recommender_matches_oracle():
+    from mfrec_amd.recommendation import KMFRecommender
+    from oracle import oracle as O
+    nu, ni, k = 200, 150, 12
+    for kernel, ofn, pred in (("train_linear_kernel", O.train_linear_kernel, "predict_linear"),
+                              ("train_logistic_kernel", O.train_logistic_kernel, "predict_logistic")):
+        R = _fill(KMFRecommender(nu, ni, {"nbr_epochs": 4, "nbr_features": k}), nu, ni, 5000, 9)
+        np.random.seed(123)
+        R.train(kernel=kernel)
+        # replay the same RNG stream for the oracle
+        np.random.seed(123)
+        u = np.random.normal(0.0, 0.1, [k, ni]); v = np.random.normal(0.0, 0.1, [k, nu])
+        idx, r = R.get_ratings(randomize_order=True)
+        ib, ub = np.zeros(ni), np.zeros(nu)
+        ofn(4, k, 0.1, 0.01, 0.01, 0.01, 0.1, 0.1, 0.007, 0.0, u, v, idx, r, ib, ub)
+        if kernel == "train_linear_kernel":
+            assert np.array_equal(R.svd_u, u) and np.array_equal(R.svd_v, v)
+            assert np.array_equal(R.items_bias, ib) and np.array_equal(R.users_bias, ub)
+        else:
+            np.testing.assert_allclose(R.svd_u, u, rtol=1e-11, atol=1e-14)
+        kind = O.RMSE_KMF_LINEAR if pred == "predict_linear" else O.RMSE_KMF_LOGISTIC
+        assert abs(R.train_rmse(pred) - O.rmse(kind, u, v, idx, r, ib, ub)) <= 1e-5
+        # scalar predict(item, user) agrees with the batched one
+        p = getattr(R, pred)(int(idx[0, 1]), int(idx[0, 0]))
+        from mfrec_amd.recommendation.metrics import predict_batch
+        assert abs(predict_batch(R, idx[:1], pred)[0][0] - p) < 1e-12
+    assert KMFRecommender.fit is KMFRecommender.train
+
+
+def test_gd_recommender_matches_oracle():
+    from mfrec_amd.recommendation import GDRecommender
+    from oracle import oracle as O
+    nu, ni, k = 150, 100, 6
+    params = {"min_epochs": 4, "max_epochs": 4, "min_improvement": 1e9, "nbr_features": k}
+    for handle_bias in (False, True):
+        R = _fill(GDRecommender(nu, ni, params), nu, ni, 4000, 4)
+        np.random.seed(5)
+        R.train(handle_bias=handle_bias)
+        np.random.seed(5)
+        idx, r = R.get_ratings(randomize_order=True)
+        u, v = synth.init_const(k, ni), synth.init_const(k, nu)
+        if handle_bias:
+            O.estimator_loop_with_bias(4, 4, 1e9, k, 0.1, 0.001, 0, 0, 0.05, R.overall_bias, u, v,
+                                       idx, r, R.items_bias, R.users_bias, nu, ni)
+            pred, kind = "predict_rating_with_bias", O.RMSE_GD_BIAS
+        else:
+            O.estimator_loop_without_bias(4, 4, 1e9, k, 0.1, 0.001, 0.05, u, v, idx, r, nu, ni)
+            pred, kind = "predict_rating", O.RMSE_GD
+        assert np.array_equal(R.svd_u, u) and np.array_equal(R.svd_v, v)
+        ref = O.rmse(kind, u, v, idx, r, R.items_bias, R.users_bias, R.overall_bias or 0.0)
+        assert abs(R.train_rmse(pred) - ref) <= 1e-5
+    # learned-bias trainer (gradient_descent.py:472-503)
+    R = _fill(GDRecommender(nu, ni, params), nu, ni, 4000, 4)
+    np.random.seed(6)
+    R.feature_training_bias()
+    assert R.svd_u.shape == (k, ni) and np.isfinite(R.svd_u).all()
+
+
+def test_wrmf_recommender_matches_oracle():
+    from mfrec_amd.lib.datasets import create_bool_sparse_col, create_bool_sparse_row
+    from mfrec_amd.recommendation import WRMFRecommender
+    from oracle import oracle as O
+    nu, ni, k = 120, 80, 10
+    R = _fill(WRMFRecommender(nu, ni, {"nbr_epochs": 1, "nbr_features": k}), nu, ni, 3000, 8)
+    R.train()
+    u, v = synth.init_const(k, ni), synth.init_const(k, nu)
+    a, b = create_bool_sparse_row(R.relationship_matrix)
+    c, d = create_bool_sparse_col(R.relationship_matrix)
+    O.als_wrmf(1, k, u, v, None, None, a, b, c, d, nu, ni, 1, 0.015)
+    np.testing.assert_allclose(R.svd_u, u, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(R.svd_v, v, rtol=1e-8, atol=1e-10)
+    assert abs(R.predict(3, 5) - np.dot(u[:, 3], v[:, 5])) < 1e-9
+
+
+def test_unknown_parameter_raises():
+    from mfrec_amd.recommendation import Error, GDRecommender
+    with pytest.raises(Error, match="Wrong parameters"):
+        GDRecommender(4, 4, {"no_such_parameter": 1})

@@ -1,0 +1,85 @@
+"""CPU: host-side marshalling that sits either side of the kernels."""
+import numpy as np
+import scipy.sparse as sp
+
+from mfrec_amd.lib import datasets as D
+from mfrec_amd.recommendation import Error, GDRecommender, KMFRecommender, WRMFRecommender
+
+
+def test_create_bool_sparse_matches_reference_fixture(golden):
+    g = golden("g10_datasets")
+    M = sp.coo_matrix((g["in_val"], (g["in_row"], g["in_col"])), shape=tuple(g["p_shape"])).tolil()
+    a, b = D.create_bool_sparse_row(M)
+    c, d = D.create_bool_sparse_col(M)
+    for x, y in ((a, "out_urow"), (b, "out_ucol"), (c, "out_irow"), (d, "out_icol")):
+        assert x.dtype == np.int32 and np.array_equal(x, g[y])
+
+
+def test_als_fixture_runlength_matches_reference(golden):
+    g = golden("g6_als")
+    M = sp.coo_matrix((g["in_coo_val"], (g["in_coo_row"], g["in_coo_col"])),
+                      shape=(int(g["p_nu"]), int(g["p_ni"]))).tolil()
+    a, b = D.create_bool_sparse_row(M)
+    c, d = D.create_bool_sparse_col(M)
+    assert np.array_equal(a, g["in_urow"]) and np.array_equal(b, g["in_ucol"])
+    assert np.array_equal(c, g["in_irow"]) and np.array_equal(d, g["in_icol"])
+
+
+def test_get_ratings_order_and_shuffle():
+    R = GDRecommender(5, 4, {"nbr_features": 3})
+    for a, b, x in ((2, 0, 5), (0, 1, 3), (0, 0, 1), (4, 3, 2)):
+        R.set_item_by_id(a, b, x)
+    idx, r = R.get_ratings()
+    assert idx.dtype == np.int32 and r.dtype == np.float64
+    assert idx.tolist() == [[0, 0], [0, 1], [2, 0], [4, 3]] and r.tolist() == [1, 3, 5, 2]
+    np.random.seed(3)
+    idx2, r2 = R.get_ratings(randomize_order=True)
+    np.random.seed(3)
+    order = np.arange(4); np.random.shuffle(order)
+    assert np.array_equal(idx2, idx[order]) and np.array_equal(r2, r[order])
+    R.compute_overall_avg()
+    assert R.overall_bias == 2.75 and R.get_nbr_ratings() == 4
+
+
+def test_bellkor_biases():
+    R = GDRecommender(4, 3, {})
+    trip = [(0, 0, 5.0), (0, 1, 3.0), (1, 0, 4.0), (2, 2, 1.0), (3, 0, 2.0)]
+    for a, b, x in trip:
+        R.set_item_by_id(a, b, x)
+    R.compute_overall_avg(); R.compute_items_bias_bk(); R.compute_users_bias_bk()
+    mu = np.mean([t[2] for t in trip])
+    bi = np.zeros(3); bu = np.zeros(4)
+    for i in range(3):                       # direct evaluation of mf.py:95
+        xs = [x - mu for (a, b, x) in trip if b == i]
+        bi[i] = sum(xs) / (R.K3 + len(xs)) if xs else 0.0
+    for u in range(4):                       # mf.py:119
+        xs = [x - mu - bi[b] for (a, b, x) in trip if a == u]
+        bu[u] = sum(xs) / (R.K2 + len(xs)) if xs else 0.0
+    np.testing.assert_allclose(R.items_bias, bi, rtol=1e-14)
+    np.testing.assert_allclose(R.users_bias, bu, rtol=1e-14)
+
+
+def test_defaults_and_parameter_maps():
+    g, k, w = GDRecommender(), KMFRecommender(), WRMFRecommender()
+    assert (g.min_epochs, g.learning_rate, g.K, g.dimensionality, g.feature_init) == (275, 0.001, 0.05, 40, 0.1)
+    assert (k.nbr_epochs, k.learning_rate, k.K_users, k.K_items, k.K_bias) == (200, 0.01, 0.1, 0.1, 0.007)
+    assert (w.nbr_epochs, w.dimensionality) == (20, 20)
+    k2 = KMFRecommender(3, 3, {"regularization_users": 9.0})
+    assert k2.K == 9.0 and k2.K_users == 0.1          # the reference's inert mapping (kmf.py:39-41)
+    try:
+        WRMFRecommender(3, 3, {"bogus": 1})
+        assert False
+    except Error:
+        pass
+    assert GDRecommender.fit is GDRecommender.train or GDRecommender.fit == GDRecommender.train
+
+
+def test_snapshot_roundtrip(tmp_path):
+    R = GDRecommender(3, 2, {"nbr_features": 2})
+    R.svd_u, R.svd_v = np.arange(4.0).reshape(2, 2), np.arange(6.0).reshape(2, 3)
+    R.save_model_snapshot(str(tmp_path / "m"))
+    Q = GDRecommender(3, 2, {"nbr_features": 2})
+    Q.load_model_snapshot(str(tmp_path / "m"))
+    assert np.array_equal(Q.svd_u, R.svd_u) and np.array_equal(Q.svd_v, R.svd_v)
+    z = np.load(str(tmp_path / "m") + "_model_snapshot.npz")
+    assert sorted(z.files) == ["svd_u", "svd_v"]          # keys of base.py:805-806

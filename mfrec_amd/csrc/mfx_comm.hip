@@ -7,6 +7,7 @@
 //     U <- U_start + scale * allreduce_sum(U_local - U_start)
 // RCCL is loaded lazily (dlopen) so single-GPU users never pay for it.
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 #include "mfx_common.h"
 
@@ -100,7 +101,7 @@ struct ShardCtx {
 
 int shard_hook(mfx_sgd_plan *p, int, void *vctx)
 {
-    if (g_world <= 1) return MFX_OK;      // a single shard is the sequential algorithm itself
+    if (!g_comm) return MFX_OK;           // a single shard is the sequential algorithm itself
     ShardCtx *c = (ShardCtx *)vctx;
     const size_t nU = (size_t)mfx::plan_ni(p) * mfx::plan_k(p), nb = (size_t)mfx::plan_ni(p);
     double *U = mfx::plan_U(p), *ib = mfx::plan_ib(p);
@@ -139,7 +140,10 @@ int mfx_comm_init(int rank, int world, const void *id)
     if (rc) return rc;
     g_rank = rank;
     g_world = world;
-    if (world == 1) return MFX_OK;
+    // world == 1 needs no communicator; MFX_FORCE_COMM=1 builds a 1-rank one anyway so that
+    // the RCCL plumbing can be exercised on a single-GPU box (tests/test_gpu_comm.py)
+    const char *force = getenv("MFX_FORCE_COMM");
+    if (world == 1 && !(force && force[0] == '1' && id)) return MFX_OK;
     rc = load_rccl();
     if (rc) return rc;
     ncclUniqueId uid;
@@ -168,7 +172,7 @@ int mfx_comm_destroy(void)
 int mfx_comm_barrier(void)
 {
     if (!mfx::ready()) return MFX_OK;
-    if (g_world > 1 && g_comm) {
+    if (g_comm) {
         MFX_HIP(hipMemsetAsync(g_token, 0, sizeof(double), mfx::stream()));
         MFX_NCCL(R.AllReduce(g_token, g_token, 1, ncclFloat64, ncclSum, g_comm, mfx::stream()));
     }
@@ -182,7 +186,7 @@ int mfx_sgd_run_kmf_sharded(mfx_sgd_plan *p, int mode, int nbr_epochs, double lr
     if (!p) return mfx::fail(MFX_E_ARG, "mfx_sgd_run_kmf_sharded: NULL plan");
     if (g_world > 1 && !g_comm) return mfx::fail(MFX_E_STATE, "mfx_comm_init has not been called");
     ShardCtx c{scale, nullptr, nullptr};
-    if (g_world > 1) {
+    if (g_comm) {
         int rc = mfx::plan_prepare_nk(p);
         if (!rc) rc = mfx::plan_start_buffers(p, &c.U_start, &c.ib_start);
         if (rc) return rc;

@@ -1,0 +1,45 @@
+"""GPU (one device): the RCCL plumbing of the sharded mode, exercised with a 1-rank
+communicator (MFX_FORCE_COMM=1): dlopen(librccl), unique id, comm init, the all-reduce on
+the library stream and the delta/combine kernels.  The result must equal the CPU simulation
+of the same arithmetic (U_start + 1.0 * (U - U_start), not bit-identical to U itself)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from mfrec_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_forced_single_rank_comm_matches_simulation():
+    from mfrec_amd import _shim as S
+    from mfrec_amd import build as B
+    from mfrec_amd.sharding import ShardedKMF
+    from oracle import sharded_sim as SIM
+    B.build(verbose=False)
+    S.init(0)
+    nu, ni, nnz, k, E = 400, 250, 12000, 64, 3
+    idx, r = synth.make_ratings(nu, ni, nnz, seed=21)
+    u0, v0 = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
+    os.environ["MFX_FORCE_COMM"] = "1"
+    try:
+        buf = C.create_string_buffer(S.UNIQUE_ID_BYTES)
+        S.check(S.lib().mfx_comm_unique_id(buf))
+        S.check(S.lib().mfx_comm_init(0, 1, buf.raw))
+        T = ShardedKMF(idx, r, nu, ni, k, 0, 1)
+        T.set_factors(u0, v0, np.zeros(ni), np.zeros(nu))
+        rm, se = T.train(0, E, 0.01, 0.1, 0.1, 0.007, scale=1.0)
+        u, v, ib, ub = T.get_local()
+        T.close()
+        S.check(S.lib().mfx_comm_barrier())
+    finally:
+        S.check(S.lib().mfx_comm_destroy())
+        del os.environ["MFX_FORCE_COMM"]
+    su, sv, sib, sub = SIM.simulate(0, 1, E, k, 0.01, 0.1, 0.1, 0.007, u0, v0, np.zeros(ni),
+                                    np.zeros(nu), idx, r, scale=1.0, force_combine=True)
+    assert np.array_equal(u, su) and np.array_equal(v, sv)
+    assert np.array_equal(ib, sib) and np.array_equal(ub, sub)
+    assert np.all(np.isfinite(rm)) and rm[-1] < rm[0]
+    np.testing.assert_allclose(rm, np.sqrt(se / nnz), rtol=1e-15)

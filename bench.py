@@ -152,6 +152,19 @@ def main():
     # cross-check: one instrumented epoch with an event pair around every launch
     kern_ms, _ = plan.profile_kmf(LINEAR, LR, KU, KI, KB)
 
+    # HBM traffic per launch: from the committed rocprofv3 PMC summary of this same command
+    # (profiles/rNN_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes)
+    traffic = traffic_src = None
+    try:
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+        if cands and a.order == "shuffled" and k == 64:
+            tj = json.load(open(cands[-1]))
+            traffic = (tj["read_bytes_per_rating"] + tj["write_bytes_per_rating"]) * nnz / launches
+            traffic_src = os.path.basename(cands[-1])
+    except Exception:
+        traffic = None
+
     if rank == 0:
         value = world * nnz * a.steps / wall
         line = {
@@ -167,7 +180,9 @@ def main():
                        "levels": info["n_levels"], "launches_per_epoch": info["launches_per_epoch"],
                        "sharding": "users x%d, item-delta all-reduce (RCCL)" % world if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
+                         "traffic_unit": "bytes per launch (PMC, %s)" % traffic_src,
+                         "algorithmic_bytes_per_launch": b_read * nnz / launches,
                          "kernel": "k1_level<64,1,%d,linear>" % info["ratings_per_wave"],
                          "bytes_per_update_read": b_read, "bytes_per_update_total": b_total,
                          "avg_launch_us": avg_launch_s * 1e6, "launches_per_epoch": launches,

@@ -13,6 +13,7 @@
 // Device layout: factors row-major [n][k] so that a neighbour row is one contiguous
 // k*8-byte gather; k is padded to KP = 16*ceil(k/16) inside LDS only.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 #include "mfx_common.h"
@@ -234,6 +235,266 @@ __global__ __launch_bounds__(256) void k_als_rows(const double *__restrict__ Y, 
     }
 }
 
+// ------------------------------------------------------------------------------------
+// v2 of the per-row kernel: symmetric-half MFMA tiles, software-prefetched neighbour
+// gather, MFMA-blocked Cholesky (16-wide panels), register back substitution.
+// ------------------------------------------------------------------------------------
+constexpr int CH2 = 32;                // neighbour rows per chunk
+
+__device__ __forceinline__ void tile_ij(int tt, int &I, int &J)
+{
+    int i = 0;
+    while ((i + 1) * (i + 2) / 2 <= tt) ++i;
+    I = i;
+    J = tt - i * (i + 1) / 2;
+}
+
+__device__ __forceinline__ double readlane_f64(double x, int l)      // l must be wave-uniform
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+    return __hiloint2double(hi, lo);
+}
+
+// 1/sqrt(d) to ~1 ulp: hardware estimate + two Newton steps (the result only has to meet
+// the 1e-9 ALS tolerance; a correctly rounded sqrt/divide pair costs ~4x the instructions)
+__device__ __forceinline__ double rsqrt_nr(double d)
+{
+    double y = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    y = y * (1.5 - h * y * y);
+    y = y * (1.5 - h * y * y);
+    return y;
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_als_rows2(const double *__restrict__ Y, int k,
+                                                   const double *__restrict__ G,
+                                                   const int64_t *__restrict__ off,
+                                                   const int32_t *__restrict__ col, double c_pos,
+                                                   double one_plus_c, double lambda, double *X,
+                                                   int *status)
+{
+    constexpr int KP = NT * 16;
+    constexpr int AS = KP + 2;                       // row stride = 2 mod 32 / 18 mod 32 doubles:
+                                                     // conflict-free MFMA operand reads of panels
+    constexpr int NTT = NT * (NT + 1) / 2;           // lower-triangle tiles
+    constexpr int TPW = (NTT + 3) / 4;
+    constexpr int PF = CH2 * KP / 256;               // gathered doubles per thread per chunk
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int S = ych_stride(KP);
+    constexpr int A_ELEMS = (KP + 1) * AS;
+    const int stage_elems = CH2 * S;
+    const int region = (A_ELEMS > stage_elems ? A_ELEMS : stage_elems) + 1 & ~1;
+    double *A = lds;                                 // [KP + 1][AS]; row KP = right-hand side
+    double *ych = lds;                               // aliases A while Y_N^T Y_N is accumulated
+    double *dinv = lds + region;                     // [KP]  1 / L[c][c]
+    int *cidx = (int *)(dinv + KP);                  // [2][CH2] neighbour ids of two chunks
+    int *bad = cidx + 2 * CH2;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int j = blockIdx.x;
+    const int64_t start = off[j];
+    const int span = (int)(off[j + 1] - start);
+    double *xrow = X + (size_t)j * k;
+    if (span == 0) {                                 // b = 0  =>  x = 0 (als_implicit.pyx:298-302)
+        for (int f = tid; f < k; f += 256) xrow[f] = 0.0;
+        return;
+    }
+    if (tid == 0) *bad = 0;
+
+    int tI[TPW], tJ[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        tI[t] = 0; tJ[t] = 0;
+        if (t * 4 + wid < NTT) tile_ij(t * 4 + wid, tI[t], tJ[t]);
+    }
+    double4_t acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    double bsum = 0.0;
+
+    // ---- Y_N^T Y_N and b: chunked gather, next chunk in flight under the MFMAs -----------
+    const int nchunks = (span + CH2 - 1) / CH2;
+    if (tid < CH2) cidx[tid] = (tid < span) ? col[start + tid] : -1;
+    __syncthreads();
+    double pre[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+        const int e = tid + 256 * i, n = e / KP, f = e % KP;
+        const int id = cidx[n];
+        pre[i] = (id >= 0 && f < k) ? Y[(size_t)id * k + f] : 0.0;
+    }
+    int cnext = (tid < CH2 && CH2 + tid < span) ? col[start + CH2 + tid] : -1;
+    for (int c = 0; c < nchunks; ++c) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int e = tid + 256 * i, n = e / KP, f = e % KP;
+            ych[n * S + f] = pre[i];
+        }
+        const int nb = ((c + 1) & 1) * CH2;
+        if (tid < CH2) cidx[nb + tid] = cnext;
+        __syncthreads();
+        if (c + 1 < nchunks) {
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const int e = tid + 256 * i, n = e / KP, f = e % KP;
+                const int id = cidx[nb + n];
+                pre[i] = (id >= 0 && f < k) ? Y[(size_t)id * k + f] : 0.0;
+            }
+            const int t2 = (c + 2) * CH2 + tid;
+            cnext = (tid < CH2 && t2 < span) ? col[start + t2] : -1;
+        }
+        if (tid < KP) {
+#pragma unroll
+            for (int n = 0; n < CH2; ++n) bsum += ych[n * S + tid] * one_plus_c;
+        }
+#pragma unroll
+        for (int n0 = 0; n0 < CH2; n0 += 4) {
+            const double *base = ych + (n0 + (lane >> 4)) * S + (lane & 15);
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+                if (t * 4 + wid < NTT)
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(base[tI[t] * 16], base[tJ[t] * 16],
+                                                                  acc[t], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- A = G + c * acc + lambda I (identity on the padding), b as border row -----------
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        if (t * 4 + wid < NTT) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = tI[t] * 16 + (lane >> 4) + 4 * q, c = tJ[t] * 16 + (lane & 15);
+                double a;
+                if (r < k && c < k) {
+                    a = G[r * KP + c] + acc[t][q] * c_pos;
+                    if (r == c) a += lambda;
+                } else {
+                    a = (r == c) ? 1.0 : 0.0;
+                }
+                A[r * AS + c] = a;
+            }
+        }
+    }
+    if (tid < KP) A[KP * AS + tid] = (tid < k) ? bsum : 0.0;
+    __syncthreads();
+
+    // ---- blocked Cholesky of the bordered matrix, 16-wide panels --------------------------
+    for (int Jb = 0; Jb < NT; ++Jb) {
+        const int c0 = Jb * 16;
+        if (wid == 0) {
+            // (a) diagonal block: lane r (< 16) holds row r in registers; right-looking by columns
+            const int r = lane & 15;
+            double d[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) d[c] = A[(c0 + r) * AS + c0 + c];
+            double myinv = 1.0;
+            bool ok = true;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                const double pj = readlane_f64(d[jj], jj);
+                ok = ok && (pj > 0.0);
+                const double inv = rsqrt_nr(pj);
+                if (r == jj) myinv = inv;
+                d[jj] = (r == jj) ? pj * inv : d[jj] * inv;
+#pragma unroll
+                for (int c = jj + 1; c < 16; ++c) {
+                    const double lcj = readlane_f64(d[jj], c);
+                    d[c] -= d[jj] * lcj;
+                }
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+                    if (c <= r) A[(c0 + r) * AS + c0 + c] = d[c];
+                dinv[c0 + r] = myinv;
+            }
+            if (!ok && lane == 0) *bad = 1;
+        }
+        __syncthreads();
+        // (b) panel: rows below the block and the border row:  X = A21 * L11^{-T}
+        {
+            const int pr = c0 + 16 + tid;            // physical row; pr == KP is the border row
+            if (pr <= KP) {
+                double a[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) a[c] = A[pr * AS + c0 + c];
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) {
+                    double x = a[jj];
+#pragma unroll
+                    for (int m = 0; m < jj; ++m) x -= a[m] * A[(c0 + jj) * AS + c0 + m];
+                    a[jj] = x * dinv[c0 + jj];
+                }
+#pragma unroll
+                for (int c = 0; c < 16; ++c) A[pr * AS + c0 + c] = a[c];
+            }
+        }
+        __syncthreads();
+        // (c) trailing update.  Border row first (VALU), then the lower tiles on the matrix cores
+        {
+            const int c = c0 + 16 + tid;
+            if (c < KP) {
+                double sum = 0.0;
+#pragma unroll
+                for (int m = 0; m < 16; ++m) sum += A[KP * AS + c0 + m] * A[c * AS + c0 + m];
+                A[KP * AS + c] -= sum;
+            }
+        }
+        {
+            const int nt = NT - Jb - 1;              // trailing tile rows
+            const int ntt = nt * (nt + 1) / 2;
+            for (int tt = wid; tt < ntt; tt += 4) {
+                int I, J2;
+                tile_ij(tt, I, J2);
+                I += Jb + 1;
+                J2 += Jb + 1;
+                double4_t cacc;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    cacc[q] = A[(I * 16 + (lane >> 4) + 4 * q) * AS + J2 * 16 + (lane & 15)];
+                const double *pa = A + (I * 16 + (lane & 15)) * AS + c0 + (lane >> 4);
+                const double *pb = A + (J2 * 16 + (lane & 15)) * AS + c0 + (lane >> 4);
+#pragma unroll
+                for (int s4 = 0; s4 < 16; s4 += 4)
+                    cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[s4], pb[s4], cacc, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    A[(I * 16 + (lane >> 4) + 4 * q) * AS + J2 * 16 + (lane & 15)] = cacc[q];
+            }
+        }
+        __syncthreads();
+    }
+    if (*bad) {
+        if (tid == 0) atomicExch(status, j + 1);
+        return;
+    }
+
+    // ---- back substitution L^T x = z (z = border row) by wave 0, x in registers ----------
+    if (wid == 0) {
+        double z0 = A[KP * AS + lane];               // KP >= 16; lanes >= KP read padding zeros
+        double z1 = (KP > 64) ? A[KP * AS + 64 + (lane < KP - 64 ? lane : 0)] : 0.0;
+        if (KP <= 64 && lane >= KP) z0 = 0.0;
+        if (KP > 64 && lane >= KP - 64) z1 = 0.0;
+        for (int c = KP - 1; c >= 64; --c) {         // pivots owned by z1
+            const double x = readlane_f64(z1, c - 64) * dinv[c];
+            if (lane == c - 64) z1 = x;
+            z0 -= A[c * AS + lane] * x;
+            if (lane + 64 < c) z1 -= A[c * AS + lane + 64] * x;
+        }
+        for (int c = (KP > 64 ? 63 : KP - 1); c >= 0; --c) {
+            const double x = readlane_f64(z0, c) * dinv[c];
+            if (lane == c) z0 = x;
+            if (lane < c) z0 -= A[c * AS + lane] * x;
+        }
+        if (lane < k) xrow[lane] = z0;
+        if (lane + 64 < k) xrow[lane + 64] = z1;
+    }
+}
+
 // out[c][r] = in[r][c]
 __global__ __launch_bounds__(256) void k_transpose_als(const double *in, double *out, int rows, int cols)
 {
@@ -253,11 +514,22 @@ __global__ __launch_bounds__(256) void k_transpose_als(const double *in, double 
 
 struct AlsKernels {
     void *gram;
-    void *rows;
+    void *rows;     // v1: unblocked (kept as a cross-check, MFX_ALS_V1=1)
+    void *rows2;    // v2: blocked
 };
 
 template <int NT>
-AlsKernels als_kernels_nt() { return {(void *)k_gram_partial<NT>, (void *)k_als_rows<NT>}; }
+AlsKernels als_kernels_nt()
+{
+    return {(void *)k_gram_partial<NT>, (void *)k_als_rows<NT>, (void *)k_als_rows2<NT>};
+}
+
+size_t rows2_lds_bytes(int KP)
+{
+    const size_t a = (size_t)(KP + 1) * (KP + 2), st = (size_t)CH2 * ych_stride(KP);
+    const size_t region = ((a > st ? a : st) + 1) & ~(size_t)1;
+    return (region + KP) * sizeof(double) + (2 * CH2 + 2) * sizeof(int);
+}
 
 AlsKernels als_kernels(int nt)
 {
@@ -311,10 +583,14 @@ int als_half(int k, int NT, const AlsKernels &K, const double *dY, int ny, doubl
         MFX_HIP(hipGetLastError());
     }
     if (n_active > 0) {
+        const char *v1 = getenv("MFX_ALS_V1");
+        const bool use_v1 = v1 && v1[0] == '1';
         const size_t a_elems = (size_t)(KP + 1) * (KP + 1);
-        const size_t lds = (a_elems + (a_elems & 1) + (size_t)CH * ych_stride(KP) + KP + 2) * sizeof(double);
+        const size_t lds = use_v1 ? (a_elems + (a_elems & 1) + (size_t)CH * ych_stride(KP) + KP + 2) * sizeof(double)
+                                  : rows2_lds_bytes(KP);
+        void *rows_fn = use_v1 ? K.rows : K.rows2;
         if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute(K.rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(rows_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         const double *Yc = dY;
         const double *Gc = dG;
         int kk = k;
@@ -327,7 +603,7 @@ int als_half(int k, int NT, const AlsKernels &K, const double *dY, int ny, doubl
             double *X_s = dX + (size_t)r0 * k;
             args[3] = &off_s;
             args[8] = &X_s;
-            MFX_HIP(hipLaunchKernel(K.rows, dim3(n), dim3(256), args, lds, s));
+            MFX_HIP(hipLaunchKernel(rows_fn, dim3(n), dim3(256), args, lds, s));
         }
     }
     return MFX_OK;

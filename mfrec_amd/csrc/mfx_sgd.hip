@@ -37,6 +37,9 @@ struct mfx_sgd_plan {
     bool have_factors = false;
     bool nk_current = false, km_current = false;
 
+    K2Dyn *d_k2dyn = nullptr;            // Funk per-feature record (lazy)
+    hipGraphExec_t graph2 = nullptr;     // cached hipGraph of one Funk epoch
+    K2Params graph2_params{};
     // cached hipGraph of one full-k epoch
     hipGraphExec_t graph = nullptr;
     K1Params graph_params{};
@@ -75,6 +78,8 @@ void drop_graph(mfx_sgd_plan *p)
     if (p->graph) (void)hipGraphExecDestroy(p->graph);
     p->graph = nullptr;
     p->graph_mode = -1;
+    if (p->graph2) (void)hipGraphExecDestroy(p->graph2);
+    p->graph2 = nullptr;
 }
 
 int transpose(const double *in, double *out, int rows, int cols)
@@ -414,7 +419,7 @@ void mfx_sgd_plan_destroy(mfx_sgd_plan *p)
     if (ready()) (void)hipStreamSynchronize(stream());
     drop_graph(p);
     void *ptrs[] = {p->d_recs, p->d_U_km, p->d_V_km, p->d_U_nk, p->d_V_nk, p->d_ib, p->d_ub,
-                    p->d_cache, p->d_se_partial, p->d_se_tmp, p->d_se_epoch, p->d_counter, p->d_U_start,
+                    p->d_cache, p->d_k2dyn, p->d_se_partial, p->d_se_tmp, p->d_se_epoch, p->d_counter, p->d_U_start,
                     p->d_ib_start};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -520,6 +525,19 @@ int mfx_sgd_profile_kmf(mfx_sgd_plan *p, int mode, double lr, double Ku, double 
 }
 
 // ---- Funk: per-feature passes with the data-dependent stopping rule (host-driven) ----
+static int enqueue_k2_epoch(mfx_sgd_plan *p, const K2Params &P)
+{
+    for (int64_t l = 0; l < p->n_levels; ++l) {
+        const int64_t start = p->level_off[l];
+        const int count = (int)(p->level_off[l + 1] - start);
+        if (count <= 0) continue;
+        hipLaunchKernelGGL(k2_level, dim3(ceil_div(count, 256)), dim3(256), 0, stream(), P, start,
+                           count, p->k2_wave_off[l]);
+    }
+    MFX_HIP(hipGetLastError());
+    return enqueue_reduce(p, p->k2_waves);
+}
+
 int mfx_sgd_run_funk(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_init,
                      double lr, double K, double mu, int use_bias, int upd_u, int upd_i,
                      int epoch_cap, double *rmse_hist, int64_t hist_cap, int64_t *n_hist)
@@ -531,6 +549,7 @@ int mfx_sgd_run_funk(mfx_sgd_plan *p, int min_epochs, double min_improvement, do
     p->nk_current = false;
     if (!p->d_cache) {
         rc = dev_alloc(p, &p->d_cache, (size_t)p->nnz);
+        if (!rc) rc = dev_alloc(p, &p->d_k2dyn, 1);
         if (rc) return rc;
     }
     MFX_HIP(hipMemsetAsync(p->d_cache, 0, (size_t)(p->nnz ? p->nnz : 1) * sizeof(double), stream()));
@@ -539,6 +558,7 @@ int mfx_sgd_run_funk(mfx_sgd_plan *p, int min_epochs, double min_improvement, do
     K2Params P;
     memset(&P, 0, sizeof(P));
     P.recs = p->d_recs;
+    P.dyn = p->d_k2dyn;
     P.cache = p->d_cache;
     P.ib = use_bias ? p->d_ib : nullptr;
     P.ub = use_bias ? p->d_ub : nullptr;
@@ -549,24 +569,46 @@ int mfx_sgd_run_funk(mfx_sgd_plan *p, int min_epochs, double min_improvement, do
     P.upd_u = upd_u ? 1 : 0;
     P.upd_i = upd_i ? 1 : 0;
     const int commit_blocks = (int)(p->nnz ? (ceil_div(p->nnz, (int64_t)256) < 4096 ? ceil_div(p->nnz, (int64_t)256) : 4096) : 1);
+
+    // one epoch = all levels + the SE reduction, captured once and replayed for every
+    // (feature, epoch): the per-feature pointers live behind P.dyn
+    const bool graph = use_graph();
+    if (graph && !(p->graph2 && memcmp(&p->graph2_params, &P, sizeof(P)) == 0)) {
+        if (p->graph2) (void)hipGraphExecDestroy(p->graph2);
+        p->graph2 = nullptr;
+        hipGraph_t g = nullptr;
+        MFX_HIP(hipStreamBeginCapture(stream(), hipStreamCaptureModeThreadLocal));
+        rc = enqueue_k2_epoch(p, P);
+        hipError_t e = hipStreamEndCapture(stream(), &g);
+        if (rc || e != hipSuccess) {
+            if (g) (void)hipGraphDestroy(g);
+            return rc ? rc : fail(MFX_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+        }
+        e = hipGraphInstantiate(&p->graph2, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e != hipSuccess) {
+            p->graph2 = nullptr;
+            return fail(MFX_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+        }
+        p->graph2_params = P;
+    }
     for (int f = 0; f < p->k; ++f) {
-        P.uf = p->d_U_km + (size_t)f * p->ni;
-        P.vf = p->d_V_km + (size_t)f * p->nu;
-        P.trail = (p->k - f - 1) * f_init * f_init;          // gd_estimator.pyx:70
+        K2Dyn dyn;
+        dyn.uf = p->d_U_km + (size_t)f * p->ni;
+        dyn.vf = p->d_V_km + (size_t)f * p->nu;
+        dyn.trail = (p->k - f - 1) * f_init * f_init;        // gd_estimator.pyx:70
+        MFX_HIP(hipMemcpyAsync(p->d_k2dyn, &dyn, sizeof(dyn), hipMemcpyHostToDevice, stream()));
+        MFX_HIP(hipStreamSynchronize(stream()));             // `dyn` is a stack object
         int epoch = 0;
         while (epoch < min_epochs || rmse <= rmse_last - min_improvement) {
             if (epoch_cap > 0 && epoch >= epoch_cap) break;
             rmse_last = rmse;
             MFX_HIP(hipMemsetAsync(p->d_counter, 0, sizeof(int), stream()));
-            for (int64_t l = 0; l < p->n_levels; ++l) {
-                const int64_t start = p->level_off[l];
-                const int count = (int)(p->level_off[l + 1] - start);
-                if (count <= 0) continue;
-                hipLaunchKernelGGL(k2_level, dim3(ceil_div(count, 256)), dim3(256), 0, stream(), P,
-                                   start, count, p->k2_wave_off[l]);
+            if (graph) MFX_HIP(hipGraphLaunch(p->graph2, stream()));
+            else {
+                rc = enqueue_k2_epoch(p, P);
+                if (rc) return rc;
             }
-            rc = enqueue_reduce(p, p->k2_waves);
-            if (rc) return rc;
             double se = 0.0;
             MFX_HIP(hipMemcpyAsync(&se, p->d_se_epoch, sizeof(double), hipMemcpyDeviceToHost, stream()));
             MFX_HIP(hipStreamSynchronize(stream()));
@@ -575,9 +617,7 @@ int mfx_sgd_run_funk(mfx_sgd_plan *p, int min_epochs, double min_improvement, do
             ++nh;
             ++epoch;
         }
-        K2Params Pc = P;
-        Pc.trail = 0.0;
-        hipLaunchKernelGGL(k2_commit, dim3(commit_blocks), dim3(256), 0, stream(), Pc, p->nnz);
+        hipLaunchKernelGGL(k2_commit, dim3(commit_blocks), dim3(256), 0, stream(), P, p->nnz);
         MFX_HIP(hipGetLastError());
     }
     MFX_HIP(hipStreamSynchronize(stream()));

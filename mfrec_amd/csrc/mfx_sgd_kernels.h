@@ -247,15 +247,22 @@ __global__ __launch_bounds__(kWaves * 64) void k1_level(K1Params P, int64_t star
 // K2: Funk per-feature pass.  One lane per rating of one level; the feature vectors
 // uf = U[f, :], vf = V[f, :] are feature-major slices (L2 resident).
 // ------------------------------------------------------------------------------------
-struct K2Params {
-    const Rec *recs;
+// per-feature state, read through a device pointer so that ONE captured epoch graph serves
+// every feature of the run (only this 24-byte record changes between features)
+struct K2Dyn {
     double *uf;           // U + f*ni
     double *vf;           // V + f*nu
+    double trail;         // (k - f - 1) * f_init^2, gd_estimator.pyx:70
+};
+
+struct K2Params {
+    const Rec *recs;
+    const K2Dyn *dyn;
     double *cache;        // level-major, one per rating
     const double *ib;     // nullable (without_bias)
     const double *ub;
     double *se_partial;
-    double lr, K, mu, trail;
+    double lr, K, mu;
     int upd_u, upd_i;
 };
 
@@ -278,18 +285,20 @@ __global__ __launch_bounds__(256) void k2_level(K2Params P, int64_t start, int c
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     double e2 = 0.0;
+    double *const uf = P.dyn->uf, *const vf = P.dyn->vf;
+    const double trail = P.dyn->trail;
     if (t < count) {
         const Rec rec = P.recs[start + t];
         const double c = P.cache[start + t];
         double base;
         if (P.ib) base = P.mu + P.ib[rec.item] + P.ub[rec.user];
         else base = P.mu + 0.0 + 0.0;
-        const double mf = P.uf[rec.item], cf = P.vf[rec.user];
-        const double p = funk_estimate(mf, cf, c, base, P.trail, true);
+        const double mf = uf[rec.item], cf = vf[rec.user];
+        const double p = funk_estimate(mf, cf, c, base, trail, true);
         const double err = rec.r - p;
         e2 = err * err;
-        if (P.upd_i) P.uf[rec.item] = mf + P.lr * (err * cf - P.K * mf);
-        if (P.upd_u) P.vf[rec.user] = cf + P.lr * (err * mf - P.K * cf);
+        if (P.upd_i) uf[rec.item] = mf + P.lr * (err * cf - P.K * mf);
+        if (P.upd_u) vf[rec.user] = cf + P.lr * (err * mf - P.K * cf);
     }
     const double wsum = wave_sum_fixed(e2);
     if ((threadIdx.x & 63) == 0)
@@ -299,13 +308,14 @@ __global__ __launch_bounds__(256) void k2_level(K2Params P, int64_t start, int c
 // cache-commit pass (gd_estimator.pyx:771-777): embarrassingly parallel over all ratings
 __global__ __launch_bounds__(256) void k2_commit(K2Params P, int64_t nnz)
 {
+    const double *const uf = P.dyn->uf, *const vf = P.dyn->vf;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < nnz;
          t += (int64_t)gridDim.x * 256) {
         const Rec rec = P.recs[t];
         double base;
         if (P.ib) base = P.mu + P.ib[rec.item] + P.ub[rec.user];
         else base = P.mu + 0.0 + 0.0;
-        P.cache[t] = funk_estimate(P.uf[rec.item], P.vf[rec.user], P.cache[t], base, 0.0, false);
+        P.cache[t] = funk_estimate(uf[rec.item], vf[rec.user], P.cache[t], base, 0.0, false);
     }
 }
 

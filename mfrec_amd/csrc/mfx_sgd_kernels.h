@@ -13,6 +13,21 @@
 #pragma once
 #include "mfx_common.h"
 
+// Diagnostic builds only (tools/k1_stamps.hip defines MFX_K1_STAMPS): per-wave s_memtime
+// stamps written to a side buffer that nothing else reads.  The product build has none.
+#ifdef MFX_K1_STAMPS
+#define MFX_STAMP(i)                                                                          \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        unsigned long long t_;                                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        if (lane == 0) P.stamps[(wave_off + wave_g) * 8 + (i)] = t_;                          \
+    } while (0)
+#else
+#define MFX_STAMP(i) do { } while (0)
+#endif
+
 namespace mfx {
 
 struct Rec {        // one rating in level-major order: 16 B, one dwordx4 load
@@ -36,9 +51,15 @@ struct K1Params {
     // learned-bias family only
     double lr_u, lr_i, mu, trail;
     int f;               // the single feature that is updated
+#ifdef MFX_K1_STAMPS
+    unsigned long long *stamps;
+#endif
 };
 
-static constexpr int kWaves = 4;         // waves per block
+#ifndef MFX_KWAVES
+#define MFX_KWAVES 4
+#endif
+static constexpr int kWaves = MFX_KWAVES;   // waves per block
 // ratings per wave for rank k (measured on cfg 2, k = 64: 8 per wave = 2 waves per SIMD beats
 // 16 per wave by 19 %; 4 is no better); the product tile stays at <= 8 KB per wave
 static inline int k1_batch(int k) { return k <= 32 ? 16 : (k <= 128 ? 8 : (k <= 256 ? 4 : 2)); }
@@ -78,74 +99,85 @@ __device__ __forceinline__ double wave_sum_fixed(double x)
 
 // KP  lanes per rating slot (8/16/32/64), SPW = 64/KP slots side by side
 // FPL features per lane (f = j*KP + q), NR ratings per slot in flight; SPW*NR == BATCH
-template <int KP, int FPL, int BATCH, int MODE, int NT>
-__global__ __launch_bounds__(kWaves * 64) void k1_level(K1Params P, int64_t start, int count,
-                                                       int64_t wave_off)
+//
+// FULL = the wave holds a complete batch and both update gates are on: no per-rating
+// branches remain, so the 2*BATCH row loads and the 2*BATCH row stores are each ONE basic
+// block.  (With a branch around every store hipcc loses count of the outstanding memory
+// operations and emits s_waitcnt vmcnt(0) before each one: every store then waits for the
+// previous store's round trip -- measured 300 cycles per store instruction.)
+template <int KP, int FPL, int BATCH, int MODE, int NT, bool FULL>
+__device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cnt, int64_t base,
+                                        int64_t slot, double *prod, int lane)
 {
     constexpr int SPW = 64 / KP;
     constexpr int NR = BATCH / SPW;
-    constexpr int kBatch = BATCH;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-
-    const int lane = threadIdx.x & 63;
-    const int wid = threadIdx.x >> 6;
-    const int64_t wave_g = (int64_t)blockIdx.x * kWaves + wid;
-    const int64_t base = wave_g * kBatch;
-    if (base >= count) {                             // wave-uniform; padding wave of the last block
-        if (lane == 0) P.se_partial[wave_off + wave_g] = 0.0;
-        return;
-    }
-    const int cnt = (count - base) < kBatch ? (int)(count - base) : kBatch;
-
     const int k = P.k;
-    const int stride = k1_stride(k);                 // even, = 2 mod 4: conflict-free b128 column walk
-    double *prod = lds + (size_t)wid * kBatch * stride;
-
+    const int stride = k1_stride(k);
     const int g = lane / KP;                         // slot
     const int q = lane % KP;                         // lane in slot
+#ifdef MFX_K1_STAMPS
+    const int64_t wave_off = 0, wave_g = slot;
+#endif
 
+    MFX_STAMP(0);
     // ---- the rating owned by this lane (lanes 0..cnt-1) -------------------------------
     Rec rec;
     rec.user = 0; rec.item = 0; rec.r = 0.0;
-    if (lane < cnt) rec = P.recs[start + base + lane];
+    if (FULL ? (lane < BATCH) : (lane < cnt)) rec = P.recs[start + base + lane];
+#ifdef MFX_K1_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    MFX_STAMP(1);
 
     // ---- gather both factor rows of every rating of the batch -------------------------
     double uval[NR][FPL], vval[NR][FPL];
-    int usr[NR], itm[NR];
+    const double *ur[NR];
+    const double *vr[NR];
 #pragma unroll
     for (int s = 0; s < NR; ++s) {
-        const int n = s * SPW + g;                   // rating number inside the batch
+        int usr, itm;
         if constexpr (KP == 64) {
-            usr[s] = __builtin_amdgcn_readlane(rec.user, s);
-            itm[s] = __builtin_amdgcn_readlane(rec.item, s);
+            usr = __builtin_amdgcn_readlane(rec.user, s);
+            itm = __builtin_amdgcn_readlane(rec.item, s);
         } else {
-            usr[s] = __shfl(rec.user, n, 64);
-            itm[s] = __shfl(rec.item, n, 64);
+            usr = __shfl(rec.user, s * SPW + g, 64);
+            itm = __shfl(rec.item, s * SPW + g, 64);
         }
-        const double *ur = P.U + (size_t)itm[s] * k;
-        const double *vr = P.V + (size_t)usr[s] * k;
+        ur[s] = P.U + (size_t)itm * k;
+        vr[s] = P.V + (size_t)usr * k;
+    }
 #pragma unroll
-        for (int j = 0; j < FPL; ++j) {
-            const int f = j * KP + q;
-            const bool on = (n < cnt) && (f < k);
-            uval[s][j] = on ? ur[f] : 0.0;
-            vval[s][j] = on ? vr[f] : 0.0;
+    for (int j = 0; j < FPL; ++j) {
+        const int f = j * KP + q;
+#pragma unroll
+        for (int s = 0; s < NR; ++s) { uval[s][j] = 0.0; vval[s][j] = 0.0; }
+        if (f < k) {
+#pragma unroll
+            for (int s = 0; s < NR; ++s) {
+                if (FULL || (s * SPW + g < cnt)) {
+                    uval[s][j] = ur[s][f];
+                    vval[s][j] = vr[s][f];
+                }
+            }
         }
     }
     double ibv = 0.0, ubv = 0.0;
-    if (lane < cnt) {
+    if (FULL ? (lane < BATCH) : (lane < cnt)) {
         ibv = P.ib[rec.item];
         ubv = P.ub[rec.user];
     }
+#ifdef MFX_K1_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    MFX_STAMP(2);
 
     // ---- products to LDS: prod[n][f] -------------------------------------------------
 #pragma unroll
-    for (int s = 0; s < NR; ++s) {
-        const int n = s * SPW + g;
+    for (int j = 0; j < FPL; ++j) {
+        const int f = j * KP + q;
+        if (f < k) {
 #pragma unroll
-        for (int j = 0; j < FPL; ++j) {
-            const int f = j * KP + q;
-            if (f < k) prod[n * stride + f] = uval[s][j] * vval[s][j];
+            for (int s = 0; s < NR; ++s) prod[(s * SPW + g) * stride + f] = uval[s][j] * vval[s][j];
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -154,7 +186,7 @@ __global__ __launch_bounds__(kWaves * 64) void k1_level(K1Params P, int64_t star
 
     // ---- lane n: strictly sequential k-term sum, error, gradient, bias update ---------
     double grad = 0.0, e2 = 0.0;
-    if (lane < cnt) {
+    if (FULL ? (lane < BATCH) : (lane < cnt)) {
         double sum;
         if constexpr (MODE == K1_LEARNED) sum = P.mu + ibv + ubv;     // gd_estimator.pyx:138
         else sum = 0.0 + ibv + ubv;                                   // kmf_train.pyx:92
@@ -192,55 +224,92 @@ __global__ __launch_bounds__(kWaves * 64) void k1_level(K1Params P, int64_t star
             P.ib[rec.item] = ibv + P.lr_i * (err - P.Kb * ibv);
         } else {
             // linear: unconditional (kmf_train.pyx:259-260); logistic: gated (:168-171)
-            if (MODE == K1_LINEAR || P.upd_u) P.ub[rec.user] = ubv + P.lr * (grad - P.Kb * ubv);
-            if (MODE == K1_LINEAR || P.upd_i) P.ib[rec.item] = ibv + P.lr * (grad - P.Kb * ibv);
+            if (FULL || MODE == K1_LINEAR || P.upd_u) P.ub[rec.user] = ubv + P.lr * (grad - P.Kb * ubv);
+            if (FULL || MODE == K1_LINEAR || P.upd_i) P.ib[rec.item] = ibv + P.lr * (grad - P.Kb * ibv);
         }
     }
+    MFX_STAMP(3);
 
     // ---- row updates ------------------------------------------------------------------
+    double gr[NR];
 #pragma unroll
     for (int s = 0; s < NR; ++s) {
-        const int n = s * SPW + g;
-        double gr;
         if constexpr (KP == 64) {
             const int lo = __builtin_amdgcn_readlane(__double2loint(grad), s);
             const int hi = __builtin_amdgcn_readlane(__double2hiint(grad), s);
-            gr = __hiloint2double(hi, lo);
+            gr[s] = __hiloint2double(hi, lo);
         } else {
-            gr = shfl_f64(grad, n);
+            gr[s] = shfl_f64(grad, s * SPW + g);
         }
-        if (n < cnt) {
-            double *ur = P.U + (size_t)itm[s] * k;
-            double *vr = P.V + (size_t)usr[s] * k;
+    }
 #pragma unroll
-            for (int j = 0; j < FPL; ++j) {
-                const int f = j * KP + q;
-                if (f < k) {
+    for (int j = 0; j < FPL; ++j) {
+        const int f = j * KP + q;
+        if constexpr (MODE == K1_LEARNED) {
+            if (f == P.f) {                                           // gd_estimator.pyx:476-477
+#pragma unroll
+                for (int s = 0; s < NR; ++s) {
+                    if (FULL || (s * SPW + g < cnt)) {
+                        const double mf = uval[s][j], cf = vval[s][j];
+                        const_cast<double *>(ur[s])[f] = mf + P.lr * (gr[s] * cf - P.Ki * mf);
+                        const_cast<double *>(vr[s])[f] = cf + P.lr * (gr[s] * mf - P.Ku * cf);
+                    }
+                }
+            }
+        } else if (f < k) {
+#pragma unroll
+            for (int s = 0; s < NR; ++s) {
+                if (FULL || (s * SPW + g < cnt)) {
                     const double mf = uval[s][j], cf = vval[s][j];
-                    if constexpr (MODE == K1_LEARNED) {
-                        if (f == P.f) {                               // gd_estimator.pyx:476-477
-                            ur[f] = mf + P.lr * (gr * cf - P.Ki * mf);
-                            vr[f] = cf + P.lr * (gr * mf - P.Ku * cf);
-                        }
+                    const double un = mf + P.lr * (gr[s] * cf - P.Ki * mf);       // kmf_train.pyx:267-270
+                    const double vn = cf + P.lr * (gr[s] * mf - P.Ku * cf);
+                    double *up = const_cast<double *>(ur[s]) + f, *vp = const_cast<double *>(vr[s]) + f;
+                    if constexpr (NT == 1) {
+                        if (FULL || P.upd_i) __builtin_nontemporal_store(un, up);
+                        if (FULL || P.upd_u) __builtin_nontemporal_store(vn, vp);
+                    } else if constexpr (NT == 2) {        // write-through (sc1) 8-byte stores
+                        if (FULL || P.upd_i) __hip_atomic_store(up, un, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (FULL || P.upd_u) __hip_atomic_store(vp, vn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else if constexpr (NT == 3) {        // diagnostic: no row stores
+                        asm volatile("" ::"v"(un), "v"(vn));
                     } else {
-                        const double un = mf + P.lr * (gr * cf - P.Ki * mf);      // kmf_train.pyx:267-270
-                        const double vn = cf + P.lr * (gr * mf - P.Ku * cf);
-                        if constexpr (NT) {
-                            if (P.upd_i) __builtin_nontemporal_store(un, ur + f);
-                            if (P.upd_u) __builtin_nontemporal_store(vn, vr + f);
-                        } else {
-                            if (P.upd_i) ur[f] = un;
-                            if (P.upd_u) vr[f] = vn;
-                        }
+                        if (FULL || P.upd_i) *up = un;
+                        if (FULL || P.upd_u) *vp = vn;
                     }
                 }
             }
         }
     }
+    MFX_STAMP(4);
+#ifdef MFX_K1_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    MFX_STAMP(5);
 
     // ---- squared-error partial of this wave (deterministic) ---------------------------
     const double wsum = wave_sum_fixed(e2);
-    if (lane == 0) P.se_partial[wave_off + wave_g] = wsum;
+    if (lane == 0) P.se_partial[slot] = wsum;
+}
+
+template <int KP, int FPL, int BATCH, int MODE, int NT>
+__global__ __launch_bounds__(kWaves * 64) void k1_level(K1Params P, int64_t start, int count,
+                                                       int64_t wave_off)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    const int64_t wave_g = (int64_t)blockIdx.x * kWaves + wid;
+    const int64_t base = wave_g * BATCH;
+    if (base >= count) {                             // wave-uniform; padding wave of the last block
+        if (lane == 0) P.se_partial[wave_off + wave_g] = 0.0;
+        return;
+    }
+    const int cnt = (count - base) < BATCH ? (int)(count - base) : BATCH;
+    double *prod = lds + (size_t)wid * BATCH * k1_stride(P.k);
+    if (cnt == BATCH && P.upd_u && P.upd_i)
+        k1_body<KP, FPL, BATCH, MODE, NT, true>(P, start, cnt, base, wave_off + wave_g, prod, lane);
+    else
+        k1_body<KP, FPL, BATCH, MODE, NT, false>(P, start, cnt, base, wave_off + wave_g, prod, lane);
 }
 
 // ------------------------------------------------------------------------------------

@@ -1,0 +1,78 @@
+"""GPU: BASELINE.json configs[1] at FULL size (100K x 50K, 10M ratings, k=64).
+
+The oracle needs a few seconds per epoch at this size, so one epoch is compared bit for
+bit; beyond that the tests use size-independent properties of the path:
+  * schedule idempotence: feeding the ratings already in level-major order, or with the
+    ratings of every level internally shuffled, gives bit-identical factors;
+  * the online RMSE decreases monotonically over the first epochs and the batched
+    predict/RMSE kernel agrees with the oracle's RMSE within 1e-5 (the north-star bar)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from mfrec_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+NU, NI, NNZ, K = 100000, 50000, 10000000, 64
+HP = (0.01, 0.1, 0.1, 0.007)
+
+
+@pytest.fixture(scope="module")
+def data():
+    from mfrec_amd import _shim as S
+    from mfrec_amd import build as B
+    B.build(verbose=False)
+    S.init(0)
+    idx, r = synth.make_ratings(NU, NI, NNZ)
+    return idx, r, synth.init_normal(K, NI, synth.SEED_INIT), synth.init_normal(K, NU, synth.SEED_INIT + 1)
+
+
+def _run(idx, r, u0, v0, epochs):
+    from mfrec_amd.plan import SgdPlan
+    u, v, ib, ub = u0.copy(), v0.copy(), np.zeros(NI), np.zeros(NU)
+    with SgdPlan(idx, r, NU, NI, K) as p:
+        p.set_factors(u, v, ib, ub)
+        rm = p.run_kmf(0, epochs, *HP)
+        p.get_factors(u, v, ib, ub)
+        info = p.info()
+    return u, v, ib, ub, rm, info
+
+
+def test_one_epoch_bitexact_vs_oracle_and_properties(data):
+    from mfrec_amd import _shim as S
+    from oracle import oracle as O
+    idx, r, u0, v0 = data
+    u, v, ib, ub, rm, info = _run(idx, r, u0, v0, 1)
+    u2, v2, ib2, ub2, rm2 = u0.copy(), v0.copy(), np.zeros(NI), np.zeros(NU), np.zeros(1)
+    O.train_linear_kernel(1, K, 0.1, HP[0], 0, 0, HP[1], HP[2], HP[3], 0.0, u2, v2, idx, r, ib2, ub2,
+                          1, 1, 0, rm2)
+    assert np.array_equal(u, u2) and np.array_equal(v, v2)
+    assert np.array_equal(ib, ib2) and np.array_equal(ub, ub2)
+    assert abs(rm[0] - rm2[0]) <= 1e-12 * rm2[0]
+    assert 500 < info["n_levels"] < 800 and info["max_level"] < 40000
+
+    # level-major input (stable) and within-level shuffles must not change a single bit
+    lev = np.empty(NNZ, dtype=np.int32); n = C.c_int64(0)
+    S.check(S.lib().mfx_schedule_levels(S.i32(idx, "idx", 2), NNZ, NU, NI, lev.ctypes.data_as(S._ip), C.byref(n)))
+    rs = np.random.RandomState(0)
+    order = np.lexsort((rs.rand(NNZ), lev))           # level-major, random inside a level
+    ua, va, iba, uba, _, _ = _run(np.ascontiguousarray(idx[order]), np.ascontiguousarray(r[order]), u0, v0, 1)
+    assert np.array_equal(ua, u) and np.array_equal(va, v)
+    assert np.array_equal(iba, ib) and np.array_equal(uba, ub)
+
+
+def test_rmse_trajectory_and_predict_kernel(data):
+    from mfrec_amd import _shim as S
+    from oracle import oracle as O
+    idx, r, u0, v0 = data
+    u, v, ib, ub, rm, _ = _run(idx, r, u0, v0, 4)
+    assert np.all(np.diff(rm) < 0) and np.all(np.isfinite(rm))
+    out = C.c_double(0.0)
+    S.check(S.lib().mfx_predict_rmse(1, K, S.f64(u, "u", 2), S.f64(v, "v", 2), S.i32(idx, "idx", 2),
+                                     S.f64(r, "r", 1), S.f64(ib, "ib", 1), S.f64(ub, "ub", 1), 0.0,
+                                     NNZ, NU, NI, None, C.byref(out)))
+    ref = O.rmse(O.RMSE_KMF_LINEAR, u, v, idx, r, ib, ub)
+    assert abs(out.value - ref) <= 1e-5 and abs(out.value - ref) <= 1e-10
+    assert out.value < rm[-1]            # the post-epoch RMSE beats the last online RMSE

@@ -52,6 +52,10 @@ int mfx_device_name(char *buf, int buflen); /* gcnArchName of the bound device  
 /* HIP-event stopwatch on the library's stream (the stream every kernel is launched on). */
 int mfx_timer_start(void);
 int mfx_timer_stop(double *elapsed_ms);
+/* Device time (HIP events on the library stream) of the compute part -- epochs only, no
+ * schedule build, no H2D/D2H -- of the most recent one-shot call that measures it
+ * (currently mfx_als_wrmf); 0 if none. */
+double mfx_last_compute_ms(void);
 
 /* ----------------------------------------------------- host-side scheduling
  * Dependency-level schedule of a rating sequence (pure host code, no GPU).

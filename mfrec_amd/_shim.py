@@ -30,6 +30,7 @@ SIGNATURES = {
     "mfx_device_name": (C.c_int, [C.c_char_p, C.c_int]),
     "mfx_timer_start": (C.c_int, []),
     "mfx_timer_stop": (C.c_int, [_dp]),
+    "mfx_last_compute_ms": (C.c_double, []),
     "mfx_schedule_levels": (C.c_int, [_ip, C.c_int64, C.c_int, C.c_int, _ip, _lp]),
     "mfx_schedule_permutation": (C.c_int, [_ip, C.c_int64, C.c_int64, _lp, _lp]),
     "mfx_kmf_train": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,

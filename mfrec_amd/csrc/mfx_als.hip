@@ -685,6 +685,10 @@ extern "C" int mfx_als_wrmf(int nbr_epochs, int dim, double *u, double *v, const
     MFX_HIP(hipMemset(dStatus.p, 0, 4));
     rc = transpose_to(dUkm.as<double>(), dU.as<double>(), dim, ni);      // [k][ni] -> [ni][k]
     if (!rc) rc = transpose_to(dVkm.as<double>(), dV.as<double>(), dim, nu);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    MFX_HIP(hipEventCreate(&ev0));
+    MFX_HIP(hipEventCreate(&ev1));
+    MFX_HIP(hipEventRecord(ev0, s));
     for (int e = 0; e < nbr_epochs && !rc; ++e) {
         // user pass (als_implicit.pyx:257-302), then item pass (:307-352)
         rc = als_half(dim, NT, K, dU.as<double>(), ni, dV.as<double>(), dUoff.as<int64_t>(), nau,
@@ -695,6 +699,15 @@ extern "C" int mfx_als_wrmf(int nbr_epochs, int dim, double *u, double *v, const
                           dIcol.as<int32_t>(), c_pos, lambda, dPart.as<double>(), dG.as<double>(),
                           dStatus.as<int>());
     }
+    if (!rc) {
+        MFX_HIP(hipEventRecord(ev1, s));
+        MFX_HIP(hipEventSynchronize(ev1));
+        float ms = 0.f;
+        MFX_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+        mfx::set_last_compute_ms((double)ms);
+    }
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
     if (rc) return rc;
     rc = transpose_to(dU.as<double>(), dUkm.as<double>(), ni, dim);
     if (!rc) rc = transpose_to(dV.as<double>(), dVkm.as<double>(), nu, dim);

@@ -14,6 +14,7 @@ int last_code();                              // code of the last fail() / MFX_H
 hipStream_t stream();          // library stream (created by mfx_init)
 bool ready();                  // mfx_init succeeded
 int ensure_init();             // lazily bind device 0 if mfx_init was never called
+void set_last_compute_ms(double ms);
 
 #define MFX_HIP(call)                                                                   \
     do {                                                                                \

@@ -5,6 +5,7 @@
 namespace {
 char g_err[1024] = "";
 int g_code = 0;
+double g_last_ms = 0.0;
 hipStream_t g_stream = nullptr;
 bool g_ready = false;
 int g_device = -1;
@@ -29,6 +30,7 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 int last_code() { return g_code; }
+void set_last_compute_ms(double ms) { g_last_ms = ms; }
 hipStream_t stream() { return g_stream; }
 bool ready() { return g_ready; }
 int ensure_init() { return g_ready ? MFX_OK : mfx_init(0); }
@@ -37,6 +39,7 @@ int ensure_init() { return g_ready ? MFX_OK : mfx_init(0); }
 extern "C" {
 
 int mfx_version(void) { return 100; }
+double mfx_last_compute_ms(void) { return g_last_ms; }
 const char *mfx_last_error(void) { return g_err; }
 
 int mfx_device_count(void)

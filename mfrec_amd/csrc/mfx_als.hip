@@ -267,6 +267,14 @@ __device__ __forceinline__ double rsqrt_nr(double d)
     return y;
 }
 
+// offset (doubles) of row r of the packed lower-block-triangular A (r == 16*NT: border row)
+template <int NT>
+__host__ __device__ constexpr int als_row_off(int r)
+{
+    const int I = r >> 4;
+    return 128 * I * (I + 1) + 32 * I + (r & 15) * (16 * (I + 1) + 2);
+}
+
 template <int NT>
 __global__ __launch_bounds__(256) void k_als_rows2(const double *__restrict__ Y, int k,
                                                    const double *__restrict__ G,
@@ -276,17 +284,20 @@ __global__ __launch_bounds__(256) void k_als_rows2(const double *__restrict__ Y,
                                                    int *status)
 {
     constexpr int KP = NT * 16;
-    constexpr int AS = KP + 2;                       // row stride = 2 mod 32 / 18 mod 32 doubles:
-                                                     // conflict-free MFMA operand reads of panels
+    // A is stored PACKED: only the lower block triangle.  A row of block-row I holds its
+    // 16*(I+1) columns + 2 pad doubles (row stride = 2 or 18 mod 32 doubles: conflict-free
+    // MFMA operand reads of the panels); 77 KB instead of 134 KB at k = 128, so two
+    // workgroups share a CU and one's Cholesky overlaps the other's gather + MFMA phase.
     constexpr int NTT = NT * (NT + 1) / 2;           // lower-triangle tiles
     constexpr int TPW = (NTT + 3) / 4;
     constexpr int PF = CH2 * KP / 256;               // gathered doubles per thread per chunk
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int S = ych_stride(KP);
-    constexpr int A_ELEMS = (KP + 1) * AS;
+    constexpr int BORDER = als_row_off<NT>(KP);      // right-hand side row
+    constexpr int A_ELEMS = BORDER + KP + 2;
     const int stage_elems = CH2 * S;
     const int region = (A_ELEMS > stage_elems ? A_ELEMS : stage_elems) + 1 & ~1;
-    double *A = lds;                                 // [KP + 1][AS]; row KP = right-hand side
+    double *A = lds;                                 // packed lower triangle + border row
     double *ych = lds;                               // aliases A while Y_N^T Y_N is accumulated
     double *dinv = lds + region;                     // [KP]  1 / L[c][c]
     int *cidx = (int *)(dinv + KP);                  // [2][CH2] neighbour ids of two chunks
@@ -375,11 +386,11 @@ __global__ __launch_bounds__(256) void k_als_rows2(const double *__restrict__ Y,
                 } else {
                     a = (r == c) ? 1.0 : 0.0;
                 }
-                A[r * AS + c] = a;
+                A[als_row_off<NT>(r) + c] = a;
             }
         }
     }
-    if (tid < KP) A[KP * AS + tid] = (tid < k) ? bsum : 0.0;
+    if (tid < KP) A[BORDER + tid] = (tid < k) ? bsum : 0.0;
     __syncthreads();
 
     // ---- blocked Cholesky of the bordered matrix, 16-wide panels --------------------------
@@ -389,8 +400,9 @@ __global__ __launch_bounds__(256) void k_als_rows2(const double *__restrict__ Y,
             // (a) diagonal block: lane r (< 16) holds row r in registers; right-looking by columns
             const int r = lane & 15;
             double d[16];
+            const int drow = als_row_off<NT>(c0 + r) + c0;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) d[c] = A[(c0 + r) * AS + c0 + c];
+            for (int c = 0; c < 16; ++c) d[c] = A[drow + c];
             double myinv = 1.0;
             bool ok = true;
 #pragma unroll
@@ -409,7 +421,7 @@ __global__ __launch_bounds__(256) void k_als_rows2(const double *__restrict__ Y,
             if (lane < 16) {
 #pragma unroll
                 for (int c = 0; c < 16; ++c)
-                    if (c <= r) A[(c0 + r) * AS + c0 + c] = d[c];
+                    if (c <= r) A[drow + c] = d[c];
                 dinv[c0 + r] = myinv;
             }
             if (!ok && lane == 0) *bad = 1;
@@ -419,18 +431,21 @@ __global__ __launch_bounds__(256) void k_als_rows2(const double *__restrict__ Y,
         {
             const int pr = c0 + 16 + tid;            // physical row; pr == KP is the border row
             if (pr <= KP) {
+                const int prow = als_row_off<NT>(pr) + c0;
+                const int lrow = als_row_off<NT>(c0) + c0;       // L11; its rows share one stride
+                const int lstride = 16 * (Jb + 1) + 2;
                 double a[16];
 #pragma unroll
-                for (int c = 0; c < 16; ++c) a[c] = A[pr * AS + c0 + c];
+                for (int c = 0; c < 16; ++c) a[c] = A[prow + c];
 #pragma unroll
                 for (int jj = 0; jj < 16; ++jj) {
                     double x = a[jj];
 #pragma unroll
-                    for (int m = 0; m < jj; ++m) x -= a[m] * A[(c0 + jj) * AS + c0 + m];
+                    for (int m = 0; m < jj; ++m) x -= a[m] * A[lrow + jj * lstride + m];
                     a[jj] = x * dinv[c0 + jj];
                 }
 #pragma unroll
-                for (int c = 0; c < 16; ++c) A[pr * AS + c0 + c] = a[c];
+                for (int c = 0; c < 16; ++c) A[prow + c] = a[c];
             }
         }
         __syncthreads();
@@ -439,9 +454,10 @@ __global__ __launch_bounds__(256) void k_als_rows2(const double *__restrict__ Y,
             const int c = c0 + 16 + tid;
             if (c < KP) {
                 double sum = 0.0;
+                const int crow = als_row_off<NT>(c) + c0;
 #pragma unroll
-                for (int m = 0; m < 16; ++m) sum += A[KP * AS + c0 + m] * A[c * AS + c0 + m];
-                A[KP * AS + c] -= sum;
+                for (int m = 0; m < 16; ++m) sum += A[BORDER + c0 + m] * A[crow + m];
+                A[BORDER + c] -= sum;
             }
         }
         {
@@ -455,15 +471,15 @@ __global__ __launch_bounds__(256) void k_als_rows2(const double *__restrict__ Y,
                 double4_t cacc;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    cacc[q] = A[(I * 16 + (lane >> 4) + 4 * q) * AS + J2 * 16 + (lane & 15)];
-                const double *pa = A + (I * 16 + (lane & 15)) * AS + c0 + (lane >> 4);
-                const double *pb = A + (J2 * 16 + (lane & 15)) * AS + c0 + (lane >> 4);
+                    cacc[q] = A[als_row_off<NT>(I * 16 + (lane >> 4) + 4 * q) + J2 * 16 + (lane & 15)];
+                const double *pa = A + als_row_off<NT>(I * 16 + (lane & 15)) + c0 + (lane >> 4);
+                const double *pb = A + als_row_off<NT>(J2 * 16 + (lane & 15)) + c0 + (lane >> 4);
 #pragma unroll
                 for (int s4 = 0; s4 < 16; s4 += 4)
                     cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[s4], pb[s4], cacc, 0, 0, 0);
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    A[(I * 16 + (lane >> 4) + 4 * q) * AS + J2 * 16 + (lane & 15)] = cacc[q];
+                    A[als_row_off<NT>(I * 16 + (lane >> 4) + 4 * q) + J2 * 16 + (lane & 15)] = cacc[q];
             }
         }
         __syncthreads();
@@ -475,20 +491,21 @@ __global__ __launch_bounds__(256) void k_als_rows2(const double *__restrict__ Y,
 
     // ---- back substitution L^T x = z (z = border row) by wave 0, x in registers ----------
     if (wid == 0) {
-        double z0 = A[KP * AS + lane];               // KP >= 16; lanes >= KP read padding zeros
-        double z1 = (KP > 64) ? A[KP * AS + 64 + (lane < KP - 64 ? lane : 0)] : 0.0;
+        double z0 = A[BORDER + (lane < KP ? lane : 0)];
+        double z1 = (KP > 64) ? A[BORDER + 64 + (lane < KP - 64 ? lane : 0)] : 0.0;
         if (KP <= 64 && lane >= KP) z0 = 0.0;
         if (KP > 64 && lane >= KP - 64) z1 = 0.0;
         for (int c = KP - 1; c >= 64; --c) {         // pivots owned by z1
             const double x = readlane_f64(z1, c - 64) * dinv[c];
             if (lane == c - 64) z1 = x;
-            z0 -= A[c * AS + lane] * x;
-            if (lane + 64 < c) z1 -= A[c * AS + lane + 64] * x;
+            const int crow = als_row_off<NT>(c);
+            z0 -= A[crow + lane] * x;
+            if (lane + 64 < c) z1 -= A[crow + lane + 64] * x;
         }
         for (int c = (KP > 64 ? 63 : KP - 1); c >= 0; --c) {
             const double x = readlane_f64(z0, c) * dinv[c];
             if (lane == c) z0 = x;
-            if (lane < c) z0 -= A[c * AS + lane] * x;
+            if (lane < c) z0 -= A[als_row_off<NT>(c) + lane] * x;
         }
         if (lane < k) xrow[lane] = z0;
         if (lane + 64 < k) xrow[lane + 64] = z1;
@@ -526,7 +543,8 @@ AlsKernels als_kernels_nt()
 
 size_t rows2_lds_bytes(int KP)
 {
-    const size_t a = (size_t)(KP + 1) * (KP + 2), st = (size_t)CH2 * ych_stride(KP);
+    const int NTv = KP / 16;
+    const size_t a = (size_t)(128 * NTv * (NTv + 1) + 32 * NTv) + KP + 2, st = (size_t)CH2 * ych_stride(KP);
     const size_t region = ((a > st ? a : st) + 1) & ~(size_t)1;
     return (region + KP) * sizeof(double) + (2 * CH2 + 2) * sizeof(int);
 }

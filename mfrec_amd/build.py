@@ -24,7 +24,8 @@ def build(force=False, verbose=True):
             and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps)):
         return OUT
     hipcc = os.environ.get("HIPCC", "hipcc")
-    cmd = [hipcc] + FLAGS + srcs + ["-o", OUT, "-ldl"]
+    extra = os.environ.get("MFX_EXTRA_FLAGS", "").split()      # diagnostic builds only
+    cmd = [hipcc] + FLAGS + extra + srcs + ["-o", OUT if not extra else OUT.replace("libmfx.so", "libmfx_diag.so"), "-ldl"]
     if verbose:
         print("[mfrec_amd.build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

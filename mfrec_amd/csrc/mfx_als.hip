@@ -241,6 +241,22 @@ __global__ __launch_bounds__(256) void k_als_rows(const double *__restrict__ Y, 
 // ------------------------------------------------------------------------------------
 constexpr int CH2 = 32;                // neighbour rows per chunk
 
+// Diagnostic builds only (-DMFX_ALS_STAMPS): s_memtime at phase boundaries of the first rows.
+#ifdef MFX_ALS_STAMPS
+__device__ unsigned long long g_als_stamps[4096 * 8];
+#define ALS_STAMP(i)                                                                        \
+    do {                                                                                    \
+        __syncthreads();                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) {                                        \
+            unsigned long long t_;                                                          \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");     \
+            g_als_stamps[blockIdx.x * 8 + (i)] = t_;                                        \
+        }                                                                                   \
+    } while (0)
+#else
+#define ALS_STAMP(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ void tile_ij(int tt, int &I, int &J)
 {
     int i = 0;
@@ -275,8 +291,10 @@ __host__ __device__ constexpr int als_row_off(int r)
     return 128 * I * (I + 1) + 32 * I + (r & 15) * (16 * (I + 1) + 2);
 }
 
+// waves per SIMD (= workgroups per CU) the register allocation must leave room for: LDS admits
+// 2 workgroups at k = 128 and more below
 template <int NT>
-__global__ __launch_bounds__(256) void k_als_rows2(const double *__restrict__ Y, int k,
+__global__ __launch_bounds__(256, (NT >= 5 ? 2 : 3)) void k_als_rows2(const double *__restrict__ Y, int k,
                                                    const double *__restrict__ G,
                                                    const int64_t *__restrict__ off,
                                                    const int32_t *__restrict__ col, double c_pos,
@@ -320,11 +338,21 @@ __global__ __launch_bounds__(256) void k_als_rows2(const double *__restrict__ Y,
         tI[t] = 0; tJ[t] = 0;
         if (t * 4 + wid < NTT) tile_ij(t * 4 + wid, tI[t], tJ[t]);
     }
+    // accumulators start at G / c, so that A = c * acc needs no second pass over G (c != 0)
+    const bool from_g = (c_pos != 0.0);
+    const double inv_c = from_g ? 1.0 / c_pos : 0.0;
     double4_t acc[TPW];
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    for (int t = 0; t < TPW; ++t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = tI[t] * 16 + (lane >> 4) + 4 * q, c = tJ[t] * 16 + (lane & 15);
+            acc[t][q] = (from_g && t * 4 + wid < NTT) ? G[r * KP + c] * inv_c : 0.0;
+        }
+    }
     double bsum = 0.0;
 
+    ALS_STAMP(0);
     // ---- Y_N^T Y_N and b: chunked gather, next chunk in flight under the MFMAs -----------
     const int nchunks = (span + CH2 - 1) / CH2;
     if (tid < CH2) cidx[tid] = (tid < span) ? col[start + tid] : -1;
@@ -372,6 +400,7 @@ __global__ __launch_bounds__(256) void k_als_rows2(const double *__restrict__ Y,
         __syncthreads();
     }
 
+    ALS_STAMP(1);
     // ---- A = G + c * acc + lambda I (identity on the padding), b as border row -----------
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
@@ -381,7 +410,7 @@ __global__ __launch_bounds__(256) void k_als_rows2(const double *__restrict__ Y,
                 const int r = tI[t] * 16 + (lane >> 4) + 4 * q, c = tJ[t] * 16 + (lane & 15);
                 double a;
                 if (r < k && c < k) {
-                    a = G[r * KP + c] + acc[t][q] * c_pos;
+                    a = from_g ? acc[t][q] * c_pos : G[r * KP + c];
                     if (r == c) a += lambda;
                 } else {
                     a = (r == c) ? 1.0 : 0.0;
@@ -393,40 +422,64 @@ __global__ __launch_bounds__(256) void k_als_rows2(const double *__restrict__ Y,
     if (tid < KP) A[BORDER + tid] = (tid < k) ? bsum : 0.0;
     __syncthreads();
 
-    // ---- blocked Cholesky of the bordered matrix, 16-wide panels --------------------------
+    ALS_STAMP(2);
+    // ---- blocked Cholesky of the bordered matrix, 16-wide panels, with look-ahead: while
+    //      waves 1-3 apply panel Jb to the trailing tiles, wave 0 updates the next diagonal
+    //      tile first and factors it, so the serial 16-step block factorisation is hidden -----
+    auto factor_diag = [&](int c0) {
+        // lane r (< 16) holds row r of the 16x16 block in registers; right-looking by columns
+        const int r = lane & 15;
+        double d[16];
+        const int drow = als_row_off<NT>(c0 + r) + c0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) d[c] = A[drow + c];
+        double myinv = 1.0;
+        bool ok = true;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+            const double pj = readlane_f64(d[jj], jj);
+            ok = ok && (pj > 0.0);
+            const double inv = rsqrt_nr(pj);
+            if (r == jj) myinv = inv;
+            d[jj] = (r == jj) ? pj * inv : d[jj] * inv;
+#pragma unroll
+            for (int c = jj + 1; c < 16; ++c) {
+                const double lcj = readlane_f64(d[jj], c);
+                d[c] -= d[jj] * lcj;
+            }
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                if (c <= r) A[drow + c] = d[c];
+            dinv[c0 + r] = myinv;
+        }
+        if (!ok && lane == 0) *bad = 1;
+    };
+    auto trailing_tile = [&](int Jb, int tt) {
+        const int c0 = Jb * 16;
+        int I, J2;
+        tile_ij(tt, I, J2);
+        I += Jb + 1;
+        J2 += Jb + 1;
+        double4_t cacc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            cacc[q] = A[als_row_off<NT>(I * 16 + (lane >> 4) + 4 * q) + J2 * 16 + (lane & 15)];
+        const double *pa = A + als_row_off<NT>(I * 16 + (lane & 15)) + c0 + (lane >> 4);
+        const double *pb = A + als_row_off<NT>(J2 * 16 + (lane & 15)) + c0 + (lane >> 4);
+#pragma unroll
+        for (int s4 = 0; s4 < 16; s4 += 4)
+            cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[s4], pb[s4], cacc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            A[als_row_off<NT>(I * 16 + (lane >> 4) + 4 * q) + J2 * 16 + (lane & 15)] = cacc[q];
+    };
+
+    if (wid == 0) factor_diag(0);
+    __syncthreads();
     for (int Jb = 0; Jb < NT; ++Jb) {
         const int c0 = Jb * 16;
-        if (wid == 0) {
-            // (a) diagonal block: lane r (< 16) holds row r in registers; right-looking by columns
-            const int r = lane & 15;
-            double d[16];
-            const int drow = als_row_off<NT>(c0 + r) + c0;
-#pragma unroll
-            for (int c = 0; c < 16; ++c) d[c] = A[drow + c];
-            double myinv = 1.0;
-            bool ok = true;
-#pragma unroll
-            for (int jj = 0; jj < 16; ++jj) {
-                const double pj = readlane_f64(d[jj], jj);
-                ok = ok && (pj > 0.0);
-                const double inv = rsqrt_nr(pj);
-                if (r == jj) myinv = inv;
-                d[jj] = (r == jj) ? pj * inv : d[jj] * inv;
-#pragma unroll
-                for (int c = jj + 1; c < 16; ++c) {
-                    const double lcj = readlane_f64(d[jj], c);
-                    d[c] -= d[jj] * lcj;
-                }
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int c = 0; c < 16; ++c)
-                    if (c <= r) A[drow + c] = d[c];
-                dinv[c0 + r] = myinv;
-            }
-            if (!ok && lane == 0) *bad = 1;
-        }
-        __syncthreads();
         // (b) panel: rows below the block and the border row:  X = A21 * L11^{-T}
         {
             const int pr = c0 + 16 + tid;            // physical row; pr == KP is the border row
@@ -449,7 +502,7 @@ __global__ __launch_bounds__(256) void k_als_rows2(const double *__restrict__ Y,
             }
         }
         __syncthreads();
-        // (c) trailing update.  Border row first (VALU), then the lower tiles on the matrix cores
+        // (c) trailing update: border row (VALU), then the lower tiles on the matrix cores
         {
             const int c = c0 + 16 + tid;
             if (c < KP) {
@@ -463,23 +516,16 @@ __global__ __launch_bounds__(256) void k_als_rows2(const double *__restrict__ Y,
         {
             const int nt = NT - Jb - 1;              // trailing tile rows
             const int ntt = nt * (nt + 1) / 2;
-            for (int tt = wid; tt < ntt; tt += 4) {
-                int I, J2;
-                tile_ij(tt, I, J2);
-                I += Jb + 1;
-                J2 += Jb + 1;
-                double4_t cacc;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    cacc[q] = A[als_row_off<NT>(I * 16 + (lane >> 4) + 4 * q) + J2 * 16 + (lane & 15)];
-                const double *pa = A + als_row_off<NT>(I * 16 + (lane & 15)) + c0 + (lane >> 4);
-                const double *pb = A + als_row_off<NT>(J2 * 16 + (lane & 15)) + c0 + (lane >> 4);
-#pragma unroll
-                for (int s4 = 0; s4 < 16; s4 += 4)
-                    cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[s4], pb[s4], cacc, 0, 0, 0);
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    A[als_row_off<NT>(I * 16 + (lane >> 4) + 4 * q) + J2 * 16 + (lane & 15)] = cacc[q];
+            if (wid == 0) {
+                if (ntt > 0) {
+                    trailing_tile(Jb, 0);            // tile (Jb+1, Jb+1) ...
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    factor_diag(c0 + 16);            // ... factored right away (look-ahead)
+                }
+            } else {
+                for (int tt = wid; tt < ntt; tt += 3) trailing_tile(Jb, tt);
             }
         }
         __syncthreads();
@@ -488,29 +534,53 @@ __global__ __launch_bounds__(256) void k_als_rows2(const double *__restrict__ Y,
         if (tid == 0) atomicExch(status, j + 1);
         return;
     }
+    ALS_STAMP(3);
 
-    // ---- back substitution L^T x = z (z = border row) by wave 0, x in registers ----------
+    // ---- back substitution L^T x = z (z = border row) by wave 0, x in registers; the rows
+    //      of L and the reciprocal pivots of 16 steps are fetched ahead of the serial chain ---
     if (wid == 0) {
         double z0 = A[BORDER + (lane < KP ? lane : 0)];
         double z1 = (KP > 64) ? A[BORDER + 64 + (lane < KP - 64 ? lane : 0)] : 0.0;
         if (KP <= 64 && lane >= KP) z0 = 0.0;
         if (KP > 64 && lane >= KP - 64) z1 = 0.0;
-        for (int c = KP - 1; c >= 64; --c) {         // pivots owned by z1
-            const double x = readlane_f64(z1, c - 64) * dinv[c];
-            if (lane == c - 64) z1 = x;
-            const int crow = als_row_off<NT>(c);
-            z0 -= A[crow + lane] * x;
-            if (lane + 64 < c) z1 -= A[crow + lane + 64] * x;
-        }
-        for (int c = (KP > 64 ? 63 : KP - 1); c >= 0; --c) {
-            const double x = readlane_f64(z0, c) * dinv[c];
-            if (lane == c) z0 = x;
-            if (lane < c) z0 -= A[als_row_off<NT>(c) + lane] * x;
+        constexpr int PB = 8;                        // steps fetched ahead (register budget)
+        for (int cb = KP - PB; cb >= 0; cb -= PB) {
+            double lo[PB], hi[KP > 64 ? PB : 1], dv[PB];
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                const int c = cb + i;
+                const int crow = als_row_off<NT>(c);
+                lo[i] = (lane < c) ? A[crow + lane] : 0.0;
+                if constexpr (KP > 64) hi[i] = (lane + 64 < c) ? A[crow + lane + 64] : 0.0;
+                dv[i] = dinv[c];
+            }
+#pragma unroll
+            for (int i = PB - 1; i >= 0; --i) {
+                const int c = cb + i;
+                double x;
+                if (cb >= 64) {                      // wave-uniform: pivots owned by z1
+                    x = readlane_f64(z1, c - 64) * dv[i];
+                    if (lane == c - 64) z1 = x;
+                } else {
+                    x = readlane_f64(z0, c) * dv[i];
+                    if (lane == c) z0 = x;
+                }
+                z0 -= lo[i] * x;
+                if constexpr (KP > 64) z1 -= hi[i] * x;
+            }
         }
         if (lane < k) xrow[lane] = z0;
         if (lane + 64 < k) xrow[lane + 64] = z1;
     }
+    ALS_STAMP(4);
 }
+
+#ifdef MFX_ALS_STAMPS
+extern "C" int mfx_debug_als_stamps(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_als_stamps), sizeof(unsigned long long) * 4096 * 8) == hipSuccess ? 0 : -4;
+}
+#endif
 
 // out[c][r] = in[r][c]
 __global__ __launch_bounds__(256) void k_transpose_als(const double *in, double *out, int rows, int cols)

@@ -179,6 +179,16 @@ int mfx_sgd_run_kmf_sharded(mfx_sgd_plan *p, int mode, int nbr_epochs, double le
                             double *rmse_out /* local shard's online RMSE */,
                             double *se_out /* nullable: f64[nbr_epochs] local sum of squared errors */);
 
+/* ALS shards exactly: every rank holds full replicas of u, v and both run-length views,
+ * solves a contiguous slice of the rows of each half-epoch and the slices are all-gathered
+ * (RCCL ncclAllGather over xGMI) -- same arguments and same result as mfx_als_wrmf
+ * (als_implicit.pyx:211-352) on every rank. */
+int mfx_als_wrmf_sharded(int nbr_epochs, int dim, double *u, double *v,
+                         const int32_t *ratings_users_row, int64_t n_urow,
+                         const int32_t *ratings_users_col, const int32_t *ratings_items_row,
+                         int64_t n_irow, const int32_t *ratings_items_col, int nu, int ni, int c_pos,
+                         double lambda);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,8 @@ SIGNATURES = {
                                    _dp, C.c_int64, _lp]),
     "mfx_als_wrmf": (C.c_int, [C.c_int, C.c_int, _dp, _dp, _ip, C.c_int64, _ip, _ip, C.c_int64,
                                _ip, C.c_int, C.c_int, C.c_int, C.c_double]),
+    "mfx_als_wrmf_sharded": (C.c_int, [C.c_int, C.c_int, _dp, _dp, _ip, C.c_int64, _ip, _ip,
+                                       C.c_int64, _ip, C.c_int, C.c_int, C.c_int, C.c_double]),
     "mfx_predict_rmse": (C.c_int, [C.c_int, C.c_int, _dp, _dp, _ip, _dp, _dp, _dp, C.c_double,
                                    C.c_int64, C.c_int, C.c_int, _dp, _dp]),
     "mfx_sgd_plan_create": (C.c_void_p, [_ip, _dp, C.c_int64, C.c_int, C.c_int, C.c_int]),

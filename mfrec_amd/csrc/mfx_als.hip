@@ -18,6 +18,13 @@
 #include <vector>
 #include "mfx_common.h"
 
+namespace mfx {
+bool comm_active();
+int comm_rank();
+int comm_world();
+int comm_allgather_f64(double *buf, size_t count);
+}  // namespace mfx
+
 namespace {
 
 using mfx::ceil_div;
@@ -648,9 +655,12 @@ struct DevBuf {
 constexpr int kGramBlocks = 512;
 
 // one half-epoch: solve X (n_active rows) from Y
+// rank/world: this process solves rows [rank*B, (rank+1)*B) with B = ceil(n_active / world) and
+// the slices are all-gathered in place (dX has room for world*B rows); world == 1: all rows.
 int als_half(int k, int NT, const AlsKernels &K, const double *dY, int ny, double *dX,
              const int64_t *d_off, int64_t n_active, const int32_t *d_col, int c_pos, double lambda,
-             double *d_partial, double *dG, int *d_status)
+             double *d_partial, double *dG, int *d_status, int rank = 0, int world = 1,
+             bool gather = false)
 {
     const int KP = NT * 16;
     hipStream_t s = mfx::stream();
@@ -684,14 +694,25 @@ int als_half(int k, int NT, const AlsKernels &K, const double *dY, int ny, doubl
         int kk = k;
         double c = (double)c_pos, opc = (double)(1 + c_pos), lam = lambda;
         void *args[] = {&Yc, &kk, &Gc, &d_off, &d_col, &c, &opc, &lam, &dX, &d_status};
+        const int64_t B = ceil_div(n_active, (int64_t)world);
+        // rank < 0 (test hook MFX_ALS_FAKE_WORLD): run every rank's slice on this GPU in turn
+        const int r_first = rank < 0 ? 0 : rank, r_last = rank < 0 ? world - 1 : rank;
+        for (int rr = r_first; rr <= r_last; ++rr) {
+        const int64_t lo = (int64_t)rr * B < n_active ? (int64_t)rr * B : n_active;
+        const int64_t hi = lo + B < n_active ? lo + B : n_active;
         // the grid is one block per active row; launch in slices of <= 2^20 rows
-        for (int64_t r0 = 0; r0 < n_active; r0 += (1 << 20)) {
-            const int n = (int)((n_active - r0) < (1 << 20) ? (n_active - r0) : (1 << 20));
+        for (int64_t r0 = lo; r0 < hi; r0 += (1 << 20)) {
+            const int n = (int)((hi - r0) < (1 << 20) ? (hi - r0) : (1 << 20));
             const int64_t *off_s = d_off + r0;
             double *X_s = dX + (size_t)r0 * k;
             args[3] = &off_s;
             args[8] = &X_s;
             MFX_HIP(hipLaunchKernel(rows_fn, dim3(n), dim3(256), args, lds, s));
+        }
+        }
+        if (gather) {
+            int rc = mfx::comm_allgather_f64(dX, (size_t)B * k);
+            if (rc) return rc;
         }
     }
     return MFX_OK;
@@ -730,10 +751,9 @@ int offsets_from_runlength(const int32_t *row, int64_t n_row, const int32_t *col
 
 }  // namespace
 
-extern "C" int mfx_als_wrmf(int nbr_epochs, int dim, double *u, double *v, const int32_t *urow,
-                            int64_t n_urow, const int32_t *ucol, const int32_t *irow,
-                            int64_t n_irow, const int32_t *icol, int nu, int ni, int c_pos,
-                            double lambda)
+static int als_wrmf_impl(int nbr_epochs, int dim, double *u, double *v, const int32_t *urow,
+                         int64_t n_urow, const int32_t *ucol, const int32_t *irow, int64_t n_irow,
+                         const int32_t *icol, int nu, int ni, int c_pos, double lambda, bool sharded)
 {
     if (!u || !v || !urow || !irow || dim < 1 || dim > 128 || nu <= 0 || ni <= 0 || n_urow < 1 ||
         n_irow < 1)
@@ -756,8 +776,19 @@ extern "C" int mfx_als_wrmf(int nbr_epochs, int dim, double *u, double *v, const
     const int NT = ceil_div(dim, 16), KP = NT * 16;
     const AlsKernels K = als_kernels(NT);
     const size_t su = (size_t)dim * ni * sizeof(double), sv = (size_t)dim * nu * sizeof(double);
+    // sharded: every rank holds full replicas, solves a contiguous slice of the rows of each
+    // half-epoch and all-gathers the slices (row solves are independent: same result as 1 GPU)
+    const bool gather = sharded && mfx::comm_active();
+    int rank = gather ? mfx::comm_rank() : 0, world = gather ? mfx::comm_world() : 1;
+    if (!gather) {                                  // slicing arithmetic check on one GPU
+        const char *fw = getenv("MFX_ALS_FAKE_WORLD");
+        if (fw && atoi(fw) > 1) { world = atoi(fw); rank = -1; }
+    }
+    if (sharded && !mfx::comm_active() && mfx::comm_world() > 1)
+        return mfx::fail(MFX_E_STATE, "mfx_als_wrmf_sharded: mfx_comm_init has not been called");
+    const size_t pad = (size_t)world * dim * sizeof(double);   // in-place all-gather slack rows
     DevBuf dUkm, dVkm, dU, dV, dUoff, dIoff, dUcol, dIcol, dPart, dG, dStatus;
-    if ((rc = dUkm.alloc(su)) || (rc = dVkm.alloc(sv)) || (rc = dU.alloc(su)) || (rc = dV.alloc(sv)) ||
+    if ((rc = dUkm.alloc(su)) || (rc = dVkm.alloc(sv)) || (rc = dU.alloc(su + pad)) || (rc = dV.alloc(sv + pad)) ||
         (rc = dUoff.alloc((nau + 1) * 8)) || (rc = dIoff.alloc((nai + 1) * 8)) ||
         (rc = dUcol.alloc((size_t)nnz_u * 4)) || (rc = dIcol.alloc((size_t)nnz_i * 4)) ||
         (rc = dPart.alloc((size_t)kGramBlocks * KP * KP * 8)) || (rc = dG.alloc((size_t)KP * KP * 8)) ||
@@ -781,11 +812,11 @@ extern "C" int mfx_als_wrmf(int nbr_epochs, int dim, double *u, double *v, const
         // user pass (als_implicit.pyx:257-302), then item pass (:307-352)
         rc = als_half(dim, NT, K, dU.as<double>(), ni, dV.as<double>(), dUoff.as<int64_t>(), nau,
                       dUcol.as<int32_t>(), c_pos, lambda, dPart.as<double>(), dG.as<double>(),
-                      dStatus.as<int>());
+                      dStatus.as<int>(), rank, world, gather);
         if (!rc)
             rc = als_half(dim, NT, K, dV.as<double>(), nu, dU.as<double>(), dIoff.as<int64_t>(), nai,
                           dIcol.as<int32_t>(), c_pos, lambda, dPart.as<double>(), dG.as<double>(),
-                          dStatus.as<int>());
+                          dStatus.as<int>(), rank, world, gather);
     }
     if (!rc) {
         MFX_HIP(hipEventRecord(ev1, s));
@@ -808,4 +839,22 @@ extern "C" int mfx_als_wrmf(int nbr_epochs, int dim, double *u, double *v, const
     MFX_HIP(hipMemcpy(u, dUkm.p, su, hipMemcpyDeviceToHost));
     MFX_HIP(hipMemcpy(v, dVkm.p, sv, hipMemcpyDeviceToHost));
     return MFX_OK;
+}
+
+extern "C" int mfx_als_wrmf(int nbr_epochs, int dim, double *u, double *v, const int32_t *urow,
+                            int64_t n_urow, const int32_t *ucol, const int32_t *irow,
+                            int64_t n_irow, const int32_t *icol, int nu, int ni, int c_pos,
+                            double lambda)
+{
+    return als_wrmf_impl(nbr_epochs, dim, u, v, urow, n_urow, ucol, irow, n_irow, icol, nu, ni, c_pos,
+                         lambda, false);
+}
+
+extern "C" int mfx_als_wrmf_sharded(int nbr_epochs, int dim, double *u, double *v,
+                                    const int32_t *urow, int64_t n_urow, const int32_t *ucol,
+                                    const int32_t *irow, int64_t n_irow, const int32_t *icol,
+                                    int nu, int ni, int c_pos, double lambda)
+{
+    return als_wrmf_impl(nbr_epochs, dim, u, v, urow, n_urow, ucol, irow, n_irow, icol, nu, ni, c_pos,
+                         lambda, true);
 }

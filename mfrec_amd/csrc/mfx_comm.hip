@@ -39,6 +39,7 @@ struct Rccl {
     int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     int (*CommDestroy)(ncclComm_t) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 } R;
 
@@ -59,8 +60,9 @@ int load_rccl()
     R.CommInitRank = (decltype(R.CommInitRank))dlsym(R.h, "ncclCommInitRank");
     R.CommDestroy = (decltype(R.CommDestroy))dlsym(R.h, "ncclCommDestroy");
     R.AllReduce = (decltype(R.AllReduce))dlsym(R.h, "ncclAllReduce");
+    R.AllGather = (decltype(R.AllGather))dlsym(R.h, "ncclAllGather");
     R.GetErrorString = (decltype(R.GetErrorString))dlsym(R.h, "ncclGetErrorString");
-    if (!R.GetUniqueId || !R.CommInitRank || !R.CommDestroy || !R.AllReduce) {
+    if (!R.GetUniqueId || !R.CommInitRank || !R.CommDestroy || !R.AllReduce || !R.AllGather) {
         dlclose(R.h);
         R.h = nullptr;
         return mfx::fail(MFX_E_RCCL, "librccl lacks a required symbol");
@@ -117,6 +119,19 @@ int shard_hook(mfx_sgd_plan *p, int, void *vctx)
 }
 
 }  // namespace
+
+namespace mfx {
+bool comm_active() { return g_comm != nullptr; }
+int comm_rank() { return g_rank; }
+int comm_world() { return g_world; }
+// in-place all-gather of f64: rank g's contribution sits at buf + g*count
+int comm_allgather_f64(double *buf, size_t count)
+{
+    if (!g_comm) return MFX_OK;
+    MFX_NCCL(R.AllGather(buf + (size_t)g_rank * count, buf, count, ncclFloat64, g_comm, mfx::stream()));
+    return MFX_OK;
+}
+}  // namespace mfx
 
 extern "C" {
 

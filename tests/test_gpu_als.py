@@ -89,3 +89,20 @@ def test_als_errors():
     with pytest.raises(ValueError, match="dtype"):
         als_wrmf(1, 4, u, v, None, None, row.astype(np.int64), np.array([0], dtype=np.int32), row,
                  np.array([0], dtype=np.int32), 5, 3)
+
+
+def test_als_row_slicing_arithmetic(monkeypatch):
+    """MFX_ALS_FAKE_WORLD=W runs the W rank-slices of the sharded scheme one after the other on
+    this GPU: the slice bounds must tile the active rows exactly (bit-identical result)."""
+    from mfrec_amd.lib.als_implicit import als_wrmf
+    nu, ni, k = 301, 197, 24
+    urow, ucol, irow, icol = _problem(nu, ni, 5000, 5)
+    rs = np.random.RandomState(1)
+    u0, v0 = rs.normal(0, 0.1, (k, ni)), rs.normal(0, 0.1, (k, nu))
+    u, v = u0.copy(), v0.copy()
+    als_wrmf(2, k, u, v, None, None, urow, ucol, irow, icol, nu, ni)
+    for w in ("2", "3", "8"):
+        monkeypatch.setenv("MFX_ALS_FAKE_WORLD", w)
+        u2, v2 = u0.copy(), v0.copy()
+        als_wrmf(2, k, u2, v2, None, None, urow, ucol, irow, icol, nu, ni)
+        assert np.array_equal(u, u2) and np.array_equal(v, v2)

@@ -43,3 +43,31 @@ def test_forced_single_rank_comm_matches_simulation():
     assert np.array_equal(ib, sib) and np.array_equal(ub, sub)
     assert np.all(np.isfinite(rm)) and rm[-1] < rm[0]
     np.testing.assert_allclose(rm, np.sqrt(se / nnz), rtol=1e-15)
+
+
+def test_forced_single_rank_als_allgather():
+    """The sharded ALS entry point with a 1-rank communicator (real ncclAllGather on the
+    library stream) must reproduce the un-sharded result bit for bit."""
+    import scipy.sparse as sp
+    from mfrec_amd import _shim as S
+    from mfrec_amd.lib.als_implicit import als_wrmf, als_wrmf_sharded
+    from mfrec_amd.lib.datasets import create_bool_sparse_col, create_bool_sparse_row
+    S.init(0)
+    nu, ni, k = 300, 200, 40
+    rs = np.random.RandomState(2)
+    M = sp.coo_matrix((np.ones(6000), (rs.randint(0, nu, 6000), rs.randint(0, ni, 6000))), shape=(nu, ni)).tocsr()
+    a, b = create_bool_sparse_row(M); c, d = create_bool_sparse_col(M)
+    u0, v0 = rs.normal(0, 0.1, (k, ni)), rs.normal(0, 0.1, (k, nu))
+    u, v = u0.copy(), v0.copy()
+    als_wrmf(2, k, u, v, None, None, a, b, c, d, nu, ni)
+    os.environ["MFX_FORCE_COMM"] = "1"
+    try:
+        buf = C.create_string_buffer(S.UNIQUE_ID_BYTES)
+        S.check(S.lib().mfx_comm_unique_id(buf))
+        S.check(S.lib().mfx_comm_init(0, 1, buf.raw))
+        u2, v2 = u0.copy(), v0.copy()
+        als_wrmf_sharded(2, k, u2, v2, None, None, a, b, c, d, nu, ni)
+    finally:
+        S.check(S.lib().mfx_comm_destroy())
+        del os.environ["MFX_FORCE_COMM"]
+    assert np.array_equal(u, u2) and np.array_equal(v, v2)

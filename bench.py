@@ -106,19 +106,22 @@ def main():
     from mfrec_amd import synth
     from mfrec_amd.plan import SgdPlan, Timer, LINEAR
     B.build(verbose=False)
-    S.init(local)
+    # MFX_BENCH_DEVICE: rehearsal hook (several ranks on one GPU); the driver never sets it
+    S.init(int(os.environ.get("MFX_BENCH_DEVICE", local)))
 
-    dist = None
     if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # torch.distributed.run is only the launcher: no torch import in the ranks (see
+        # mfrec_amd/rendezvous.py); the RCCL unique id travels through a file.
         import ctypes as C
-        idbuf = C.create_string_buffer(S.UNIQUE_ID_BYTES)
-        if rank == 0:
+        from mfrec_amd import rendezvous
+
+        def make_id():
+            idbuf = C.create_string_buffer(S.UNIQUE_ID_BYTES)
             S.check(S.lib().mfx_comm_unique_id(idbuf))
-        obj = [idbuf.raw]
-        dist.broadcast_object_list(obj, src=0)
-        S.check(S.lib().mfx_comm_init(rank, world, obj[0]))
+            return idbuf.raw
+
+        uid = rendezvous.exchange_unique_id(rank, world, make_id)
+        S.check(S.lib().mfx_comm_init(rank, world, uid))
 
     nu, ni, nnz, k = a.users, a.items, a.nnz, a.k
     # this rank's shard: its own users (local ids 0..nu-1), the shared item catalogue
@@ -138,10 +141,9 @@ def main():
             plan.run_kmf(LINEAR, n, LR, KU, KI, KB, want_rmse=False)
 
     def barrier():
-        S.sync()
+        S.sync()                                      # hipStreamSynchronize on the library stream
         if world > 1:
-            S.check(S.lib().mfx_comm_barrier())
-            dist.barrier()
+            S.check(S.lib().mfx_comm_barrier())       # RCCL all-reduce + sync = cross-rank barrier
 
     run(max(a.warmup, 0))
     barrier()
@@ -150,11 +152,11 @@ def main():
         run(a.steps)
     barrier()
     wall = time.perf_counter() - t0
-    if world > 1:
-        import torch
-        t = torch.tensor([wall], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t[0])
+    if world > 1:                                     # MAX over ranks
+        import ctypes as C
+        w = C.c_double(wall)
+        S.check(S.lib().mfx_comm_allreduce_max(C.byref(w)))
+        wall = w.value
 
     # Dominant kernel = k1_level (one launch per dependency level).  Its average launch
     # duration is taken from the HIP events that bracket the timed region on the library's
@@ -212,8 +214,10 @@ def main():
         print(json.dumps(line), flush=True)
     plan.close()
     if world > 1:
+        S.check(S.lib().mfx_comm_barrier())
         S.check(S.lib().mfx_comm_destroy())
-        dist.destroy_process_group()
+        from mfrec_amd import rendezvous
+        rendezvous.cleanup(rank)
 
 
 if __name__ == "__main__":

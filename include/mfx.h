@@ -172,6 +172,8 @@ int mfx_comm_unique_id(void *id_out);
 int mfx_comm_init(int rank, int world, const void *id);
 int mfx_comm_destroy(void);
 int mfx_comm_barrier(void);
+/* *value <- max over ranks (bench.py takes the slowest rank's time with it) */
+int mfx_comm_allreduce_max(double *value);
 /* full-k SGD with the per-epoch item-delta all-reduce; the plan holds this rank's shard
  * (its users' ratings, user ids local to the shard). */
 int mfx_sgd_run_kmf_sharded(mfx_sgd_plan *p, int mode, int nbr_epochs, double learning_rate,

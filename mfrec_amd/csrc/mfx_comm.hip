@@ -31,7 +31,7 @@ typedef struct { char internal[128]; } ncclUniqueId;
 typedef void *ncclComm_t;
 enum { ncclSuccess = 0 };
 enum { ncclFloat64 = 8 };
-enum { ncclSum = 0 };
+enum { ncclSum = 0, ncclMax = 2 };
 
 struct Rccl {
     void *h = nullptr;
@@ -191,6 +191,17 @@ int mfx_comm_barrier(void)
         MFX_HIP(hipMemsetAsync(g_token, 0, sizeof(double), mfx::stream()));
         MFX_NCCL(R.AllReduce(g_token, g_token, 1, ncclFloat64, ncclSum, g_comm, mfx::stream()));
     }
+    MFX_HIP(hipStreamSynchronize(mfx::stream()));
+    return MFX_OK;
+}
+
+int mfx_comm_allreduce_max(double *value)
+{
+    if (!value) return mfx::fail(MFX_E_ARG, "mfx_comm_allreduce_max: NULL");
+    if (!g_comm) return MFX_OK;                      // single rank: the value is its own maximum
+    MFX_HIP(hipMemcpyAsync(g_token, value, sizeof(double), hipMemcpyHostToDevice, mfx::stream()));
+    MFX_NCCL(R.AllReduce(g_token, g_token, 1, ncclFloat64, ncclMax, g_comm, mfx::stream()));
+    MFX_HIP(hipMemcpyAsync(value, g_token, sizeof(double), hipMemcpyDeviceToHost, mfx::stream()));
     MFX_HIP(hipStreamSynchronize(mfx::stream()));
     return MFX_OK;
 }

@@ -364,17 +364,18 @@ mfx_sgd_plan *mfx_sgd_plan_create(const int32_t *idx, const double *r, int64_t n
         const auto t0 = std::chrono::steady_clock::now();
         std::vector<int32_t> level((size_t)(nnz ? nnz : 1));
         if (mfx_schedule_levels(idx, nnz, nu, ni, level.data(), &p->n_levels)) return bail();
-        std::vector<int64_t> perm((size_t)(nnz ? nnz : 1));
+        // counting sort by level straight into the 16-byte device records: one sequential
+        // read of (idx, r, level), n_levels write cursors (no permutation array, no gather)
         p->level_off.assign((size_t)p->n_levels + 1, 0);
-        if (mfx_schedule_permutation(level.data(), nnz, p->n_levels, perm.data(),
-                                     p->level_off.data()))
-            return bail();
+        for (int64_t t = 0; t < nnz; ++t) ++p->level_off[level[t]];
+        for (int64_t l = 0; l < p->n_levels; ++l) p->level_off[l + 1] += p->level_off[l];
+        std::vector<int64_t> cur(p->level_off.begin(), p->level_off.end());
         std::vector<Rec> recs((size_t)(nnz ? nnz : 1));
-        for (int64_t j = 0; j < nnz; ++j) {
-            const int64_t t = perm[j];
-            recs[j].user = idx[2 * t];
-            recs[j].item = idx[2 * t + 1];
-            recs[j].r = r[t];
+        for (int64_t t = 0; t < nnz; ++t) {
+            Rec &q = recs[cur[level[t] - 1]++];
+            q.user = idx[2 * t];
+            q.item = idx[2 * t + 1];
+            q.r = r[t];
         }
         p->k1_wave_off.assign((size_t)p->n_levels + 1, 0);
         p->k2_wave_off.assign((size_t)p->n_levels + 1, 0);

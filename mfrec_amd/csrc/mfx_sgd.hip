@@ -11,8 +11,15 @@ using namespace mfx;
 // ------------------------------------------------------------------------------------
 // plan
 // ------------------------------------------------------------------------------------
+struct LaunchSeg {      // one kernel launch of a full-k epoch
+    int64_t l0, l1;     // levels [l0, l1)
+    bool tail;          // run of small levels handled by the single-workgroup tail kernel
+};
+
 struct mfx_sgd_plan {
     int64_t nnz = 0;
+    std::vector<LaunchSeg> segs;
+    int64_t *d_level_off = nullptr, *d_k1_wave_off = nullptr;
     int nu = 0, ni = 0, k = 0;
     int64_t n_levels = 0, max_level = 0;
     int batch = 16, nt = 0;              // full-k kernel: ratings per wave, non-temporal row stores
@@ -131,6 +138,34 @@ void *k1_pick(int k, int batch)
     return (void *)k1_level<64, 8, 2, MODE, NT>;
 }
 
+template <int MODE, int NT>
+void *k1_pick_tail(int k, int batch)
+{
+    if (k <= 8) return (void *)k1_tail<8, 1, 16, MODE, NT>;
+    if (k <= 16) return (void *)k1_tail<16, 1, 16, MODE, NT>;
+    if (k <= 32) return (void *)k1_tail<32, 1, 16, MODE, NT>;
+    if (k <= 64) {
+        if (batch == 16) return (void *)k1_tail<64, 1, 16, MODE, NT>;
+        if (batch == 4) return (void *)k1_tail<64, 1, 4, MODE, NT>;
+        return (void *)k1_tail<64, 1, 8, MODE, NT>;
+    }
+    if (k <= 128) return (void *)k1_tail<64, 2, 8, MODE, NT>;
+    if (k <= 256) return (void *)k1_tail<64, 4, 4, MODE, NT>;
+    return (void *)k1_tail<64, 8, 2, MODE, NT>;
+}
+
+void *k1_tail_kernel(int k, int mode, int batch, int nt)
+{
+    switch (mode * 2 + (nt ? 1 : 0)) {
+    case 0: return k1_pick_tail<K1_LINEAR, 0>(k, batch);
+    case 1: return k1_pick_tail<K1_LINEAR, 1>(k, batch);
+    case 2: return k1_pick_tail<K1_LOGISTIC, 0>(k, batch);
+    case 3: return k1_pick_tail<K1_LOGISTIC, 1>(k, batch);
+    case 4: return k1_pick_tail<K1_LEARNED, 0>(k, batch);
+    default: return k1_pick_tail<K1_LEARNED, 1>(k, batch);
+    }
+}
+
 void *k1_kernel(int k, int mode, int batch, int nt)
 {
     switch (mode * 2 + (nt ? 1 : 0)) {
@@ -178,21 +213,30 @@ int enqueue_k1_epoch(mfx_sgd_plan *p, int mode, const K1Params &P, std::vector<h
 {
     const int batch = p->batch;
     void *fn = k1_kernel(p->k, mode, batch, p->nt);
+    void *fn_tail = k1_tail_kernel(p->k, mode, batch, p->nt);
     const size_t lds = k1_lds_bytes(p->k, batch);
+    const size_t lds_tail = lds / kWaves * kTailWaves;
+    if (lds_tail > 64 * 1024)
+        (void)hipFuncSetAttribute(fn_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tail);
     size_t e = 0;
-    for (int64_t l = 0; l < p->n_levels; ++l) {
-        const int64_t start = p->level_off[l];
-        const int count = (int)(p->level_off[l + 1] - start);
-        if (count <= 0) continue;
-        const int waves = ceil_div(count, batch);
-        const int blocks = ceil_div(waves, kWaves);
-        int64_t woff = p->k1_wave_off[l];
+    for (const LaunchSeg &sg : p->segs) {
         K1Params Pl = P;
-        int cnt = count;
-        int64_t st = start;
-        void *args[] = {&Pl, &st, &cnt, &woff};
         if (ev) MFX_HIP(hipEventRecord((*ev)[e++], stream()));
-        MFX_HIP(hipLaunchKernel(fn, dim3(blocks), dim3(kWaves * 64), args, lds, stream()));
+        if (sg.l1 - sg.l0 == 1 && !sg.tail) {
+            const int64_t l = sg.l0;
+            int64_t st = p->level_off[l];
+            int cnt = (int)(p->level_off[l + 1] - st);
+            const int waves = ceil_div(cnt, batch);
+            const int blocks = ceil_div(waves, kWaves);
+            int64_t woff = p->k1_wave_off[l];
+            void *args[] = {&Pl, &st, &cnt, &woff};
+            MFX_HIP(hipLaunchKernel(fn, dim3(blocks), dim3(kWaves * 64), args, lds, stream()));
+        } else {
+            const int64_t *lo = p->d_level_off, *wo = p->d_k1_wave_off;
+            int l0 = (int)sg.l0, l1 = (int)sg.l1;
+            void *args[] = {&Pl, &lo, &wo, &l0, &l1};
+            MFX_HIP(hipLaunchKernel(fn_tail, dim3(1), dim3(kTailWaves * 64), args, lds_tail, stream()));
+        }
         if (ev) MFX_HIP(hipEventRecord((*ev)[e++], stream()));
     }
     return enqueue_reduce(p, p->k1_waves);
@@ -387,12 +431,40 @@ mfx_sgd_plan *mfx_sgd_plan_create(const int32_t *idx, const double *r, int64_t n
                                     ceil_div(ceil_div(c, (int64_t)p->batch), (int64_t)kWaves) * kWaves;
             p->k2_wave_off[l + 1] = p->k2_wave_off[l] + ceil_div(c, (int64_t)256) * 4;
         }
+        // launch segments: big levels one launch each; runs of small levels -> tail kernel
+        {
+            const int64_t T = (int64_t)kTailWaves * p->batch;
+            const char *e = getenv("MFX_K1_TAIL");
+            const bool tail_on = !(e && e[0] == '0');
+            int64_t l = 0;
+            while (l < p->n_levels) {
+                const int64_t c = p->level_off[l + 1] - p->level_off[l];
+                if (c <= 0) { ++l; continue; }
+                if (tail_on && c <= T) {
+                    int64_t m = l;
+                    while (m < p->n_levels && p->level_off[m + 1] - p->level_off[m] <= T) ++m;
+                    p->segs.push_back({l, m, true});
+                    l = m;
+                } else {
+                    p->segs.push_back({l, l + 1, false});
+                    ++l;
+                }
+            }
+        }
         p->k1_waves = p->k1_wave_off[p->n_levels];
         p->k2_waves = p->k2_wave_off[p->n_levels];
         p->sched_us = std::chrono::duration_cast<std::chrono::microseconds>(
                           std::chrono::steady_clock::now() - t0).count();
 
         if (dev_alloc(p, &p->d_recs, (size_t)nnz)) return bail();
+        if (dev_alloc(p, &p->d_level_off, (size_t)p->n_levels + 1) ||
+            dev_alloc(p, &p->d_k1_wave_off, (size_t)p->n_levels + 1))
+            return bail();
+        if (hipMemcpy(p->d_level_off, p->level_off.data(), ((size_t)p->n_levels + 1) * 8, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(p->d_k1_wave_off, p->k1_wave_off.data(), ((size_t)p->n_levels + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) {
+            fail(MFX_E_HIP, "mfx_sgd_plan_create: upload of level offsets failed");
+            return bail();
+        }
         if (dev_alloc(p, &p->d_U_km, (size_t)ni * dim) || dev_alloc(p, &p->d_V_km, (size_t)nu * dim) ||
             dev_alloc(p, &p->d_U_nk, (size_t)ni * dim) || dev_alloc(p, &p->d_V_nk, (size_t)nu * dim) ||
             dev_alloc(p, &p->d_ib, (size_t)ni) || dev_alloc(p, &p->d_ub, (size_t)nu) ||
@@ -420,7 +492,7 @@ void mfx_sgd_plan_destroy(mfx_sgd_plan *p)
     if (ready()) (void)hipStreamSynchronize(stream());
     drop_graph(p);
     void *ptrs[] = {p->d_recs, p->d_U_km, p->d_V_km, p->d_U_nk, p->d_V_nk, p->d_ib, p->d_ub,
-                    p->d_cache, p->d_k2dyn, p->d_se_partial, p->d_se_tmp, p->d_se_epoch, p->d_counter, p->d_U_start,
+                    p->d_cache, p->d_k2dyn, p->d_level_off, p->d_k1_wave_off, p->d_se_partial, p->d_se_tmp, p->d_se_epoch, p->d_counter, p->d_U_start,
                     p->d_ib_start};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -430,17 +502,18 @@ void mfx_sgd_plan_destroy(mfx_sgd_plan *p)
 int mfx_sgd_plan_info(const mfx_sgd_plan *p, int64_t info[8])
 {
     if (!p || !info) return MFX_E_ARG;
-    int64_t launches = 0;
+    int64_t launches = 0, tails = 0, flaunches = 0;
     for (int64_t l = 0; l < p->n_levels; ++l)
-        if (p->level_off[l + 1] > p->level_off[l]) ++launches;
+        if (p->level_off[l + 1] > p->level_off[l]) ++flaunches;
+    for (const LaunchSeg &sg : p->segs) { ++launches; if (sg.tail) ++tails; }
     info[0] = p->n_levels;
     info[1] = p->max_level;
     info[2] = launches;
-    info[3] = 0;
+    info[3] = tails;
     info[4] = p->batch;
     info[5] = (int64_t)p->dev_bytes;
     info[6] = p->sched_us;
-    info[7] = launches;
+    info[7] = flaunches;
     return MFX_OK;
 }
 
@@ -503,9 +576,7 @@ int mfx_sgd_profile_kmf(mfx_sgd_plan *p, int mode, double lr, double Ku, double 
     if (rc) return rc;
     p->km_current = false;
     K1Params P = k1_params(p, lr, Ku, Ki, Kb, 1, 1);
-    int64_t launches = 0;
-    for (int64_t l = 0; l < p->n_levels; ++l)
-        if (p->level_off[l + 1] > p->level_off[l]) ++launches;
+    const int64_t launches = (int64_t)p->segs.size();
     std::vector<hipEvent_t> ev((size_t)launches * 2, nullptr);
     for (auto &e : ev) MFX_HIP(hipEventCreate(&e));
     MFX_HIP(hipMemsetAsync(p->d_counter, 0, sizeof(int), stream()));

@@ -312,6 +312,41 @@ __global__ __launch_bounds__(kWaves * 64) void k1_level(K1Params P, int64_t star
         k1_body<KP, FPL, BATCH, MODE, NT, false>(P, start, cnt, base, wave_off + wave_g, prod, lane);
 }
 
+// Tail kernel: a run of consecutive SMALL levels (each <= kTailWaves*BATCH ratings) in ONE
+// launch by ONE workgroup, __syncthreads() between levels (same-CU visibility of the row
+// stores is guaranteed at workgroup scope).  With power-law data most levels are the long
+// chain of a few hot items/users with a handful of ratings each; a launch per level would
+// cost ~9 us for ~no work.
+static constexpr int kTailWaves = 16;
+template <int KP, int FPL, int BATCH, int MODE, int NT>
+__global__ __launch_bounds__(kTailWaves * 64) void k1_tail(K1Params P, const int64_t *level_off,
+                                                          const int64_t *wave_off, int l0, int l1)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    double *prod = lds + (size_t)wid * BATCH * k1_stride(P.k);
+    for (int l = l0; l < l1; ++l) {
+        const int64_t start = level_off[l];
+        const int count = (int)(level_off[l + 1] - start);
+        const int64_t woff = wave_off[l];
+        const int nslots = (int)(wave_off[l + 1] - woff);
+        const int base = wid * BATCH;
+        if (wid < nslots) {
+            if (base >= count) {
+                if (lane == 0) P.se_partial[woff + wid] = 0.0;
+            } else {
+                const int cnt = (count - base) < BATCH ? (count - base) : BATCH;
+                if (cnt == BATCH && P.upd_u && P.upd_i)
+                    k1_body<KP, FPL, BATCH, MODE, NT, true>(P, start, cnt, base, woff + wid, prod, lane);
+                else
+                    k1_body<KP, FPL, BATCH, MODE, NT, false>(P, start, cnt, base, woff + wid, prod, lane);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // K2: Funk per-feature pass.  One lane per rating of one level; the feature vectors
 // uf = U[f, :], vf = V[f, :] are feature-major slices (L2 resident).

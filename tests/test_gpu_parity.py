@@ -192,3 +192,40 @@ def test_empty_and_errors():
     with pytest.raises(ValueError, match="outside"):       # the reference would corrupt memory
         K.train_linear_kernel(1, 4, 0.1, 0.01, 0, 0, 0.1, 0.1, 0.007, 0.0, u, v,
                               np.array([[0, 3]], dtype=np.int32), np.array([3.0]), ib, ub)
+
+
+def _zipf_problem(nu, ni, nnz, seed):
+    rs = np.random.RandomState(seed)
+    pi = 1.0 / np.arange(1, ni + 1) ** 1.1
+    pu = 1.0 / np.arange(1, nu + 1) ** 0.8
+    idx = np.stack([rs.choice(nu, nnz, p=pu / pu.sum()), rs.choice(ni, nnz, p=pi / pi.sum())], 1).astype(np.int32)
+    return idx, rs.randint(1, 6, nnz).astype(np.float64)
+
+
+@pytest.mark.parametrize("k", [16, 64])
+def test_power_law_tail_kernel_bitexact(k, monkeypatch):
+    """Skewed degrees: thousands of tiny levels (the chain of the hottest item) go through the
+    single-workgroup tail kernel; result must still be the sequential loop's, bit for bit, and
+    identical to the launch-per-level path (MFX_K1_TAIL=0)."""
+    from mfrec_amd.plan import SgdPlan
+    from oracle import oracle as O
+    nu, ni, nnz = 3000, 2000, 60000
+    idx, r = _zipf_problem(nu, ni, nnz, 3)
+    u0, v0 = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
+    res = []
+    for tail in ("1", "0"):
+        monkeypatch.setenv("MFX_K1_TAIL", tail)
+        u, v, ib, ub = u0.copy(), v0.copy(), np.zeros(ni), np.zeros(nu)
+        with SgdPlan(idx, r, nu, ni, k) as p:
+            info = p.info()
+            p.set_factors(u, v, ib, ub)
+            rm = p.run_kmf(0, 2, 0.01, 0.1, 0.1, 0.007)
+            p.get_factors(u, v, ib, ub)
+        res.append((u, v, ib, ub, rm, info))
+    assert res[0][5]["tail_launches"] >= 1 and res[1][5]["tail_launches"] == 0
+    assert res[0][5]["launches_per_epoch"] < res[1][5]["launches_per_epoch"] / 4
+    u2, v2, ib2, ub2, rm2 = u0.copy(), v0.copy(), np.zeros(ni), np.zeros(nu), np.zeros(2)
+    O.train_linear_kernel(2, k, 0.1, 0.01, 0, 0, 0.1, 0.1, 0.007, 0.0, u2, v2, idx, r, ib2, ub2, 1, 1, 0, rm2)
+    for u, v, ib, ub, rm, _ in res:
+        eq(u, u2); eq(v, v2); eq(ib, ib2); eq(ub, ub2)
+        np.testing.assert_allclose(rm, rm2, rtol=1e-12)

@@ -18,8 +18,8 @@ struct LaunchSeg {      // one kernel launch of a full-k epoch
 
 struct mfx_sgd_plan {
     int64_t nnz = 0;
-    std::vector<LaunchSeg> segs;
-    int64_t *d_level_off = nullptr, *d_k1_wave_off = nullptr;
+    std::vector<LaunchSeg> segs, segs2;   // full-k / Funk launch sequences
+    int64_t *d_level_off = nullptr, *d_k1_wave_off = nullptr, *d_k2_wave_off = nullptr;
     int nu = 0, ni = 0, k = 0;
     int64_t n_levels = 0, max_level = 0;
     int batch = 16, nt = 0;              // full-k kernel: ratings per wave, non-temporal row stores
@@ -196,6 +196,7 @@ int plan_batch(int k)
 }
 
 constexpr int kMaxK = 512;
+constexpr size_t kMaxGraphNodes = 16384;
 
 int enqueue_reduce(mfx_sgd_plan *p, int64_t n_partials)
 {
@@ -297,7 +298,8 @@ int run_k1_epochs(mfx_sgd_plan *p, int mode, int epochs, const K1Params &P, Hook
     if (rc) return rc;
     p->km_current = false;
     MFX_HIP(hipMemsetAsync(p->d_counter, 0, sizeof(int), stream()));
-    const bool graph = use_graph();
+    // very long launch sequences (power-law data without the tail kernel) are not worth a graph
+    const bool graph = use_graph() && p->segs.size() <= kMaxGraphNodes;
     if (graph && !(p->graph && p->graph_mode == mode && same_params(p->graph_params, P))) {
         drop_graph(p);
         hipGraph_t g = nullptr;
@@ -450,6 +452,20 @@ mfx_sgd_plan *mfx_sgd_plan_create(const int32_t *idx, const double *r, int64_t n
                     ++l;
                 }
             }
+            l = 0;
+            while (l < p->n_levels) {                      // same for the Funk pass
+                const int64_t c = p->level_off[l + 1] - p->level_off[l];
+                if (c <= 0) { ++l; continue; }
+                if (tail_on && c <= kTail2) {
+                    int64_t m = l;
+                    while (m < p->n_levels && p->level_off[m + 1] - p->level_off[m] <= kTail2) ++m;
+                    p->segs2.push_back({l, m, true});
+                    l = m;
+                } else {
+                    p->segs2.push_back({l, l + 1, false});
+                    ++l;
+                }
+            }
         }
         p->k1_waves = p->k1_wave_off[p->n_levels];
         p->k2_waves = p->k2_wave_off[p->n_levels];
@@ -458,10 +474,12 @@ mfx_sgd_plan *mfx_sgd_plan_create(const int32_t *idx, const double *r, int64_t n
 
         if (dev_alloc(p, &p->d_recs, (size_t)nnz)) return bail();
         if (dev_alloc(p, &p->d_level_off, (size_t)p->n_levels + 1) ||
-            dev_alloc(p, &p->d_k1_wave_off, (size_t)p->n_levels + 1))
+            dev_alloc(p, &p->d_k1_wave_off, (size_t)p->n_levels + 1) ||
+            dev_alloc(p, &p->d_k2_wave_off, (size_t)p->n_levels + 1))
             return bail();
         if (hipMemcpy(p->d_level_off, p->level_off.data(), ((size_t)p->n_levels + 1) * 8, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(p->d_k1_wave_off, p->k1_wave_off.data(), ((size_t)p->n_levels + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) {
+            hipMemcpy(p->d_k1_wave_off, p->k1_wave_off.data(), ((size_t)p->n_levels + 1) * 8, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(p->d_k2_wave_off, p->k2_wave_off.data(), ((size_t)p->n_levels + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) {
             fail(MFX_E_HIP, "mfx_sgd_plan_create: upload of level offsets failed");
             return bail();
         }
@@ -492,7 +510,7 @@ void mfx_sgd_plan_destroy(mfx_sgd_plan *p)
     if (ready()) (void)hipStreamSynchronize(stream());
     drop_graph(p);
     void *ptrs[] = {p->d_recs, p->d_U_km, p->d_V_km, p->d_U_nk, p->d_V_nk, p->d_ib, p->d_ub,
-                    p->d_cache, p->d_k2dyn, p->d_level_off, p->d_k1_wave_off, p->d_se_partial, p->d_se_tmp, p->d_se_epoch, p->d_counter, p->d_U_start,
+                    p->d_cache, p->d_k2dyn, p->d_level_off, p->d_k1_wave_off, p->d_k2_wave_off, p->d_se_partial, p->d_se_tmp, p->d_se_epoch, p->d_counter, p->d_U_start,
                     p->d_ib_start};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -513,7 +531,8 @@ int mfx_sgd_plan_info(const mfx_sgd_plan *p, int64_t info[8])
     info[4] = p->batch;
     info[5] = (int64_t)p->dev_bytes;
     info[6] = p->sched_us;
-    info[7] = flaunches;
+    info[7] = (int64_t)p->segs2.size();
+    (void)flaunches;
     return MFX_OK;
 }
 
@@ -599,12 +618,17 @@ int mfx_sgd_profile_kmf(mfx_sgd_plan *p, int mode, double lr, double Ku, double 
 // ---- Funk: per-feature passes with the data-dependent stopping rule (host-driven) ----
 static int enqueue_k2_epoch(mfx_sgd_plan *p, const K2Params &P)
 {
-    for (int64_t l = 0; l < p->n_levels; ++l) {
-        const int64_t start = p->level_off[l];
-        const int count = (int)(p->level_off[l + 1] - start);
-        if (count <= 0) continue;
-        hipLaunchKernelGGL(k2_level, dim3(ceil_div(count, 256)), dim3(256), 0, stream(), P, start,
-                           count, p->k2_wave_off[l]);
+    for (const LaunchSeg &sg : p->segs2) {
+        if (!sg.tail) {
+            const int64_t start = p->level_off[sg.l0];
+            const int count = (int)(p->level_off[sg.l0 + 1] - start);
+            hipLaunchKernelGGL(k2_level, dim3(ceil_div(count, 256)), dim3(256), 0, stream(), P, start,
+                               count, p->k2_wave_off[sg.l0]);
+        } else {
+            hipLaunchKernelGGL(k2_tail, dim3(1), dim3(kTail2), 0, stream(), P,
+                               (const int64_t *)p->d_level_off, (const int64_t *)p->d_k2_wave_off,
+                               (int)sg.l0, (int)sg.l1);
+        }
     }
     MFX_HIP(hipGetLastError());
     return enqueue_reduce(p, p->k2_waves);
@@ -644,7 +668,7 @@ int mfx_sgd_run_funk(mfx_sgd_plan *p, int min_epochs, double min_improvement, do
 
     // one epoch = all levels + the SE reduction, captured once and replayed for every
     // (feature, epoch): the per-feature pointers live behind P.dyn
-    const bool graph = use_graph();
+    const bool graph = use_graph() && p->segs2.size() <= kMaxGraphNodes;
     if (graph && !(p->graph2 && memcmp(&p->graph2_params, &P, sizeof(P)) == 0)) {
         if (p->graph2) (void)hipGraphExecDestroy(p->graph2);
         p->graph2 = nullptr;

@@ -384,13 +384,10 @@ __device__ __forceinline__ double funk_estimate(double uf, double vf, double cac
     return sum;
 }
 
-__global__ __launch_bounds__(256) void k2_level(K2Params P, int64_t start, int count,
-                                                int64_t wave_off)
+__device__ __forceinline__ double k2_one(const K2Params &P, double *uf, double *vf, double trail,
+                                         int64_t start, int t, int count)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;
     double e2 = 0.0;
-    double *const uf = P.dyn->uf, *const vf = P.dyn->vf;
-    const double trail = P.dyn->trail;
     if (t < count) {
         const Rec rec = P.recs[start + t];
         const double c = P.cache[start + t];
@@ -404,9 +401,38 @@ __global__ __launch_bounds__(256) void k2_level(K2Params P, int64_t start, int c
         if (P.upd_i) uf[rec.item] = mf + P.lr * (err * cf - P.K * mf);
         if (P.upd_u) vf[rec.user] = cf + P.lr * (err * mf - P.K * cf);
     }
+    return e2;
+}
+
+__global__ __launch_bounds__(256) void k2_level(K2Params P, int64_t start, int count,
+                                                int64_t wave_off)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    double *const uf = P.dyn->uf, *const vf = P.dyn->vf;
+    const double e2 = k2_one(P, uf, vf, P.dyn->trail, start, t, count);
     const double wsum = wave_sum_fixed(e2);
     if ((threadIdx.x & 63) == 0)
         P.se_partial[wave_off + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)] = wsum;
+}
+
+// run of small levels (each <= 1024 ratings) by one 1024-thread workgroup
+static constexpr int kTail2 = 1024;
+__global__ __launch_bounds__(kTail2) void k2_tail(K2Params P, const int64_t *level_off,
+                                                  const int64_t *wave_off, int l0, int l1)
+{
+    double *const uf = P.dyn->uf, *const vf = P.dyn->vf;
+    const double trail = P.dyn->trail;
+    const int wid = threadIdx.x >> 6;
+    for (int l = l0; l < l1; ++l) {
+        const int64_t start = level_off[l];
+        const int count = (int)(level_off[l + 1] - start);
+        const int64_t woff = wave_off[l];
+        const int nslots = (int)(wave_off[l + 1] - woff);        // = 4 * ceil(count / 256)
+        const double e2 = k2_one(P, uf, vf, trail, start, (int)threadIdx.x, count);
+        const double wsum = wave_sum_fixed(e2);
+        if ((threadIdx.x & 63) == 0 && wid < nslots) P.se_partial[woff + wid] = wsum;
+        __syncthreads();
+    }
 }
 
 // cache-commit pass (gd_estimator.pyx:771-777): embarrassingly parallel over all ratings

@@ -229,3 +229,17 @@ def test_power_law_tail_kernel_bitexact(k, monkeypatch):
     for u, v, ib, ub, rm, _ in res:
         eq(u, u2); eq(v, v2); eq(ib, ib2); eq(ub, ub2)
         np.testing.assert_allclose(rm, rm2, rtol=1e-12)
+
+
+def test_power_law_funk_tail_bitexact(monkeypatch):
+    from mfrec_amd.lib import gd_estimator as G
+    from oracle import oracle as O
+    nu, ni, nnz, k = 3000, 2000, 60000, 4
+    idx, r = _zipf_problem(nu, ni, nnz, 5)
+    fu2, fv2 = synth.init_const(k, ni), synth.init_const(k, nu)
+    O.estimator_loop_without_bias(3, 3, 1e9, k, 0.1, 0.001, 0.05, fu2, fv2, idx, r, nu, ni)
+    for tail in ("1", "0"):
+        monkeypatch.setenv("MFX_K1_TAIL", tail)
+        fu, fv = synth.init_const(k, ni), synth.init_const(k, nu)
+        G.estimator_loop_without_bias(3, 3, 1e9, k, 0.1, 0.001, 0.05, fu, fv, idx, r, nu, ni)
+        eq(fu, fu2); eq(fv, fv2)

@@ -196,7 +196,7 @@ int plan_batch(int k)
 }
 
 constexpr int kMaxK = 512;
-constexpr size_t kMaxGraphNodes = 16384;
+constexpr size_t kMaxGraphNodes = 65536;
 
 int enqueue_reduce(mfx_sgd_plan *p, int64_t n_partials)
 {

@@ -102,149 +102,9 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const double *partial, int 
 }
 
 // ------------------------------------------------------------------------------------
-// per-row assemble + solve.  One workgroup (256 threads) per active row.
-// ------------------------------------------------------------------------------------
-template <int NT>
-__global__ __launch_bounds__(256) void k_als_rows(const double *__restrict__ Y, int k,
-                                                  const double *__restrict__ G,   // [KP][KP]
-                                                  const int64_t *__restrict__ off,  // [n_active+1]
-                                                  const int32_t *__restrict__ col, double c_pos,
-                                                  double one_plus_c, double lambda, double *X,
-                                                  int *status)
-{
-    constexpr int KP = NT * 16;
-    constexpr int TPW = (NT * NT + 3) / 4;
-    constexpr int AS = KP + 1;                       // A row stride
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int S = ych_stride(KP);
-    double *A = lds;                                 // [KP + 1][AS]; row KP = right-hand side
-    double *ych = A + (KP + 1) * AS + ((KP + 1) * AS & 1);   // [CH][S], 16-B aligned
-    double *dinv = ych + CH * S;                     // [KP] 1 / L[c][c]
-    int *bad = (int *)(dinv + KP);                   // not-SPD flag (kept in the dynamic region: G17)
-
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int j = blockIdx.x;
-    const int64_t start = off[j];
-    const int span = (int)(off[j + 1] - start);
-    double *xrow = X + (size_t)j * k;
-
-    if (span == 0) {                                 // b = 0  =>  x = 0 (als_implicit.pyx:298-302)
-        for (int f = threadIdx.x; f < k; f += 256) xrow[f] = 0.0;
-        return;
-    }
-    if (threadIdx.x == 0) *bad = 0;
-
-    double4_t acc[TPW];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    double bsum = 0.0;                               // thread f < KP owns b[f]
-
-    for (int c0 = 0; c0 < span; c0 += CH) {
-        // gather CH neighbour rows (zero-padded)
-        for (int e = threadIdx.x; e < CH * KP; e += 256) {
-            const int n = e / KP, f = e % KP;
-            double val = 0.0;
-            if (c0 + n < span && f < k) val = Y[(size_t)col[start + c0 + n] * k + f];
-            ych[n * S + f] = val;
-        }
-        __syncthreads();
-        if ((int)threadIdx.x < KP) {
-#pragma unroll
-            for (int n = 0; n < CH; ++n) bsum += ych[n * S + threadIdx.x] * one_plus_c;
-        }
-#pragma unroll
-        for (int n0 = 0; n0 < CH; n0 += 4) {
-            const double *base = ych + (n0 + (lane >> 4)) * S + (lane & 15);
-#pragma unroll
-            for (int t = 0; t < TPW; ++t) {
-                const int tile = wid * TPW + t;
-                if (tile < NT * NT) {
-                    const int I = tile / NT, J = tile % NT;
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(base[I * 16], base[J * 16], acc[t], 0, 0, 0);
-                }
-            }
-        }
-        __syncthreads();
-    }
-
-    // A = G + c * acc + lambda I  (identity on the padding); row KP carries b
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const int tile = wid * TPW + t;
-        if (tile < NT * NT) {
-            const int I = tile / NT, J = tile % NT;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = I * 16 + (lane >> 4) + 4 * q, c = J * 16 + (lane & 15);
-                double a;
-                if (r < k && c < k) {
-                    a = G[r * KP + c] + acc[t][q] * c_pos;
-                    if (r == c) a += lambda;
-                } else {
-                    a = (r == c) ? 1.0 : 0.0;
-                }
-                A[r * AS + c] = a;
-            }
-        }
-    }
-    if ((int)threadIdx.x < KP) A[KP * AS + threadIdx.x] = ((int)threadIdx.x < k) ? bsum : 0.0;
-    __syncthreads();
-
-    // ---- Cholesky of the bordered matrix [A b; b^T .]: A = L L^T in place (lower), and the
-    //      border row comes out as z = L^{-1} b, so no separate forward substitution ---------
-    for (int c = 0; c < k; ++c) {
-        const double d = A[c * AS + c];
-        if (!(d > 0.0)) {                            // uniform: every thread reads the same d
-            if (threadIdx.x == 0) *bad = 1;
-            break;
-        }
-        const double inv = 1.0 / sqrt(d);
-        __syncthreads();                             // everyone has read A[c][c]
-        // rows c+1 .. k-1 and the border row (logical row k -> physical row KP)
-        for (int r = c + 1 + threadIdx.x; r <= k; r += 256) {
-            const int pr = (r == k) ? KP : r;
-            A[pr * AS + c] *= inv;
-        }
-        if (threadIdx.x == 0) dinv[c] = inv;
-        __syncthreads();
-        const int m = k - c - 1;                     // trailing columns c+1 .. k-1
-        for (int e = threadIdx.x; e < (m + 1) * m; e += 256) {
-            const int r = c + 1 + e / m, cc = c + 1 + e % m;
-            if (cc <= r) {
-                const int pr = (r == k) ? KP : r;
-                A[pr * AS + cc] -= A[pr * AS + c] * A[cc * AS + c];
-            }
-        }
-        __syncthreads();
-    }
-    __syncthreads();
-    if (*bad) {
-        if (threadIdx.x == 0) atomicExch(status, j + 1);
-        return;
-    }
-
-    // ---- back substitution L^T x = z by wave 0; lane owns x[lane] and x[lane + 64] ---------
-    if (wid == 0) {
-        double z0 = (lane < k) ? A[KP * AS + lane] : 0.0;
-        double z1 = (lane + 64 < k) ? A[KP * AS + lane + 64] : 0.0;
-        for (int c = k - 1; c >= 0; --c) {
-            const double zc = (c >= 64) ? z1 : z0;
-            const int src = c & 63;
-            const int lo = __shfl(__double2loint(zc), src, 64), hi = __shfl(__double2hiint(zc), src, 64);
-            const double x = __hiloint2double(hi, lo) * dinv[c];
-            if (lane == src) { if (c >= 64) z1 = x; else z0 = x; }
-            // z_r -= L[c][r] * x for r < c (row c of L is contiguous)
-            if (lane < c) z0 -= A[c * AS + lane] * x;
-            if (lane + 64 < c) z1 -= A[c * AS + lane + 64] * x;
-        }
-        if (lane < k) xrow[lane] = z0;
-        if (lane + 64 < k) xrow[lane + 64] = z1;
-    }
-}
-
-// ------------------------------------------------------------------------------------
-// v2 of the per-row kernel: symmetric-half MFMA tiles, software-prefetched neighbour
-// gather, MFMA-blocked Cholesky (16-wide panels), register back substitution.
+// per-row assemble + solve, one 256-thread workgroup per active row: symmetric-half MFMA
+// tiles, software-prefetched neighbour gather, MFMA-blocked Cholesky (16-wide panels) with
+// look-ahead, register back substitution.
 // ------------------------------------------------------------------------------------
 constexpr int CH2 = 32;                // neighbour rows per chunk
 
@@ -608,14 +468,13 @@ __global__ __launch_bounds__(256) void k_transpose_als(const double *in, double 
 
 struct AlsKernels {
     void *gram;
-    void *rows;     // v1: unblocked (kept as a cross-check, MFX_ALS_V1=1)
-    void *rows2;    // v2: blocked
+    void *rows2;
 };
 
 template <int NT>
 AlsKernels als_kernels_nt()
 {
-    return {(void *)k_gram_partial<NT>, (void *)k_als_rows<NT>, (void *)k_als_rows2<NT>};
+    return {(void *)k_gram_partial<NT>, (void *)k_als_rows2<NT>};
 }
 
 size_t rows2_lds_bytes(int KP)
@@ -681,12 +540,8 @@ int als_half(int k, int NT, const AlsKernels &K, const double *dY, int ny, doubl
         MFX_HIP(hipGetLastError());
     }
     if (n_active > 0) {
-        const char *v1 = getenv("MFX_ALS_V1");
-        const bool use_v1 = v1 && v1[0] == '1';
-        const size_t a_elems = (size_t)(KP + 1) * (KP + 1);
-        const size_t lds = use_v1 ? (a_elems + (a_elems & 1) + (size_t)CH * ych_stride(KP) + KP + 2) * sizeof(double)
-                                  : rows2_lds_bytes(KP);
-        void *rows_fn = use_v1 ? K.rows : K.rows2;
+        const size_t lds = rows2_lds_bytes(KP);
+        void *rows_fn = K.rows2;
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute(rows_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         const double *Yc = dY;

@@ -97,6 +97,25 @@ int mfx_funk(int min_epochs, double min_improvement, int dim, double f_init, dou
              int64_t nnz, int nu, int ni, int update_users, int update_items, int epoch_cap,
              double *rmse_hist, int64_t hist_cap, int64_t *n_hist);
 
+/* Dense-cache members of the same family.  The reference indexes a dense f64[nu*ni] cache by
+ * user + item*nu, so duplicate (user,item) ratings share a cell; reproduced exactly.
+ * variant 1 = estimator_loop (gd_estimator.pyx:210-303: honours max_epochs, fills
+ * rmse_hist[epoch + f*max_epochs + batch*max_epochs*dim]); variant 2 = estimator_loop2
+ * (:308-395: the stopping rule of :360, rmse_hist unused). */
+int mfx_funk_dense(int variant, int min_epochs, int max_epochs, double min_improvement, int dim,
+                   double f_init, double learning_rate, double K, double *u, double *v,
+                   const int32_t *ratings_index, const double *ratings, int batch,
+                   double *rmse_hist, int64_t nnz, int nu, int ni);
+/* estimator_subloop (gd_estimator.pyx:903-962): one epoch of feature f on the caller's dense
+ * cache f64[nu*ni]; *rmse_out = the value the reference returns. */
+int mfx_funk_subloop(int f, int dim, double f_init, double learning_rate, double K, double *u,
+                     double *v, const int32_t *ratings_index, const double *ratings,
+                     double *rating_cache, int64_t nnz, int nu, int ni, double *rmse_out);
+/* predictor_subloop (gd_estimator.pyx:967-995): cache-commit of feature f into the dense cache. */
+int mfx_funk_predictor_subloop(int f, int dim, double f_init, const double *u, const double *v,
+                               const int32_t *ratings_index, const double *ratings,
+                               double *rating_cache, int64_t nnz, int nu, int ni);
+
 /* estimator_loop_with_learned_bias (gd_estimator.pyx:401-421). */
 int mfx_learned_bias(int min_epochs, double min_improvement, int dim, double f_init,
                      double learning_rate, double learning_rate_users, double learning_rate_items,

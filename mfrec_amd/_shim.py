@@ -39,6 +39,13 @@ SIGNATURES = {
     "mfx_funk": (C.c_int, [C.c_int, C.c_double, C.c_int, C.c_double, C.c_double, C.c_double,
                            C.c_double, _dp, _dp, _ip, _dp, _dp, _dp, C.c_int64, C.c_int, C.c_int,
                            C.c_int, C.c_int, C.c_int, _dp, C.c_int64, _lp]),
+    "mfx_funk_dense": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double,
+                                 C.c_double, C.c_double, _dp, _dp, _ip, _dp, C.c_int, _dp,
+                                 C.c_int64, C.c_int, C.c_int]),
+    "mfx_funk_subloop": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, _dp, _dp,
+                                   _ip, _dp, _dp, C.c_int64, C.c_int, C.c_int, _dp]),
+    "mfx_funk_predictor_subloop": (C.c_int, [C.c_int, C.c_int, C.c_double, _dp, _dp, _ip, _dp, _dp,
+                                             C.c_int64, C.c_int, C.c_int]),
     "mfx_learned_bias": (C.c_int, [C.c_int, C.c_double, C.c_int, C.c_double, C.c_double,
                                    C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _dp,
                                    _dp, _ip, _dp, _dp, _dp, C.c_int64, C.c_int, C.c_int, C.c_int,

@@ -3,6 +3,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <chrono>
+#include <unordered_map>
 #include <vector>
 #include "mfx_sgd_kernels.h"
 
@@ -827,6 +828,209 @@ int mfx_learned_bias(int min_epochs, double min_improvement, int dim, double f_i
                                            hist_cap, n_hist);
     if (!rc) rc = mfx_sgd_get_factors(p, u, v, ib, ub);
     mfx_sgd_plan_destroy(p);
+    return rc;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------
+// Dense-cache members of the Funk family: estimator_loop (gd_estimator.pyx:210-303),
+// estimator_loop2 (:308-395), estimator_subloop (:903-962), predictor_subloop (:967-995).
+// The reference indexes an f64[nu*ni] cache by user + item*nu, so ratings with the same
+// (user, item) share a cell.  Here the cell of a pair is the device cache slot of its first
+// occurrence (no O(nu*ni) device memory); everything else is the K2 machinery.
+// ------------------------------------------------------------------------------------
+namespace {
+
+struct DenseCtx {
+    mfx_sgd_plan *p = nullptr;
+    std::vector<Rec> recs;          // level-major copy of the device records
+    std::vector<int32_t> slot;      // canonical position per position
+    int32_t *d_slot = nullptr;
+    K2Params P{};
+    ~DenseCtx()
+    {
+        if (d_slot) (void)hipFree(d_slot);
+        if (p) mfx_sgd_plan_destroy(p);
+    }
+};
+
+int dense_setup(DenseCtx &c, double *u, double *v, const int32_t *idx, const double *r, int64_t nnz,
+                int nu, int ni, int dim, double lr, double K)
+{
+    if (nnz > 0x7fffffff) return fail(MFX_E_ARG, "dense-cache variants: nnz too large");
+    c.p = mfx_sgd_plan_create(idx, r, nnz, nu, ni, dim);
+    if (!c.p) return last_code();
+    mfx_sgd_plan *p = c.p;
+    int rc = mfx_sgd_set_factors(p, u, v, nullptr, nullptr);
+    if (rc) return rc;
+    rc = dev_alloc(p, &p->d_cache, (size_t)nnz);
+    if (!rc) rc = dev_alloc(p, &p->d_k2dyn, 1);
+    if (rc) return rc;
+    c.recs.resize((size_t)nnz);
+    c.slot.resize((size_t)nnz);
+    MFX_HIP(hipMemcpy(c.recs.data(), p->d_recs, (size_t)nnz * sizeof(Rec), hipMemcpyDeviceToHost));
+    std::unordered_map<int64_t, int32_t> first;
+    first.reserve((size_t)nnz * 2);
+    for (int64_t j = 0; j < nnz; ++j) {
+        const int64_t key = (int64_t)c.recs[j].user + (int64_t)c.recs[j].item * nu;
+        auto it = first.find(key);
+        if (it == first.end()) {
+            first.emplace(key, (int32_t)j);
+            c.slot[j] = (int32_t)j;
+        } else {
+            c.slot[j] = it->second;
+        }
+    }
+    if (hipMalloc((void **)&c.d_slot, (size_t)nnz * sizeof(int32_t)) != hipSuccess)
+        return fail(MFX_E_NOMEM, "dense-cache variants: hipMalloc failed");
+    MFX_HIP(hipMemcpy(c.d_slot, c.slot.data(), (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+    MFX_HIP(hipMemset(p->d_cache, 0, (size_t)nnz * sizeof(double)));
+    K2Params &P = c.P;
+    memset(&P, 0, sizeof(P));
+    P.recs = p->d_recs;
+    P.dyn = p->d_k2dyn;
+    P.cache = p->d_cache;
+    P.slot = c.d_slot;
+    P.se_partial = p->d_se_partial;
+    P.lr = lr;
+    P.K = K;
+    P.mu = 1.0;                      // estimator() default overall_avg, gd_estimator.pyx:47
+    P.upd_u = P.upd_i = 1;
+    rc = to_km(p);
+    if (rc) return rc;
+    p->nk_current = false;
+    return MFX_OK;
+}
+
+int dense_set_feature(DenseCtx &c, int f, double f_init)
+{
+    mfx_sgd_plan *p = c.p;
+    K2Dyn dyn;
+    dyn.uf = p->d_U_km + (size_t)f * p->ni;
+    dyn.vf = p->d_V_km + (size_t)f * p->nu;
+    dyn.trail = (p->k - f - 1) * f_init * f_init;
+    MFX_HIP(hipMemcpy(p->d_k2dyn, &dyn, sizeof(dyn), hipMemcpyHostToDevice));
+    return MFX_OK;
+}
+
+int dense_epoch(DenseCtx &c, double *rmse)
+{
+    mfx_sgd_plan *p = c.p;
+    MFX_HIP(hipMemsetAsync(p->d_counter, 0, sizeof(int), stream()));
+    int rc = enqueue_k2_epoch(p, c.P);
+    if (rc) return rc;
+    double se = 0.0;
+    MFX_HIP(hipMemcpyAsync(&se, p->d_se_epoch, sizeof(double), hipMemcpyDeviceToHost, stream()));
+    MFX_HIP(hipStreamSynchronize(stream()));
+    *rmse = sqrt(se / (double)p->nnz);
+    return MFX_OK;
+}
+
+int dense_commit(DenseCtx &c)
+{
+    mfx_sgd_plan *p = c.p;
+    for (int64_t l = 0; l < p->n_levels; ++l) {
+        const int64_t start = p->level_off[l];
+        const int count = (int)(p->level_off[l + 1] - start);
+        if (count <= 0) continue;
+        hipLaunchKernelGGL(k2_commit_level, dim3(ceil_div(count, 256)), dim3(256), 0, stream(), c.P,
+                           start, count);
+    }
+    MFX_HIP(hipGetLastError());
+    return MFX_OK;
+}
+
+// caller-owned dense cache <-> device slots
+int dense_cache_in(DenseCtx &c, const double *dense, int nu)
+{
+    std::vector<double> h(c.recs.size(), 0.0);
+    for (size_t j = 0; j < c.recs.size(); ++j)
+        if (c.slot[j] == (int32_t)j) h[j] = dense[(size_t)c.recs[j].user + (size_t)c.recs[j].item * nu];
+    MFX_HIP(hipMemcpy(c.p->d_cache, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+    return MFX_OK;
+}
+
+int dense_cache_out(DenseCtx &c, double *dense, int nu)
+{
+    std::vector<double> h(c.recs.size());
+    MFX_HIP(hipStreamSynchronize(stream()));
+    MFX_HIP(hipMemcpy(h.data(), c.p->d_cache, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t j = 0; j < c.recs.size(); ++j)
+        if (c.slot[j] == (int32_t)j) dense[(size_t)c.recs[j].user + (size_t)c.recs[j].item * nu] = h[j];
+    return MFX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mfx_funk_dense(int variant, int min_epochs, int max_epochs, double min_improvement, int dim,
+                   double f_init, double lr, double K, double *u, double *v, const int32_t *idx,
+                   const double *r, int batch, double *rmse_hist, int64_t nnz, int nu, int ni)
+{
+    if (!u || !v || nnz <= 0 || !idx || !r || (variant != 1 && variant != 2) ||
+        (variant == 1 && (!rmse_hist || max_epochs < 0 || batch < 0)))
+        return fail(MFX_E_ARG, "mfx_funk_dense: bad argument");
+    DenseCtx c;
+    int rc = dense_setup(c, u, v, idx, r, nnz, nu, ni, dim, lr, K);
+    if (rc) return rc;
+    double rmse = 2.0, rmse_last = 0.0, improvement = 0.0;
+    for (int f = 0; f < dim; ++f) {
+        rc = dense_set_feature(c, f, f_init);
+        if (rc) return rc;
+        int epoch = 0;
+        for (;;) {
+            if (variant == 2) {                              // gd_estimator.pyx:360
+                if (!(epoch < min_epochs || rmse <= rmse_last - min_improvement)) break;
+            } else {                                         // gd_estimator.pyx:264
+                if (!((epoch < min_epochs || improvement >= min_improvement) && epoch < max_epochs)) break;
+            }
+            rmse_last = rmse;
+            rc = dense_epoch(c, &rmse);
+            if (rc) return rc;
+            if (variant == 1) {
+                rmse_hist[epoch + f * max_epochs + batch * max_epochs * dim] = rmse;   // :285
+                improvement = rmse_last - rmse;
+            }
+            ++epoch;
+        }
+        rc = dense_commit(c);
+        if (rc) return rc;
+    }
+    return mfx_sgd_get_factors(c.p, u, v, nullptr, nullptr);
+}
+
+int mfx_funk_subloop(int f, int dim, double f_init, double lr, double K, double *u, double *v,
+                     const int32_t *idx, const double *r, double *rating_cache, int64_t nnz, int nu,
+                     int ni, double *rmse_out)
+{
+    if (!u || !v || nnz <= 0 || !idx || !r || !rating_cache || f < 0 || f >= dim)
+        return fail(MFX_E_ARG, "mfx_funk_subloop: bad argument");
+    DenseCtx c;
+    int rc = dense_setup(c, u, v, idx, r, nnz, nu, ni, dim, lr, K);
+    if (!rc) rc = dense_cache_in(c, rating_cache, nu);
+    if (!rc) rc = dense_set_feature(c, f, f_init);
+    double rmse = 0.0;
+    if (!rc) rc = dense_epoch(c, &rmse);
+    if (rc) return rc;
+    if (rmse_out) *rmse_out = rmse;
+    return mfx_sgd_get_factors(c.p, u, v, nullptr, nullptr);
+}
+
+int mfx_funk_predictor_subloop(int f, int dim, double f_init, const double *u, const double *v,
+                               const int32_t *idx, const double *r, double *rating_cache,
+                               int64_t nnz, int nu, int ni)
+{
+    if (!u || !v || nnz <= 0 || !idx || !r || !rating_cache || f < 0 || f >= dim)
+        return fail(MFX_E_ARG, "mfx_funk_predictor_subloop: bad argument");
+    DenseCtx c;
+    int rc = dense_setup(c, const_cast<double *>(u), const_cast<double *>(v), idx, r, nnz, nu, ni,
+                         dim, 0.0, 0.0);
+    if (!rc) rc = dense_cache_in(c, rating_cache, nu);
+    if (!rc) rc = dense_set_feature(c, f, f_init);
+    if (!rc) rc = dense_commit(c);
+    if (!rc) rc = dense_cache_out(c, rating_cache, nu);
     return rc;
 }
 

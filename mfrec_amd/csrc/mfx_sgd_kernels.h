@@ -363,6 +363,8 @@ struct K2Params {
     const Rec *recs;
     const K2Dyn *dyn;
     double *cache;        // level-major, one per rating
+    const int32_t *slot;  // nullable: dense-cache semantics (gd_estimator.pyx:250-255) -- ratings
+                          // with equal (user, item) share the cell of their first occurrence
     const double *ib;     // nullable (without_bias)
     const double *ub;
     double *se_partial;
@@ -390,7 +392,7 @@ __device__ __forceinline__ double k2_one(const K2Params &P, double *uf, double *
     double e2 = 0.0;
     if (t < count) {
         const Rec rec = P.recs[start + t];
-        const double c = P.cache[start + t];
+        const double c = P.cache[P.slot ? (int64_t)P.slot[start + t] : start + t];
         double base;
         if (P.ib) base = P.mu + P.ib[rec.item] + P.ub[rec.user];
         else base = P.mu + 0.0 + 0.0;
@@ -447,6 +449,21 @@ __global__ __launch_bounds__(256) void k2_commit(K2Params P, int64_t nnz)
         else base = P.mu + 0.0 + 0.0;
         P.cache[t] = funk_estimate(uf[rec.item], vf[rec.user], P.cache[t], base, 0.0, false);
     }
+}
+
+// cache-commit of ONE level (dense-cache variants: duplicates of a cell are in different
+// levels and must be applied in order, gd_estimator.pyx:295-301)
+__global__ __launch_bounds__(256) void k2_commit_level(K2Params P, int64_t start, int count)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= count) return;
+    const double *const uf = P.dyn->uf, *const vf = P.dyn->vf;
+    const Rec rec = P.recs[start + t];
+    const int64_t cs = P.slot ? (int64_t)P.slot[start + t] : start + t;
+    double base;
+    if (P.ib) base = P.mu + P.ib[rec.item] + P.ub[rec.user];
+    else base = P.mu + 0.0 + 0.0;
+    P.cache[cs] = funk_estimate(uf[rec.item], vf[rec.user], P.cache[cs], base, 0.0, false);
 }
 
 // ------------------------------------------------------------------------------------

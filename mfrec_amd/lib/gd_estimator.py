@@ -91,3 +91,50 @@ def funk_rmse_history(min_epochs, min_improvement, dim, f_init, learning_rate, K
     """Extension: run the Funk loop and return the per-epoch online RMSE history."""
     return _funk(min_epochs, min_improvement, dim, f_init, learning_rate, K, overall_avg, u, v,
                  ratings_index, ratings, items_bias, users_bias, update_users, update_items, 0)
+
+
+def _dense_args(u, v, dim, ratings_index, ratings):
+    pu, pv, nu, ni = S.factor_args(u, v, int(dim))
+    pi, pr, nnz = S.ratings_args(ratings_index, ratings)
+    return pu, pv, nu, ni, pi, pr, nnz
+
+
+def estimator_loop(min_epochs, max_epochs, min_improvement, dim, f_init, learning_rate, K, u, v,
+                   ratings_index, ratings, batch, rmse_hist, nbr_users, nbr_features, verbose=0):
+    """gd_estimator.pyx:210-303: dense cache, honours max_epochs, fills rmse_hist in place."""
+    pu, pv, nu, ni, pi, pr, nnz = _dense_args(u, v, dim, ratings_index, ratings)
+    ph = S.f64(rmse_hist, "rmse_hist", 1)
+    if rmse_hist.shape[0] < (int(batch) + 1) * int(max_epochs) * int(dim):
+        raise ValueError("rmse_hist is too small for batch/max_epochs/dim")
+    S.check(S.lib().mfx_funk_dense(1, int(min_epochs), int(max_epochs), float(min_improvement),
+                                   int(dim), float(f_init), float(learning_rate), float(K), pu, pv,
+                                   pi, pr, int(batch), ph, nnz, nu, ni))
+
+
+def estimator_loop2(min_epochs, max_epochs, min_improvement, dim, f_init, learning_rate, K, u, v,
+                    ratings_index, ratings, features_bias, nbr_users, nbr_features, verbose=0):
+    """gd_estimator.pyx:308-395 (features_bias is accepted and unused, as in the reference)."""
+    pu, pv, nu, ni, pi, pr, nnz = _dense_args(u, v, dim, ratings_index, ratings)
+    S.check(S.lib().mfx_funk_dense(2, int(min_epochs), int(max_epochs), float(min_improvement),
+                                   int(dim), float(f_init), float(learning_rate), float(K), pu, pv,
+                                   pi, pr, 0, None, nnz, nu, ni))
+
+
+def estimator_subloop(f, epochs, min_improvement, dim, f_init, learning_rate, K, u, v,
+                      ratings_index, ratings, rating_cache, nbr_users, nbr_features, verbose=0):
+    """gd_estimator.pyx:903-962: one epoch of feature f on the caller's dense cache; returns rmse."""
+    pu, pv, nu, ni, pi, pr, nnz = _dense_args(u, v, dim, ratings_index, ratings)
+    pc = S.f64(rating_cache, "rating_cache", 1, (nu * ni,))
+    out = C.c_double(0.0)
+    S.check(S.lib().mfx_funk_subloop(int(f), int(dim), float(f_init), float(learning_rate), float(K),
+                                     pu, pv, pi, pr, pc, nnz, nu, ni, C.byref(out)))
+    return out.value
+
+
+def predictor_subloop(f, epochs, dim, f_init, u, v, ratings_index, ratings, rating_cache,
+                      nbr_users, nbr_features):
+    """gd_estimator.pyx:967-995: cache-commit of feature f into the caller's dense cache."""
+    pu, pv, nu, ni, pi, pr, nnz = _dense_args(u, v, dim, ratings_index, ratings)
+    pc = S.f64(rating_cache, "rating_cache", 1, (nu * ni,))
+    S.check(S.lib().mfx_funk_predictor_subloop(int(f), int(dim), float(f_init), pu, pv, pi, pr, pc,
+                                               nnz, nu, ni))

@@ -243,3 +243,28 @@ def test_power_law_funk_tail_bitexact(monkeypatch):
         fu, fv = synth.init_const(k, ni), synth.init_const(k, nu)
         G.estimator_loop_without_bias(3, 3, 1e9, k, 0.1, 0.001, 0.05, fu, fv, idx, r, nu, ni)
         eq(fu, fu2); eq(fv, fv2)
+
+
+def test_funk_dense_cache_family_bitexact(golden):
+    """estimator_loop / estimator_loop2 / estimator_subloop / predictor_subloop: the dense-cache
+    semantics (duplicates share a cell) against the reference's goldens."""
+    from mfrec_amd.lib import gd_estimator as G
+    g = golden("g3_funk")
+    k, E = int(g["p_k"]), int(g["p_epochs"])
+    init, lr, K = float(g["p_init"]), float(g["p_lr"]), float(g["p_K"])
+    idx, r = g["in_idx"], g["in_r"]
+    assert len(set(map(tuple, idx))) < len(idx)              # the fixture does contain duplicates
+    u, v, hist = synth.init_const(k, 40), synth.init_const(k, 60), np.zeros(k * E)
+    G.estimator_loop(E, E, 1e9, k, init, lr, K, u, v, idx, r, 0, hist, 60, 40, 0)
+    eq(u, g["out_dense_u"]); eq(v, g["out_dense_v"])
+    np.testing.assert_allclose(hist, g["out_dense_rmse_hist"], rtol=1e-12)
+    u, v = synth.init_const(k, 40), synth.init_const(k, 60)
+    G.estimator_loop2(E, E, 1e9, k, init, lr, K, u, v, idx, r, np.zeros(40), 60, 40)
+    eq(u, g["out_dense_u"]); eq(v, g["out_dense_v"])
+    u, v, c, sub = synth.init_const(k, 40), synth.init_const(k, 60), np.zeros(2400), []
+    for f in range(2):                                       # gradient_descent.py:322-328 pattern
+        for _ in range(3):
+            sub.append(G.estimator_subloop(f, 1, 0.0, k, init, lr, K, u, v, idx, r, c, 60, 40))
+        G.predictor_subloop(f, 1, k, init, u, v, idx, r, c, 60, 40)
+    np.testing.assert_allclose(sub, g["out_sub_rmse"], rtol=1e-12)
+    eq(u, g["out_sub_u"]); eq(v, g["out_sub_v"]); eq(c, g["out_sub_cache"])

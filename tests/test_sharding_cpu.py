@@ -122,3 +122,37 @@ def test_two_process_gloo_equals_simulation(tmp_path):
         lo, n = int(z["lo"]), int(z["n"])
         assert np.array_equal(z["v"], sim[1][:, lo:lo + n])
         assert np.array_equal(z["ub"], sim[3][lo:lo + n])
+
+
+RDZV_WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+from mfrec_amd import rendezvous
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+uid = rendezvous.exchange_unique_id(rank, world, lambda: bytes(range(128)) if rank == 0 else b"", timeout_s=60)
+open(%(out)r %% rank, "wb").write(uid)
+"""
+
+
+def test_file_rendezvous_delivers_the_unique_id(tmp_path):
+    """bench.py's torch-free bootstrap: rank 0 publishes 128 bytes, the other ranks (same parent
+    process, as under torch.distributed.run) receive exactly those bytes."""
+    out = str(tmp_path / "uid%d.bin")
+    script = tmp_path / "rdzv_worker.py"
+    script.write_text(RDZV_WORKER % {"root": ROOT, "out": out})
+    procs = []
+    for rank in (2, 1, 0):                    # rank 0 last: the others must wait for the publish
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="3", MASTER_PORT="47123")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env))
+    for p in procs:
+        assert p.wait(timeout=120) == 0
+    for rank in range(3):
+        assert open(out % rank, "rb").read() == bytes(range(128))
+    from mfrec_amd import rendezvous
+    os.environ["MASTER_PORT"] = "47123"
+    try:
+        # cleanup is keyed by (parent pid, port): from this process the key differs, so emulate rank 0
+        import shutil, tempfile
+        shutil.rmtree(os.path.join(tempfile.gettempdir(), "mfx_rdzv_%d_47123" % os.getpid()), ignore_errors=True)
+    finally:
+        del os.environ["MASTER_PORT"]

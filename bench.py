@@ -176,7 +176,7 @@ def main():
     try:
         import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-        if cands and a.order == "shuffled" and k == 64:
+        if cands and a.order == "shuffled" and (nu, ni, nnz, k) == (100000, 50000, 10000000, 64):
             tj = json.load(open(cands[-1]))
             traffic = (tj["read_bytes_per_rating"] + tj["write_bytes_per_rating"]) * nnz / launches
             traffic_src = os.path.basename(cands[-1])
@@ -190,10 +190,11 @@ def main():
             "unit": "rating-updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": wall * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "cfg2: synthetic %dK users x %dK items, %dM ratings per GPU, "
+            "config": {"workload": "%s: synthetic %dK users x %dK items, %dM ratings per GPU, "
                                    "k=%d, full-k SGD (train_linear_kernel), %s order, "
-                                   "exact level schedule" % (nu // 1000, ni // 1000,
-                                                             nnz // 1000000, k, a.order),
+                                   "exact level schedule" % (
+                                       "cfg2" if (nu, ni, nnz, k) == (100000, 50000, 10000000, 64) else "custom",
+                                       nu // 1000, ni // 1000, nnz // 1000000, k, a.order),
                        "users_per_gpu": nu, "items": ni, "ratings_per_gpu": nnz, "k": k,
                        "levels": info["n_levels"], "launches_per_epoch": info["launches_per_epoch"],
                        "sharding": "users x%d, item-delta all-reduce (RCCL)" % world if world > 1 else "none"},

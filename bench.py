@@ -202,7 +202,10 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
                          "traffic_unit": "bytes per launch (PMC, %s)" % traffic_src,
                          "algorithmic_bytes_per_launch": b_read * nnz / launches,
-                         "kernel": "k1_level<64,1,%d,linear>" % info["ratings_per_wave"],
+                         "kernel": "k1_level<%d,%d,%d,linear>" % (
+                             (8 if k <= 8 else 16 if k <= 16 else 32 if k <= 32 else 64),
+                             (1 if k <= 64 else 2 if k <= 128 else 4 if k <= 256 else 8),
+                             info["ratings_per_wave"]),
                          "bytes_per_update_read": b_read, "bytes_per_update_total": b_total,
                          "avg_launch_us": avg_launch_s * 1e6, "launches_per_epoch": launches,
                          "event_pair_avg_launch_us": kern_ms * 1e3 / launches,

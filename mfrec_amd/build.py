@@ -25,7 +25,7 @@ def build(force=False, verbose=True):
         return OUT
     hipcc = os.environ.get("HIPCC", "hipcc")
     extra = os.environ.get("MFX_EXTRA_FLAGS", "").split()      # diagnostic builds only
-    cmd = [hipcc] + FLAGS + extra + srcs + ["-o", OUT if not extra else OUT.replace("libmfx.so", "libmfx_diag.so"), "-ldl"]
+    cmd = [hipcc] + FLAGS + extra + srcs + ["-o", OUT if not extra else OUT.replace("libmfx.so", "libmfx_diag.so"), "-ldl", "-lpthread"]
     if verbose:
         print("[mfrec_amd.build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -200,6 +200,15 @@ int mfx_sgd_run_kmf_sharded(mfx_sgd_plan *p, int mode, int nbr_epochs, double le
                             double *rmse_out /* local shard's online RMSE */,
                             double *se_out /* nullable: f64[nbr_epochs] local sum of squared errors */);
 
+/* Funk passes (estimator_loop_without_bias / _with_bias) on a user shard: after every
+ * feature-epoch the item-side vector U[f,:] is combined as for the full-k kernels
+ * (all-reduce of [ni] doubles) and the squared error is made global, so every rank takes the
+ * same decision in the stopping rule of gd_estimator.pyx:742. */
+int mfx_sgd_run_funk_sharded(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_init,
+                             double learning_rate, double K, double overall_avg, int use_bias,
+                             int epoch_cap, double scale, double *rmse_hist, int64_t hist_cap,
+                             int64_t *n_hist);
+
 /* ALS shards exactly: every rank holds full replicas of u, v and both run-length views,
  * solves a contiguous slice of the rows of each half-epoch and the slices are all-gathered
  * (RCCL ncclAllGather over xGMI) -- same arguments and same result as mfx_als_wrmf

@@ -76,6 +76,9 @@ SIGNATURES = {
     "mfx_comm_destroy": (C.c_int, []),
     "mfx_comm_barrier": (C.c_int, []),
     "mfx_comm_allreduce_max": (C.c_int, [_dp]),
+    "mfx_sgd_run_funk_sharded": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double,
+                                           C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, _dp,
+                                           C.c_int64, _lp]),
     "mfx_sgd_run_kmf_sharded": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double,
                                           C.c_double, C.c_double, C.c_double, _dp, _dp]),
 }

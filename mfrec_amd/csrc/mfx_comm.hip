@@ -22,6 +22,15 @@ int plan_ni(mfx_sgd_plan *p);
 int plan_k(mfx_sgd_plan *p);
 int plan_start_buffers(mfx_sgd_plan *p, double **U_start, double **ib_start);
 int plan_prepare_nk(mfx_sgd_plan *p);
+struct FunkHooks {
+    int (*pre)(void *ctx, double *uf, int ni);
+    int (*post)(void *ctx, double *uf, int ni);
+    int (*global_se)(void *ctx, double *se, double *nnz);
+    void *ctx;
+};
+int funk_core(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_init, double lr,
+              double K, double mu, int use_bias, int upd_u, int upd_i, int epoch_cap,
+              double *rmse_hist, int64_t hist_cap, int64_t *n_hist, const FunkHooks *hk);
 }  // namespace mfx
 
 namespace {
@@ -204,6 +213,66 @@ int mfx_comm_allreduce_max(double *value)
     MFX_HIP(hipMemcpyAsync(value, g_token, sizeof(double), hipMemcpyDeviceToHost, mfx::stream()));
     MFX_HIP(hipStreamSynchronize(mfx::stream()));
     return MFX_OK;
+}
+
+// ---- user-sharded Funk pass: per feature-epoch all-reduce of the item-side vector U[f,:] ----
+namespace {
+struct FunkShard {
+    double scale;
+    double *start;     // [ni] snapshot of U[f,:] before the epoch
+    double *pair;      // device [2]: {se, nnz} for the global RMSE
+};
+int funk_pre(void *vc, double *uf, int ni)
+{
+    if (!g_comm) return MFX_OK;
+    FunkShard *c = (FunkShard *)vc;
+    MFX_HIP(hipMemcpyAsync(c->start, uf, (size_t)ni * sizeof(double), hipMemcpyDeviceToDevice, mfx::stream()));
+    return MFX_OK;
+}
+int funk_post(void *vc, double *uf, int ni)
+{
+    if (!g_comm) return MFX_OK;
+    FunkShard *c = (FunkShard *)vc;
+    hipStream_t s = mfx::stream();
+    hipLaunchKernelGGL(k_sub, dim3(grid_for(ni)), dim3(256), 0, s, uf, c->start, (size_t)ni);
+    MFX_NCCL(R.AllReduce(uf, uf, (size_t)ni, ncclFloat64, ncclSum, g_comm, s));
+    hipLaunchKernelGGL(k_combine, dim3(grid_for(ni)), dim3(256), 0, s, uf, c->start, c->scale, (size_t)ni);
+    MFX_HIP(hipGetLastError());
+    return MFX_OK;
+}
+int funk_global_se(void *vc, double *se, double *nnz)
+{
+    if (!g_comm) return MFX_OK;
+    FunkShard *c = (FunkShard *)vc;
+    hipStream_t s = mfx::stream();
+    double h[2] = {*se, *nnz};
+    MFX_HIP(hipMemcpyAsync(c->pair, h, sizeof(h), hipMemcpyHostToDevice, s));
+    MFX_NCCL(R.AllReduce(c->pair, c->pair, 2, ncclFloat64, ncclSum, g_comm, s));
+    MFX_HIP(hipMemcpyAsync(h, c->pair, sizeof(h), hipMemcpyDeviceToHost, s));
+    MFX_HIP(hipStreamSynchronize(s));
+    *se = h[0];
+    *nnz = h[1];
+    return MFX_OK;
+}
+}  // namespace
+
+int mfx_sgd_run_funk_sharded(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_init,
+                             double lr, double K, double mu, int use_bias, int epoch_cap,
+                             double scale, double *rmse_hist, int64_t hist_cap, int64_t *n_hist)
+{
+    if (!p) return mfx::fail(MFX_E_ARG, "mfx_sgd_run_funk_sharded: NULL plan");
+    if (g_world > 1 && !g_comm) return mfx::fail(MFX_E_STATE, "mfx_comm_init has not been called");
+    FunkShard c{scale, nullptr, nullptr};
+    if (g_comm) {
+        MFX_HIP(hipMalloc((void **)&c.start, (size_t)mfx::plan_ni(p) * sizeof(double)));
+        MFX_HIP(hipMalloc((void **)&c.pair, 2 * sizeof(double)));
+    }
+    mfx::FunkHooks hk{funk_pre, funk_post, funk_global_se, &c};
+    int rc = mfx::funk_core(p, min_epochs, min_improvement, f_init, lr, K, mu, use_bias, 1, 1, epoch_cap,
+                            rmse_hist, hist_cap, n_hist, &hk);
+    if (c.start) (void)hipFree(c.start);
+    if (c.pair) (void)hipFree(c.pair);
+    return rc;
 }
 
 int mfx_sgd_run_kmf_sharded(mfx_sgd_plan *p, int mode, int nbr_epochs, double lr, double Ku,

@@ -670,9 +670,22 @@ static int enqueue_k2_epoch(mfx_sgd_plan *p, const K2Params &P)
     return enqueue_reduce(p, p->k2_waves);
 }
 
-int mfx_sgd_run_funk(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_init,
-                     double lr, double K, double mu, int use_bias, int upd_u, int upd_i,
-                     int epoch_cap, double *rmse_hist, int64_t hist_cap, int64_t *n_hist)
+}  // extern "C"
+
+namespace mfx {
+// hooks of the user-sharded Funk pass (mfx_comm.hip): snapshot / combine the item-side feature
+// vector around every epoch and make the squared error global, so that every rank takes the
+// same decision in the data-dependent stopping rule
+struct FunkHooks {
+    int (*pre)(void *ctx, double *uf, int ni);
+    int (*post)(void *ctx, double *uf, int ni);
+    int (*global_se)(void *ctx, double *se, double *nnz);
+    void *ctx;
+};
+
+int funk_core(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_init, double lr,
+              double K, double mu, int use_bias, int upd_u, int upd_i, int epoch_cap,
+              double *rmse_hist, int64_t hist_cap, int64_t *n_hist, const FunkHooks *hk)
 {
     int rc = check_plan(p, "mfx_sgd_run_funk");
     if (rc) return rc;
@@ -735,16 +748,19 @@ int mfx_sgd_run_funk(mfx_sgd_plan *p, int min_epochs, double min_improvement, do
         while (epoch < min_epochs || rmse <= rmse_last - min_improvement) {
             if (epoch_cap > 0 && epoch >= epoch_cap) break;
             rmse_last = rmse;
+            if (hk && (rc = hk->pre(hk->ctx, dyn.uf, p->ni))) return rc;
             MFX_HIP(hipMemsetAsync(p->d_counter, 0, sizeof(int), stream()));
             if (graph) MFX_HIP(hipGraphLaunch(p->graph2, stream()));
             else {
                 rc = enqueue_k2_epoch(p, P);
                 if (rc) return rc;
             }
-            double se = 0.0;
+            if (hk && (rc = hk->post(hk->ctx, dyn.uf, p->ni))) return rc;
+            double se = 0.0, nn = (double)p->nnz;
             MFX_HIP(hipMemcpyAsync(&se, p->d_se_epoch, sizeof(double), hipMemcpyDeviceToHost, stream()));
             MFX_HIP(hipStreamSynchronize(stream()));
-            rmse = sqrt(se / (double)p->nnz);
+            if (hk && (rc = hk->global_se(hk->ctx, &se, &nn))) return rc;
+            rmse = sqrt(se / nn);
             if (rmse_hist && nh < hist_cap) rmse_hist[nh] = rmse;
             ++nh;
             ++epoch;
@@ -755,6 +771,18 @@ int mfx_sgd_run_funk(mfx_sgd_plan *p, int min_epochs, double min_improvement, do
     MFX_HIP(hipStreamSynchronize(stream()));
     if (n_hist) *n_hist = nh;
     return MFX_OK;
+}
+
+}  // namespace mfx
+
+extern "C" {
+
+int mfx_sgd_run_funk(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_init,
+                     double lr, double K, double mu, int use_bias, int upd_u, int upd_i,
+                     int epoch_cap, double *rmse_hist, int64_t hist_cap, int64_t *n_hist)
+{
+    return mfx::funk_core(p, min_epochs, min_improvement, f_init, lr, K, mu, use_bias, upd_u, upd_i,
+                          epoch_cap, rmse_hist, hist_cap, n_hist, nullptr);
 }
 
 int mfx_sgd_run_learned_bias(mfx_sgd_plan *p, int min_epochs, double min_improvement,

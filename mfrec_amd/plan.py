@@ -96,6 +96,16 @@ class SgdPlan(object):
             float(overall_avg), int(epoch_cap), S.f64(hist, "hist", 1), hist.shape[0], C.byref(n)))
         return hist[:min(n.value, hist.shape[0])]
 
+    def run_funk_sharded(self, min_epochs, min_improvement, f_init, learning_rate, K, scale,
+                         overall_avg=1.0, use_bias=False, epoch_cap=0):
+        hist = np.zeros(max(1, int(min_epochs)) * self.k * 4 + 1024)
+        n = C.c_int64(0)
+        S.check(S.lib().mfx_sgd_run_funk_sharded(
+            self._h, int(min_epochs), float(min_improvement), float(f_init), float(learning_rate),
+            float(K), float(overall_avg), int(bool(use_bias)), int(epoch_cap), float(scale),
+            S.f64(hist, "hist", 1), hist.shape[0], C.byref(n)))
+        return hist[:min(n.value, hist.shape[0])]
+
     def run_kmf_sharded(self, mode, nbr_epochs, learning_rate, K_users, K_items, K_bias, scale):
         rm, se = np.zeros(max(int(nbr_epochs), 1)), np.zeros(max(int(nbr_epochs), 1))
         S.check(S.lib().mfx_sgd_run_kmf_sharded(self._h, int(mode), int(nbr_epochs),

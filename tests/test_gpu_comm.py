@@ -71,3 +71,40 @@ def test_forced_single_rank_als_allgather():
         S.check(S.lib().mfx_comm_destroy())
         del os.environ["MFX_FORCE_COMM"]
     assert np.array_equal(u, u2) and np.array_equal(v, v2)
+
+
+def test_forced_single_rank_funk_sharded_matches_simulation():
+    """Sharded Funk pass with a 1-rank communicator: the per-feature-epoch delta / all-reduce /
+    combine arithmetic must equal its CPU simulation (oracle epoch + the same combine)."""
+    from mfrec_amd import _shim as S
+    from mfrec_amd.plan import SgdPlan
+    from mfrec_amd.sharding import combine
+    from oracle import oracle as O
+    S.init(0)
+    nu, ni, k, E = 300, 200, 5, 3
+    rs = np.random.RandomState(4)
+    cells = rs.permutation(nu * ni)[:8000]                       # no duplicate (user, item) pairs
+    idx = np.stack([cells % nu, cells // nu], 1).astype(np.int32)
+    r = rs.randint(1, 6, len(cells)).astype(np.float64)
+    os.environ["MFX_FORCE_COMM"] = "1"
+    try:
+        buf = C.create_string_buffer(S.UNIQUE_ID_BYTES)
+        S.check(S.lib().mfx_comm_unique_id(buf))
+        S.check(S.lib().mfx_comm_init(0, 1, buf.raw))
+        u, v = synth.init_const(k, ni), synth.init_const(k, nu)
+        with SgdPlan(idx, r, nu, ni, k) as p:
+            p.set_factors(u, v)
+            hist = p.run_funk_sharded(E, 1e9, 0.1, 0.01, 0.05, scale=1.0)
+            p.get_factors(u, v)
+    finally:
+        S.check(S.lib().mfx_comm_destroy())
+        del os.environ["MFX_FORCE_COMM"]
+    u2, v2, cache, h2 = synth.init_const(k, ni), synth.init_const(k, nu), np.zeros(nu * ni), []
+    for f in range(k):
+        for _ in range(E):
+            start = u2[f].copy()
+            h2.append(O.estimator_subloop(f, 1, 0.0, k, 0.1, 0.01, 0.05, u2, v2, idx, r, cache, nu, ni))
+            u2[f] = combine(start, u2[f] - start, 1.0)
+        O.predictor_subloop(f, 1, k, 0.1, u2, v2, idx, r, cache, nu, ni)
+    assert np.array_equal(u, u2) and np.array_equal(v, v2)
+    np.testing.assert_allclose(hist, h2, rtol=1e-12)

@@ -268,3 +268,51 @@ def test_funk_dense_cache_family_bitexact(golden):
         G.predictor_subloop(f, 1, k, init, u, v, idx, r, c, 60, 40)
     np.testing.assert_allclose(sub, g["out_sub_rmse"], rtol=1e-12)
     eq(u, g["out_sub_u"]); eq(v, g["out_sub_v"]); eq(c, g["out_sub_cache"])
+
+
+def test_plan_reuse_param_change_and_family_switch():
+    """One resident plan: linear epochs, then different hyper-parameters (graph re-capture),
+    then logistic, then Funk passes on the same factors, then linear again -- every step must
+    continue exactly where the oracle continues (layout switches [n,k] <-> [k,n] included)."""
+    from mfrec_amd.plan import SgdPlan
+    from oracle import oracle as O
+    nu, ni, nnz, k = 700, 500, 30000, 24
+    idx, r = synth.make_ratings(nu, ni, nnz, seed=31)
+    u, v, ib, ub = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2), np.zeros(ni), np.zeros(nu)
+    u2, v2, ib2, ub2 = u.copy(), v.copy(), ib.copy(), ub.copy()
+    with SgdPlan(idx, r, nu, ni, k) as p:
+        p.set_factors(u, v, ib, ub)
+        p.run_kmf(0, 2, 0.01, 0.1, 0.1, 0.007)
+        p.run_kmf(0, 1, 0.02, 0.05, 0.2, 0.0)            # new parameters -> new graph
+        p.run_kmf(0, 1, 0.01, 0.1, 0.1, 0.007, 1, 0)     # gates
+        p.run_funk(2, 1e9, 0.1, 0.001, 0.05)             # [n,k] -> [k,n], Funk on the same factors
+        p.run_kmf(0, 1, 0.01, 0.1, 0.1, 0.007)           # and back
+        p.get_factors(u, v, ib, ub)
+    a = (0.1, )
+    O.train_linear_kernel(2, k, 0.1, 0.01, 0, 0, 0.1, 0.1, 0.007, 0.0, u2, v2, idx, r, ib2, ub2)
+    O.train_linear_kernel(1, k, 0.1, 0.02, 0, 0, 0.05, 0.2, 0.0, 0.0, u2, v2, idx, r, ib2, ub2)
+    O.train_linear_kernel(1, k, 0.1, 0.01, 0, 0, 0.1, 0.1, 0.007, 0.0, u2, v2, idx, r, ib2, ub2, 1, 0)
+    O.estimator_loop_without_bias(2, 2, 1e9, k, 0.1, 0.001, 0.05, u2, v2, idx, r, nu, ni)
+    O.train_linear_kernel(1, k, 0.1, 0.01, 0, 0, 0.1, 0.1, 0.007, 0.0, u2, v2, idx, r, ib2, ub2)
+    eq(u, u2); eq(v, v2); eq(ib, ib2); eq(ub, ub2)
+
+
+def test_many_one_shot_calls_do_not_leak_or_drift():
+    from mfrec_amd import _shim as S
+    from mfrec_amd.lib import kmf_train as K
+    nu, ni, nnz, k = 300, 200, 5000, 16
+    idx, r = synth.make_ratings(nu, ni, nnz, seed=9)
+    u0, v0 = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
+    first = None
+    for _ in range(40):
+        u, v, ib, ub = u0.copy(), v0.copy(), np.zeros(ni), np.zeros(nu)
+        K.train_linear_kernel(2, k, 0.1, 0.01, 0, 0, 0.1, 0.1, 0.007, 0.0, u, v, idx, r, ib, ub)
+        if first is None:
+            first = (u.copy(), v.copy())
+        assert np.array_equal(u, first[0]) and np.array_equal(v, first[1])
+    # a failing call leaves a message and does not poison the next one
+    with pytest.raises(ValueError):
+        K.train_linear_kernel(1, k, 0.1, 0.01, 0, 0, 0.1, 0.1, 0.007, 0.0, u, v,
+                              np.array([[nu, 0]], dtype=np.int32), np.array([1.0]), ib, ub)
+    assert "outside" in S.last_error()
+    K.train_linear_kernel(1, k, 0.1, 0.01, 0, 0, 0.1, 0.1, 0.007, 0.0, u, v, idx, r, ib, ub)

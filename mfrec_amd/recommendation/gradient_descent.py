@@ -72,3 +72,25 @@ class GDRecommender(MFRecommender):
     def predict_rating_with_bias(self, item_index, user_index):               # :637-648
         s = np.dot(self.svd_u[:, item_index], self.svd_v[:, user_index])
         return s + self.overall_bias + (self.items_bias[item_index] + self.users_bias[user_index])
+
+    def _retrain(self, sel, ratings_index, ratings, update_users, update_items, verbose):
+        if self.items_bias is None or self.users_bias is None:
+            self.compute_overall_avg(); self.compute_items_bias_bk(); self.compute_users_bias_bk()
+        _kernels.estimator_loop_with_bias_dev(
+            self.min_epochs, self.max_epochs, self.min_improvement, self.dimensionality,
+            self.feature_init, self.learning_rate, self.learning_rate_users,
+            self.learning_rate_items, self.K, self.overall_bias, self.svd_u, self.svd_v,
+            np.ascontiguousarray(ratings_index[sel, :]), np.ascontiguousarray(ratings[sel]),
+            self.items_bias, self.users_bias, self.nbr_users, self.nbr_items, update_users,
+            update_items, int(verbose))
+
+    def retrain_user(self, user_index, ratings_index, ratings, verbose=False):
+        """Folding-in (gradient_descent.py:879-891): Funk passes with gates (1, 0) on this user's
+        ratings only."""
+        self.init_user_features(user_index)
+        self._retrain(np.where(ratings_index[:, 0] == user_index)[0], ratings_index, ratings, 1, 0, verbose)
+
+    def retrain_item(self, item_index, ratings_index, ratings, verbose=False):
+        """gradient_descent.py:894-905: gates (0, 1)."""
+        self.init_item_features(item_index)
+        self._retrain(np.where(ratings_index[:, 1] == item_index)[0], ratings_index, ratings, 0, 1, verbose)

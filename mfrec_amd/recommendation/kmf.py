@@ -66,6 +66,7 @@ class KMFRecommender(MFRecommender):
                      kernel="train_logistic_kernel"):
         """Folding-in (kmf.py:120-131): only this user's row is updated (gates 1, 0)."""
         sel = np.where(ratings_index[:, 0] == user_index)[0]
+        self.init_user_features(user_index)
         getattr(_kernels, kernel)(self.nbr_epochs, self.dimensionality, self.feature_init,
                                   self.learning_rate, self.learning_rate_users,
                                   self.learning_rate_items, self.K_users, self.K_items, self.K_bias,
@@ -73,3 +74,16 @@ class KMFRecommender(MFRecommender):
                                   np.ascontiguousarray(ratings_index[sel, :]),
                                   np.ascontiguousarray(ratings[sel]), self.items_bias,
                                   self.users_bias, 1, 0, int(verbose))
+
+    def retrain_item(self, item_index, ratings_index, ratings, verbose=False,
+                     kernel="train_logistic_kernel"):
+        """Folding-in of an item (kmf.py:134-146): only this item's row is updated (gates 0, 1)."""
+        sel = np.where(ratings_index[:, 1] == item_index)[0]
+        self.init_item_features(item_index)
+        getattr(_kernels, kernel)(self.nbr_epochs, self.dimensionality, self.feature_init,
+                                  self.learning_rate, self.learning_rate_users,
+                                  self.learning_rate_items, self.K_users, self.K_items, self.K_bias,
+                                  self.overall_bias, self.svd_u, self.svd_v,
+                                  np.ascontiguousarray(ratings_index[sel, :]),
+                                  np.ascontiguousarray(ratings[sel]), self.items_bias,
+                                  self.users_bias, 0, 1, int(verbose))

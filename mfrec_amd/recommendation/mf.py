@@ -45,6 +45,67 @@ class MFRecommender(BaseRecommender):
         self.svd_u = np.random.normal(mean, std, [self.dimensionality, self.nbr_items])
         self.svd_v = np.random.normal(mean, std, [self.dimensionality, self.nbr_users])
 
+    def init_user_features(self, user_index, mean=0.0, std=0.1):           # mf.py:136-137
+        self.svd_v[:, user_index] = np.random.normal(mean, std, self.dimensionality)
+
+    def init_item_features(self, item_index, mean=0.0, std=0.1):           # mf.py:140-141
+        self.svd_u[:, item_index] = np.random.normal(mean, std, self.dimensionality)
+
+    def _grow(self, users=0, items=0):
+        """One more user / item column in the model (folding-in: the ratings matrix is not
+        touched, as in gradient_descent.py:908-929 / kmf.py:149-169)."""
+        k = self.dimensionality
+        if users:
+            self.svd_v = np.ascontiguousarray(np.hstack([self.svd_v, np.zeros((k, users))]))
+            if self.users_bias is not None:
+                self.users_bias = np.concatenate([self.users_bias, np.zeros(users)])
+            self._nbr_users += users
+        if items:
+            self.svd_u = np.ascontiguousarray(np.hstack([self.svd_u, np.zeros((k, items))]))
+            if self.items_bias is not None:
+                self.items_bias = np.concatenate([self.items_bias, np.zeros(items)])
+            self._nbr_items += items
+
+    def add_user(self, user_label, users_ratings_index, users_ratings):
+        """Fold a new user in: returns its index.  users_ratings_index = item ids."""
+        items = np.asarray(users_ratings_index)
+        vals = np.asarray(users_ratings, dtype=np.float64)
+        if items.shape[0] != vals.shape[0]:
+            from .base import Error
+            raise Error("The index and the ratings array must be the same size")
+        self._grow(users=1)
+        new_id = self._nbr_users - 1
+        idx = np.zeros([vals.shape[0], 2], dtype=np.int32)
+        idx[:, 0] = new_id
+        idx[:, 1] = items
+        self.retrain_user(new_id, idx, vals)
+        return new_id
+
+    def add_item(self, item_label, items_ratings_index, items_ratings):
+        """Fold a new item in: returns its index.  items_ratings_index = user ids."""
+        users = np.asarray(items_ratings_index)
+        vals = np.asarray(items_ratings, dtype=np.float64)
+        if users.shape[0] != vals.shape[0]:
+            from .base import Error
+            raise Error("The index and the ratings array must be the same size")
+        self._grow(items=1)
+        new_id = self._nbr_items - 1
+        idx = np.zeros([vals.shape[0], 2], dtype=np.int32)
+        idx[:, 0] = users
+        idx[:, 1] = new_id
+        self.retrain_item(new_id, idx, vals)
+        return new_id
+
+    def find_recommended_items(self, user_index, nbr_recommendations=5, predictor="predict"):
+        """Top-N items for a user by predicted rating (mf.py:144-193), one batched GPU pass."""
+        from .metrics import predict_batch
+        idx = np.zeros([self.nbr_items, 2], dtype=np.int32)
+        idx[:, 0] = user_index
+        idx[:, 1] = np.arange(self.nbr_items)
+        pred, _ = predict_batch(self, idx, predictor)
+        order = np.argsort(-pred, kind="stable")[:nbr_recommendations]
+        return [(int(i), float(pred[i])) for i in order]
+
     def init_feature_const(self):
         """zeros + feature_init (gradient_descent.py:524-525, wrmf.py:92-93)."""
         self.svd_v = np.zeros([self.dimensionality, self.nbr_users]) + self.feature_init

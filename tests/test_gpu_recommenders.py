@@ -102,3 +102,25 @@ def test_unknown_parameter_raises():
     from mfrec_amd.recommendation import Error, GDRecommender
     with pytest.raises(Error, match="Wrong parameters"):
         GDRecommender(4, 4, {"no_such_parameter": 1})
+
+
+def test_folding_in_and_top_n():
+    """retrain_user / add_user (update gates) and the batched top-N."""
+    from mfrec_amd.recommendation import KMFRecommender
+    nu, ni, k = 120, 90, 8
+    R = _fill(KMFRecommender(nu, ni, {"nbr_epochs": 5, "nbr_features": k}), nu, ni, 3000, 2)
+    np.random.seed(1)
+    R.train(kernel="train_linear_kernel")
+    u_before, v_before = R.svd_u.copy(), R.svd_v.copy()
+    items = np.array([3, 10, 20, 33], dtype=np.int32)
+    new = R.add_user("someone", items, np.array([5.0, 4.0, 1.0, 2.0]))
+    assert new == nu and R.svd_v.shape == (k, nu + 1) and R.nbr_users == nu + 1
+    assert np.array_equal(R.svd_u, u_before)                       # items untouched (gate 0)
+    assert np.array_equal(R.svd_v[:, :nu], v_before)               # other users untouched
+    assert np.any(R.svd_v[:, nu] != 0.0)
+    top = R.find_recommended_items(new, 5, "predict_linear")
+    scores = [R.predict_linear(i, new) for i in range(ni)]
+    assert [t[0] for t in top] == list(np.argsort(-np.array(scores), kind="stable")[:5])
+    new_item = R.add_item("thing", np.array([1, 2, 3], dtype=np.int32), np.array([4.0, 4.0, 5.0]))
+    assert new_item == ni and R.svd_u.shape == (k, ni + 1)
+    assert np.array_equal(R.svd_v[:, :nu], v_before)

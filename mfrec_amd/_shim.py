@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmfx.so")
+# MFX_LIB: diagnostic builds only (e.g. libmfx_diag.so); the product is always libmfx.so
+LIB_PATH = os.environ.get("MFX_LIB") or os.path.join(_HERE, "libmfx.so")
 
 MFX_OK, MFX_E_ARG, MFX_E_RANGE, MFX_E_NOMEM, MFX_E_HIP, MFX_E_RCCL, MFX_E_SINGULAR, MFX_E_STATE = \
     0, -1, -2, -3, -4, -5, -6, -7

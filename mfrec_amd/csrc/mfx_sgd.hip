@@ -467,7 +467,7 @@ mfx_sgd_plan *mfx_sgd_plan_create(const int32_t *idx, const double *r, int64_t n
             // slots are per launched wave (blocks are whole)
             p->k1_wave_off[l + 1] = p->k1_wave_off[l] +
                                     ceil_div(ceil_div(c, (int64_t)p->batch), (int64_t)kWaves) * kWaves;
-            p->k2_wave_off[l + 1] = p->k2_wave_off[l] + ceil_div(c, (int64_t)256) * 4;
+            p->k2_wave_off[l + 1] = p->k2_wave_off[l] + ceil_div(c, (int64_t)kK2Block) * (kK2Block / 64);
         }
         // launch segments: big levels one launch each; runs of small levels -> tail kernel
         {
@@ -658,8 +658,8 @@ static int enqueue_k2_epoch(mfx_sgd_plan *p, const K2Params &P)
         if (!sg.tail) {
             const int64_t start = p->level_off[sg.l0];
             const int count = (int)(p->level_off[sg.l0 + 1] - start);
-            hipLaunchKernelGGL(k2_level, dim3(ceil_div(count, 256)), dim3(256), 0, stream(), P, start,
-                               count, p->k2_wave_off[sg.l0]);
+            hipLaunchKernelGGL(k2_level, dim3(ceil_div(count, kK2Block)), dim3(kK2Block), 0, stream(), P,
+                               start, count, p->k2_wave_off[sg.l0]);
         } else {
             hipLaunchKernelGGL(k2_tail, dim3(1), dim3(kTail2), 0, stream(), P,
                                (const int64_t *)p->d_level_off, (const int64_t *)p->d_k2_wave_off,

@@ -406,15 +406,19 @@ __device__ __forceinline__ double k2_one(const K2Params &P, double *uf, double *
     return e2;
 }
 
-__global__ __launch_bounds__(256) void k2_level(K2Params P, int64_t start, int count,
-                                                int64_t wave_off)
+#ifndef MFX_K2_BLOCK
+#define MFX_K2_BLOCK 64
+#endif
+static constexpr int kK2Block = MFX_K2_BLOCK;    // threads per block of the Funk level kernel
+__global__ __launch_bounds__(kK2Block) void k2_level(K2Params P, int64_t start, int count,
+                                                     int64_t wave_off)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int t = blockIdx.x * kK2Block + threadIdx.x;
     double *const uf = P.dyn->uf, *const vf = P.dyn->vf;
     const double e2 = k2_one(P, uf, vf, P.dyn->trail, start, t, count);
     const double wsum = wave_sum_fixed(e2);
     if ((threadIdx.x & 63) == 0)
-        P.se_partial[wave_off + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)] = wsum;
+        P.se_partial[wave_off + (int64_t)blockIdx.x * (kK2Block / 64) + (threadIdx.x >> 6)] = wsum;
 }
 
 // run of small levels (each <= 1024 ratings) by one 1024-thread workgroup
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(kTail2) void k2_tail(K2Params P, const int64_t *lev
         const int64_t start = level_off[l];
         const int count = (int)(level_off[l + 1] - start);
         const int64_t woff = wave_off[l];
-        const int nslots = (int)(wave_off[l + 1] - woff);        // = 4 * ceil(count / 256)
+        const int nslots = (int)(wave_off[l + 1] - woff);        // one slot per launched wave of the level
         const double e2 = k2_one(P, uf, vf, trail, start, (int)threadIdx.x, count);
         const double wsum = wave_sum_fixed(e2);
         if ((threadIdx.x & 63) == 0 && wid < nslots) P.se_partial[woff + wid] = wsum;

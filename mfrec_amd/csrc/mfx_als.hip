@@ -160,8 +160,11 @@ __host__ __device__ constexpr int als_row_off(int r)
 
 // waves per SIMD (= workgroups per CU) the register allocation must leave room for: LDS admits
 // 2 workgroups at k = 128 and more below
-template <int NT>
-__global__ __launch_bounds__(256, (NT >= 5 ? 2 : 3)) void k_als_rows2(const double *__restrict__ Y, int k,
+// NW = waves per workgroup: 4 for k > 32; ONE wave per row for k <= 32, where a 256-thread
+// workgroup would idle through the 16x16 / 32x32 factorisation (rows are then independent
+// single-wave workgroups: barriers degenerate to wave barriers, many rows share a CU)
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 1 ? 2 : (NT >= 5 ? 2 : 3))) void k_als_rows2(const double *__restrict__ Y, int k,
                                                    const double *__restrict__ G,
                                                    const int64_t *__restrict__ off,
                                                    const int32_t *__restrict__ col, double c_pos,
@@ -174,8 +177,9 @@ __global__ __launch_bounds__(256, (NT >= 5 ? 2 : 3)) void k_als_rows2(const doub
     // MFMA operand reads of the panels); 77 KB instead of 134 KB at k = 128, so two
     // workgroups share a CU and one's Cholesky overlaps the other's gather + MFMA phase.
     constexpr int NTT = NT * (NT + 1) / 2;           // lower-triangle tiles
-    constexpr int TPW = (NTT + 3) / 4;
-    constexpr int PF = CH2 * KP / 256;               // gathered doubles per thread per chunk
+    constexpr int TPW = (NTT + NW - 1) / NW;
+    constexpr int NTHR = 64 * NW;
+    constexpr int PF = CH2 * KP / NTHR;              // gathered doubles per thread per chunk
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int S = ych_stride(KP);
     constexpr int BORDER = als_row_off<NT>(KP);      // right-hand side row
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(256, (NT >= 5 ? 2 : 3)) void k_als_rows2(const doub
     const int span = (int)(off[j + 1] - start);
     double *xrow = X + (size_t)j * k;
     if (span == 0) {                                 // b = 0  =>  x = 0 (als_implicit.pyx:298-302)
-        for (int f = tid; f < k; f += 256) xrow[f] = 0.0;
+        for (int f = tid; f < k; f += NTHR) xrow[f] = 0.0;
         return;
     }
     if (tid == 0) *bad = 0;
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(256, (NT >= 5 ? 2 : 3)) void k_als_rows2(const doub
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         tI[t] = 0; tJ[t] = 0;
-        if (t * 4 + wid < NTT) tile_ij(t * 4 + wid, tI[t], tJ[t]);
+        if (t * NW + wid < NTT) tile_ij(t * NW + wid, tI[t], tJ[t]);
     }
     // accumulators start at G / c, so that A = c * acc needs no second pass over G (c != 0)
     const bool from_g = (c_pos != 0.0);
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(256, (NT >= 5 ? 2 : 3)) void k_als_rows2(const doub
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = tI[t] * 16 + (lane >> 4) + 4 * q, c = tJ[t] * 16 + (lane & 15);
-            acc[t][q] = (from_g && t * 4 + wid < NTT) ? G[r * KP + c] * inv_c : 0.0;
+            acc[t][q] = (from_g && t * NW + wid < NTT) ? G[r * KP + c] * inv_c : 0.0;
         }
     }
     double bsum = 0.0;
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(256, (NT >= 5 ? 2 : 3)) void k_als_rows2(const doub
     double pre[PF];
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
-        const int e = tid + 256 * i, n = e / KP, f = e % KP;
+        const int e = tid + NTHR * i, n = e / KP, f = e % KP;
         const int id = cidx[n];
         pre[i] = (id >= 0 && f < k) ? Y[(size_t)id * k + f] : 0.0;
     }
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(256, (NT >= 5 ? 2 : 3)) void k_als_rows2(const doub
     for (int c = 0; c < nchunks; ++c) {
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
-            const int e = tid + 256 * i, n = e / KP, f = e % KP;
+            const int e = tid + NTHR * i, n = e / KP, f = e % KP;
             ych[n * S + f] = pre[i];
         }
         const int nb = ((c + 1) & 1) * CH2;
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(256, (NT >= 5 ? 2 : 3)) void k_als_rows2(const doub
         if (c + 1 < nchunks) {
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
-                const int e = tid + 256 * i, n = e / KP, f = e % KP;
+                const int e = tid + NTHR * i, n = e / KP, f = e % KP;
                 const int id = cidx[nb + n];
                 pre[i] = (id >= 0 && f < k) ? Y[(size_t)id * k + f] : 0.0;
             }
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(256, (NT >= 5 ? 2 : 3)) void k_als_rows2(const doub
             const double *base = ych + (n0 + (lane >> 4)) * S + (lane & 15);
 #pragma unroll
             for (int t = 0; t < TPW; ++t)
-                if (t * 4 + wid < NTT)
+                if (t * NW + wid < NTT)
                     acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(base[tI[t] * 16], base[tJ[t] * 16],
                                                                   acc[t], 0, 0, 0);
         }
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(256, (NT >= 5 ? 2 : 3)) void k_als_rows2(const doub
     // ---- A = G + c * acc + lambda I (identity on the padding), b as border row -----------
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-        if (t * 4 + wid < NTT) {
+        if (t * NW + wid < NTT) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int r = tI[t] * 16 + (lane >> 4) + 4 * q, c = tJ[t] * 16 + (lane & 15);
@@ -383,7 +387,15 @@ __global__ __launch_bounds__(256, (NT >= 5 ? 2 : 3)) void k_als_rows2(const doub
         {
             const int nt = NT - Jb - 1;              // trailing tile rows
             const int ntt = nt * (nt + 1) / 2;
-            if (wid == 0) {
+            if (NW == 1) {
+                for (int tt = 0; tt < ntt; ++tt) trailing_tile(Jb, tt);
+                if (ntt > 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    factor_diag(c0 + 16);
+                }
+            } else if (wid == 0) {
                 if (ntt > 0) {
                     trailing_tile(Jb, 0);            // tile (Jb+1, Jb+1) ...
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -392,7 +404,7 @@ __global__ __launch_bounds__(256, (NT >= 5 ? 2 : 3)) void k_als_rows2(const doub
                     factor_diag(c0 + 16);            // ... factored right away (look-ahead)
                 }
             } else {
-                for (int tt = wid; tt < ntt; tt += 3) trailing_tile(Jb, tt);
+                for (int tt = wid; tt < ntt; tt += NW - 1) trailing_tile(Jb, tt);
             }
         }
         __syncthreads();
@@ -469,12 +481,14 @@ __global__ __launch_bounds__(256) void k_transpose_als(const double *in, double 
 struct AlsKernels {
     void *gram;
     void *rows2;
+    int rows_waves;     // waves per workgroup of the row kernel
 };
 
 template <int NT>
 AlsKernels als_kernels_nt()
 {
-    return {(void *)k_gram_partial<NT>, (void *)k_als_rows2<NT>};
+    if constexpr (NT <= 2) return {(void *)k_gram_partial<NT>, (void *)k_als_rows2<NT, 1>, 1};
+    else return {(void *)k_gram_partial<NT>, (void *)k_als_rows2<NT, 4>, 4};
 }
 
 size_t rows2_lds_bytes(int KP)
@@ -562,7 +576,7 @@ int als_half(int k, int NT, const AlsKernels &K, const double *dY, int ny, doubl
             double *X_s = dX + (size_t)r0 * k;
             args[3] = &off_s;
             args[8] = &X_s;
-            MFX_HIP(hipLaunchKernel(rows_fn, dim3(n), dim3(256), args, lds, s));
+            MFX_HIP(hipLaunchKernel(rows_fn, dim3(n), dim3(64 * K.rows_waves), args, lds, s));
         }
         }
         if (gather) {

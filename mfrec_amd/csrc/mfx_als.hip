@@ -487,8 +487,14 @@ struct AlsKernels {
 template <int NT>
 AlsKernels als_kernels_nt()
 {
-    if constexpr (NT <= 2) return {(void *)k_gram_partial<NT>, (void *)k_als_rows2<NT, 1>, 1};
-    else return {(void *)k_gram_partial<NT>, (void *)k_als_rows2<NT, 4>, 4};
+    if constexpr (NT == 1) return {(void *)k_gram_partial<NT>, (void *)k_als_rows2<NT, 1>, 1};
+    else if constexpr (NT == 2) {
+        const char *e = getenv("MFX_ALS_NW");                 // tuning hook
+        const int nw = e ? atoi(e) : 2;
+        if (nw == 1) return {(void *)k_gram_partial<NT>, (void *)k_als_rows2<NT, 1>, 1};
+        if (nw == 4) return {(void *)k_gram_partial<NT>, (void *)k_als_rows2<NT, 4>, 4};
+        return {(void *)k_gram_partial<NT>, (void *)k_als_rows2<NT, 2>, 2};
+    } else return {(void *)k_gram_partial<NT>, (void *)k_als_rows2<NT, 4>, 4};
 }
 
 size_t rows2_lds_bytes(int KP)

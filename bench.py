@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--k", type=int, default=64)
     ap.add_argument("--order", choices=["shuffled", "user-major"], default="shuffled")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--storage", choices=["f64", "f32"], default="f64",
+                    help="f32 = NOT the reference's precision: rows stored as f32 (measured option only)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -130,7 +132,7 @@ def main():
         idx, r = synth.user_major(idx, r)
     u0 = synth.init_normal(k, ni, synth.SEED_INIT)
     v0 = synth.init_normal(k, nu, synth.SEED_INIT + 1 + rank)
-    plan = SgdPlan(idx, r, nu, ni, k)
+    plan = SgdPlan(idx, r, nu, ni, k, storage=a.storage)
     plan.set_factors(u0, v0, np.zeros(ni), np.zeros(nu))
     info = plan.info()
 
@@ -189,7 +191,9 @@ def main():
             "metric": "rating-updates/s per epoch at k=%d" % k, "value": value,
             "unit": "rating-updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": wall * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f64" if a.storage == "f64" else "f64 arithmetic on f32-stored rows (NOT the reference precision)",
+            "data": "synthetic",
             "config": {"workload": "%s: synthetic %dK users x %dK items, %dM ratings per GPU, "
                                    "k=%d, full-k SGD (train_linear_kernel), %s order, "
                                    "exact level schedule" % (

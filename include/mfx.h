@@ -154,6 +154,10 @@ void mfx_sgd_plan_destroy(mfx_sgd_plan *p);
  * [4]=ratings per wave batch, [5]=device bytes held, [6]=schedule build microseconds,
  * [7]=launches per epoch (Funk) */
 int mfx_sgd_plan_info(const mfx_sgd_plan *p, int64_t info[8]);
+/* Storage type of the factor rows inside the plan: 64 (default; exact) or 32 -- "f32 storage,
+ * f64 arithmetic" fast mode of the full-k kernels: rows are widened on load and rounded once on
+ * store.  NOT bit-exact (measured RMSE delta: DESIGN.md); single-GPU; call before set_factors. */
+int mfx_sgd_plan_set_storage(mfx_sgd_plan *p, int bits);
 int mfx_sgd_set_factors(mfx_sgd_plan *p, const double *u, const double *v,
                         const double *items_bias, const double *users_bias);
 int mfx_sgd_get_factors(mfx_sgd_plan *p, double *u, double *v, double *items_bias,

@@ -24,7 +24,8 @@ struct mfx_sgd_plan {
     int64_t *d_level_off = nullptr, *d_k1_wave_off = nullptr, *d_k2_wave_off = nullptr;
     int nu = 0, ni = 0, k = 0;
     int64_t n_levels = 0, max_level = 0;
-    int batch = 16, nt = 0;              // full-k kernel: ratings per wave, non-temporal row stores
+    int batch = 16;                      // full-k kernel: ratings per wave
+    int f32 = 0;                         // factor rows stored as f32 (fast mode, not exact)
     std::vector<int64_t> level_off;      // n_levels + 1
     std::vector<int64_t> k1_wave_off;    // per level: first se_partial slot (full-k kernels)
     std::vector<int64_t> k2_wave_off;    // per level (Funk kernels)
@@ -91,20 +92,28 @@ void drop_graph(mfx_sgd_plan *p)
     p->graph2 = nullptr;
 }
 
-int transpose(const double *in, double *out, int rows, int cols)
+template <typename TI, typename TO>
+int transpose(const TI *in, TO *out, int rows, int cols)
 {
     if (rows == 0 || cols == 0) return MFX_OK;
     dim3 grid(ceil_div(cols, 32), ceil_div(rows, 32));
-    hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, stream(), in, out, rows, cols);
+    hipLaunchKernelGGL((k_transpose<TI, TO>), grid, dim3(256), 0, stream(), in, out, rows, cols);
     MFX_HIP(hipGetLastError());
     return MFX_OK;
 }
 
+// [k][n] f64 (host layout) -> [n][k] rows in the plan's storage type, and back
 int to_nk(mfx_sgd_plan *p)
 {
     if (p->nk_current) return MFX_OK;
-    int rc = transpose(p->d_U_km, p->d_U_nk, p->k, p->ni);
-    if (!rc) rc = transpose(p->d_V_km, p->d_V_nk, p->k, p->nu);
+    int rc;
+    if (p->f32) {
+        rc = transpose(p->d_U_km, (float *)p->d_U_nk, p->k, p->ni);
+        if (!rc) rc = transpose(p->d_V_km, (float *)p->d_V_nk, p->k, p->nu);
+    } else {
+        rc = transpose(p->d_U_km, p->d_U_nk, p->k, p->ni);
+        if (!rc) rc = transpose(p->d_V_km, p->d_V_nk, p->k, p->nu);
+    }
     if (!rc) p->nk_current = true;
     return rc;
 }
@@ -112,8 +121,14 @@ int to_nk(mfx_sgd_plan *p)
 int to_km(mfx_sgd_plan *p)
 {
     if (p->km_current) return MFX_OK;
-    int rc = transpose(p->d_U_nk, p->d_U_km, p->ni, p->k);
-    if (!rc) rc = transpose(p->d_V_nk, p->d_V_km, p->nu, p->k);
+    int rc;
+    if (p->f32) {
+        rc = transpose((const float *)p->d_U_nk, p->d_U_km, p->ni, p->k);
+        if (!rc) rc = transpose((const float *)p->d_V_nk, p->d_V_km, p->nu, p->k);
+    } else {
+        rc = transpose((const double *)p->d_U_nk, p->d_U_km, p->ni, p->k);
+        if (!rc) rc = transpose((const double *)p->d_V_nk, p->d_V_km, p->nu, p->k);
+    }
     if (!rc) p->km_current = true;
     return rc;
 }
@@ -123,62 +138,40 @@ size_t k1_lds_bytes(int k, int batch)
     return (size_t)kWaves * batch * (size_t)k1_stride(k) * sizeof(double);
 }
 
-// pick the kernel instantiation for (k, mode, batch, nt)
-template <int MODE, int NT>
+// pick the kernel instantiation for (k, mode, batch, storage type)
+template <int MODE, typename TS, bool TAIL>
 void *k1_pick(int k, int batch)
 {
-    if (k <= 8) return (void *)k1_level<8, 1, 16, MODE, NT>;
-    if (k <= 16) return (void *)k1_level<16, 1, 16, MODE, NT>;
-    if (k <= 32) return (void *)k1_level<32, 1, 16, MODE, NT>;
+#define MFX_K1(KP, FPL, B) (TAIL ? (void *)k1_tail<KP, FPL, B, MODE, 0, TS> : (void *)k1_level<KP, FPL, B, MODE, 0, TS>)
+    if (k <= 8) return MFX_K1(8, 1, 16);
+    if (k <= 16) return MFX_K1(16, 1, 16);
+    if (k <= 32) return MFX_K1(32, 1, 16);
     if (k <= 64) {
-        if (batch == 16) return (void *)k1_level<64, 1, 16, MODE, NT>;
-        if (batch == 4) return (void *)k1_level<64, 1, 4, MODE, NT>;
-        return (void *)k1_level<64, 1, 8, MODE, NT>;
+        if (batch == 16) return MFX_K1(64, 1, 16);
+        if (batch == 4) return MFX_K1(64, 1, 4);
+        return MFX_K1(64, 1, 8);
     }
-    if (k <= 128) return (void *)k1_level<64, 2, 8, MODE, NT>;
-    if (k <= 256) return (void *)k1_level<64, 4, 4, MODE, NT>;
-    return (void *)k1_level<64, 8, 2, MODE, NT>;
+    if (k <= 128) return MFX_K1(64, 2, 8);
+    if (k <= 256) return MFX_K1(64, 4, 4);
+    return MFX_K1(64, 8, 2);
+#undef MFX_K1
 }
 
-template <int MODE, int NT>
-void *k1_pick_tail(int k, int batch)
+template <bool TAIL>
+void *k1_select(int k, int mode, int batch, int f32)
 {
-    if (k <= 8) return (void *)k1_tail<8, 1, 16, MODE, NT>;
-    if (k <= 16) return (void *)k1_tail<16, 1, 16, MODE, NT>;
-    if (k <= 32) return (void *)k1_tail<32, 1, 16, MODE, NT>;
-    if (k <= 64) {
-        if (batch == 16) return (void *)k1_tail<64, 1, 16, MODE, NT>;
-        if (batch == 4) return (void *)k1_tail<64, 1, 4, MODE, NT>;
-        return (void *)k1_tail<64, 1, 8, MODE, NT>;
-    }
-    if (k <= 128) return (void *)k1_tail<64, 2, 8, MODE, NT>;
-    if (k <= 256) return (void *)k1_tail<64, 4, 4, MODE, NT>;
-    return (void *)k1_tail<64, 8, 2, MODE, NT>;
-}
-
-void *k1_tail_kernel(int k, int mode, int batch, int nt)
-{
-    switch (mode * 2 + (nt ? 1 : 0)) {
-    case 0: return k1_pick_tail<K1_LINEAR, 0>(k, batch);
-    case 1: return k1_pick_tail<K1_LINEAR, 1>(k, batch);
-    case 2: return k1_pick_tail<K1_LOGISTIC, 0>(k, batch);
-    case 3: return k1_pick_tail<K1_LOGISTIC, 1>(k, batch);
-    case 4: return k1_pick_tail<K1_LEARNED, 0>(k, batch);
-    default: return k1_pick_tail<K1_LEARNED, 1>(k, batch);
+    switch (mode * 2 + (f32 ? 1 : 0)) {
+    case 0: return k1_pick<K1_LINEAR, double, TAIL>(k, batch);
+    case 1: return k1_pick<K1_LINEAR, float, TAIL>(k, batch);
+    case 2: return k1_pick<K1_LOGISTIC, double, TAIL>(k, batch);
+    case 3: return k1_pick<K1_LOGISTIC, float, TAIL>(k, batch);
+    case 4: return k1_pick<K1_LEARNED, double, TAIL>(k, batch);
+    default: return k1_pick<K1_LEARNED, float, TAIL>(k, batch);
     }
 }
 
-void *k1_kernel(int k, int mode, int batch, int nt)
-{
-    switch (mode * 2 + (nt ? 1 : 0)) {
-    case 0: return k1_pick<K1_LINEAR, 0>(k, batch);
-    case 1: return k1_pick<K1_LINEAR, 1>(k, batch);
-    case 2: return k1_pick<K1_LOGISTIC, 0>(k, batch);
-    case 3: return k1_pick<K1_LOGISTIC, 1>(k, batch);
-    case 4: return k1_pick<K1_LEARNED, 0>(k, batch);
-    default: return k1_pick<K1_LEARNED, 1>(k, batch);
-    }
-}
+void *k1_kernel(int k, int mode, int batch, int f32) { return k1_select<false>(k, mode, batch, f32); }
+void *k1_tail_kernel(int k, int mode, int batch, int f32) { return k1_select<true>(k, mode, batch, f32); }
 
 int env_int(const char *name, int dflt)
 {
@@ -215,8 +208,8 @@ int enqueue_reduce(mfx_sgd_plan *p, int64_t n_partials)
 int enqueue_k1_epoch(mfx_sgd_plan *p, int mode, const K1Params &P, std::vector<hipEvent_t> *ev)
 {
     const int batch = p->batch;
-    void *fn = k1_kernel(p->k, mode, batch, p->nt);
-    void *fn_tail = k1_tail_kernel(p->k, mode, batch, p->nt);
+    void *fn = k1_kernel(p->k, mode, batch, p->f32);
+    void *fn_tail = k1_tail_kernel(p->k, mode, batch, p->f32);
     const size_t lds = k1_lds_bytes(p->k, batch);
     const size_t lds_tail = lds / kWaves * kTailWaves;
     if (lds_tail > 64 * 1024)
@@ -359,6 +352,7 @@ int sgd_run_k1_hooked(mfx_sgd_plan *p, int mode, int epochs, double lr, double K
 {
     int rc = check_plan(p, "mfx_sgd_run_kmf_sharded");
     if (rc) return rc;
+    if (p->f32) return fail(MFX_E_STATE, "mfx_sgd_run_kmf_sharded: f32 row storage is single-GPU only");
     K1Params P = k1_params(p, lr, Ku, Ki, Kb, 1, 1);
     rc = run_k1_epochs(p, mode, epochs, P, [&](int ep) { return hook ? hook(p, ep, ctx) : MFX_OK; });
     if (rc) return rc;
@@ -403,7 +397,6 @@ mfx_sgd_plan *mfx_sgd_plan_create(const int32_t *idx, const double *r, int64_t n
     p->ni = ni;
     p->k = dim;
     p->batch = plan_batch(dim);
-    p->nt = env_int("MFX_K1_NT", 0) ? 1 : 0;
     auto bail = [&]() -> mfx_sgd_plan * {
         mfx_sgd_plan_destroy(p);
         return nullptr;
@@ -569,6 +562,15 @@ int mfx_sgd_plan_info(const mfx_sgd_plan *p, int64_t info[8])
     info[6] = p->sched_us;
     info[7] = (int64_t)p->segs2.size();
     (void)flaunches;
+    return MFX_OK;
+}
+
+int mfx_sgd_plan_set_storage(mfx_sgd_plan *p, int bits)
+{
+    if (!p || (bits != 64 && bits != 32)) return fail(MFX_E_ARG, "mfx_sgd_plan_set_storage: bits must be 64 or 32");
+    if (p->have_factors) return fail(MFX_E_STATE, "mfx_sgd_plan_set_storage: call before mfx_sgd_set_factors");
+    p->f32 = (bits == 32);
+    drop_graph(p);
     return MFX_OK;
 }
 

@@ -40,8 +40,8 @@ enum { K1_LINEAR = 0, K1_LOGISTIC = 1, K1_LEARNED = 2 };
 
 struct K1Params {
     const Rec *recs;
-    double *U;           // [ni][k] row-major
-    double *V;           // [nu][k]
+    void *U;             // [ni][k] row-major, element type TS (f64, or f32 in the fast mode)
+    void *V;             // [nu][k]
     double *ib;          // [ni]
     double *ub;          // [nu]
     double *se_partial;  // one slot per wave per epoch
@@ -105,7 +105,10 @@ __device__ __forceinline__ double wave_sum_fixed(double x)
 // block.  (With a branch around every store hipcc loses count of the outstanding memory
 // operations and emits s_waitcnt vmcnt(0) before each one: every store then waits for the
 // previous store's round trip -- measured 300 cycles per store instruction.)
-template <int KP, int FPL, int BATCH, int MODE, int NT, bool FULL>
+// TS = storage type of the factor rows: double (exact), or float ("f32 storage, f64
+// arithmetic" fast mode: rows are widened on load and rounded once on store -- NOT bit-exact,
+// measured RMSE delta in DESIGN.md)
+template <int KP, int FPL, int BATCH, int MODE, int NT, bool FULL, typename TS>
 __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cnt, int64_t base,
                                         int64_t slot, double *prod, int lane)
 {
@@ -131,8 +134,8 @@ __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cn
 
     // ---- gather both factor rows of every rating of the batch -------------------------
     double uval[NR][FPL], vval[NR][FPL];
-    const double *ur[NR];
-    const double *vr[NR];
+    TS *ur[NR];
+    TS *vr[NR];
 #pragma unroll
     for (int s = 0; s < NR; ++s) {
         int usr, itm;
@@ -143,8 +146,8 @@ __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cn
             usr = __shfl(rec.user, s * SPW + g, 64);
             itm = __shfl(rec.item, s * SPW + g, 64);
         }
-        ur[s] = P.U + (size_t)itm * k;
-        vr[s] = P.V + (size_t)usr * k;
+        ur[s] = (TS *)P.U + (size_t)itm * k;
+        vr[s] = (TS *)P.V + (size_t)usr * k;
     }
 #pragma unroll
     for (int j = 0; j < FPL; ++j) {
@@ -155,8 +158,8 @@ __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cn
 #pragma unroll
             for (int s = 0; s < NR; ++s) {
                 if (FULL || (s * SPW + g < cnt)) {
-                    uval[s][j] = ur[s][f];
-                    vval[s][j] = vr[s][f];
+                    uval[s][j] = (double)ur[s][f];
+                    vval[s][j] = (double)vr[s][f];
                 }
             }
         }
@@ -251,8 +254,8 @@ __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cn
                 for (int s = 0; s < NR; ++s) {
                     if (FULL || (s * SPW + g < cnt)) {
                         const double mf = uval[s][j], cf = vval[s][j];
-                        const_cast<double *>(ur[s])[f] = mf + P.lr * (gr[s] * cf - P.Ki * mf);
-                        const_cast<double *>(vr[s])[f] = cf + P.lr * (gr[s] * mf - P.Ku * cf);
+                        ur[s][f] = (TS)(mf + P.lr * (gr[s] * cf - P.Ki * mf));
+                        vr[s][f] = (TS)(cf + P.lr * (gr[s] * mf - P.Ku * cf));
                     }
                 }
             }
@@ -261,13 +264,13 @@ __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cn
             for (int s = 0; s < NR; ++s) {
                 if (FULL || (s * SPW + g < cnt)) {
                     const double mf = uval[s][j], cf = vval[s][j];
-                    const double un = mf + P.lr * (gr[s] * cf - P.Ki * mf);       // kmf_train.pyx:267-270
-                    const double vn = cf + P.lr * (gr[s] * mf - P.Ku * cf);
-                    double *up = const_cast<double *>(ur[s]) + f, *vp = const_cast<double *>(vr[s]) + f;
+                    const TS un = (TS)(mf + P.lr * (gr[s] * cf - P.Ki * mf));     // kmf_train.pyx:267-270
+                    const TS vn = (TS)(cf + P.lr * (gr[s] * mf - P.Ku * cf));
+                    TS *up = ur[s] + f, *vp = vr[s] + f;
                     if constexpr (NT == 1) {
                         if (FULL || P.upd_i) __builtin_nontemporal_store(un, up);
                         if (FULL || P.upd_u) __builtin_nontemporal_store(vn, vp);
-                    } else if constexpr (NT == 2) {        // write-through (sc1) 8-byte stores
+                    } else if constexpr (NT == 2) {        // write-through (sc1) stores
                         if (FULL || P.upd_i) __hip_atomic_store(up, un, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (FULL || P.upd_u) __hip_atomic_store(vp, vn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     } else if constexpr (NT == 3) {        // diagnostic: no row stores
@@ -291,7 +294,7 @@ __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cn
     if (lane == 0) P.se_partial[slot] = wsum;
 }
 
-template <int KP, int FPL, int BATCH, int MODE, int NT>
+template <int KP, int FPL, int BATCH, int MODE, int NT, typename TS = double>
 __global__ __launch_bounds__(kWaves * 64) void k1_level(K1Params P, int64_t start, int count,
                                                        int64_t wave_off)
 {
@@ -307,9 +310,9 @@ __global__ __launch_bounds__(kWaves * 64) void k1_level(K1Params P, int64_t star
     const int cnt = (count - base) < BATCH ? (int)(count - base) : BATCH;
     double *prod = lds + (size_t)wid * BATCH * k1_stride(P.k);
     if (cnt == BATCH && P.upd_u && P.upd_i)
-        k1_body<KP, FPL, BATCH, MODE, NT, true>(P, start, cnt, base, wave_off + wave_g, prod, lane);
+        k1_body<KP, FPL, BATCH, MODE, NT, true, TS>(P, start, cnt, base, wave_off + wave_g, prod, lane);
     else
-        k1_body<KP, FPL, BATCH, MODE, NT, false>(P, start, cnt, base, wave_off + wave_g, prod, lane);
+        k1_body<KP, FPL, BATCH, MODE, NT, false, TS>(P, start, cnt, base, wave_off + wave_g, prod, lane);
 }
 
 // Tail kernel: a run of consecutive SMALL levels (each <= kTailWaves*BATCH ratings) in ONE
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(kWaves * 64) void k1_level(K1Params P, int64_t star
 // chain of a few hot items/users with a handful of ratings each; a launch per level would
 // cost ~9 us for ~no work.
 static constexpr int kTailWaves = 16;
-template <int KP, int FPL, int BATCH, int MODE, int NT>
+template <int KP, int FPL, int BATCH, int MODE, int NT, typename TS = double>
 __global__ __launch_bounds__(kTailWaves * 64) void k1_tail(K1Params P, const int64_t *level_off,
                                                           const int64_t *wave_off, int l0, int l1)
 {
@@ -338,9 +341,9 @@ __global__ __launch_bounds__(kTailWaves * 64) void k1_tail(K1Params P, const int
             } else {
                 const int cnt = (count - base) < BATCH ? (count - base) : BATCH;
                 if (cnt == BATCH && P.upd_u && P.upd_i)
-                    k1_body<KP, FPL, BATCH, MODE, NT, true>(P, start, cnt, base, woff + wid, prod, lane);
+                    k1_body<KP, FPL, BATCH, MODE, NT, true, TS>(P, start, cnt, base, woff + wid, prod, lane);
                 else
-                    k1_body<KP, FPL, BATCH, MODE, NT, false>(P, start, cnt, base, woff + wid, prod, lane);
+                    k1_body<KP, FPL, BATCH, MODE, NT, false, TS>(P, start, cnt, base, woff + wid, prod, lane);
             }
         }
         __syncthreads();
@@ -503,21 +506,21 @@ __global__ void k_reduce_se2(const double *tmp, double *out, int *counter)
     }
 }
 
-// out[c][r] = in[r][c]; in is rows x cols row-major
-__global__ __launch_bounds__(256) void k_transpose(const double *in, double *out, int rows,
-                                                   int cols)
+// out[c][r] = in[r][c]; in is rows x cols row-major; element types converted on the way
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void k_transpose(const TI *in, TO *out, int rows, int cols)
 {
     __shared__ double tile[32][33];
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     for (int i = ty; i < 32; i += 8) {
         const int r = by + i, c = bx + tx;
-        if (r < rows && c < cols) tile[i][tx] = in[(size_t)r * cols + c];
+        if (r < rows && c < cols) tile[i][tx] = (double)in[(size_t)r * cols + c];
     }
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
         const int c = bx + i, r = by + tx;
-        if (r < rows && c < cols) out[(size_t)c * rows + r] = tile[tx][i];
+        if (r < rows && c < cols) out[(size_t)c * rows + r] = (TO)tile[tx][i];
     }
 }
 

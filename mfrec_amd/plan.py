@@ -12,13 +12,18 @@ LINEAR, LOGISTIC = 0, 1
 
 
 class SgdPlan(object):
-    def __init__(self, ratings_index, ratings, nbr_users, nbr_items, dim):
+    def __init__(self, ratings_index, ratings, nbr_users, nbr_items, dim, storage="f64"):
         pi, pr, nnz = S.ratings_args(ratings_index, ratings)
         self.nu, self.ni, self.k, self.nnz = int(nbr_users), int(nbr_items), int(dim), nnz
         self._h = S.lib().mfx_sgd_plan_create(pi, pr, nnz, self.nu, self.ni, self.k)
         if not self._h:
             msg = S.last_error()
             raise (ValueError if ("outside" in msg or "bad argument" in msg) else S.MfxError)(msg)
+        if storage not in ("f64", "f32"):
+            raise ValueError("storage must be 'f64' (exact) or 'f32' (fast mode)")
+        self.storage = storage
+        if storage == "f32":
+            S.check(S.lib().mfx_sgd_plan_set_storage(self._h, 32))
 
     def close(self):
         if getattr(self, "_h", None):

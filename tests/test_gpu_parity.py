@@ -316,3 +316,28 @@ def test_many_one_shot_calls_do_not_leak_or_drift():
                               np.array([[nu, 0]], dtype=np.int32), np.array([1.0]), ib, ub)
     assert "outside" in S.last_error()
     K.train_linear_kernel(1, k, 0.1, 0.01, 0, 0, 0.1, 0.1, 0.007, 0.0, u, v, idx, r, ib, ub)
+
+
+def test_f32_storage_fast_mode_rmse_budget(golden):
+    """The measured option: factor rows stored as f32, arithmetic in f64.
+    Not bit-exact by construction; the contract is the north-star's RMSE budget: final train
+    RMSE within 1e-5 of the reference after the fixed epoch count (cfg-1 shape, 10 epochs)."""
+    from mfrec_amd.plan import SgdPlan
+    from oracle import oracle as O
+    g = golden("g7_cfg1")
+    nu, ni, k, E = int(g["p_nu"]), int(g["p_ni"]), int(g["p_k"]), int(g["p_epochs"])
+    idx, r = g["in_idx"], g["in_r"].astype(np.float64)
+    seed = int(g["p_seed_init"])
+    u, v = synth.init_normal(k, ni, seed), synth.init_normal(k, nu, seed + 1)
+    ib, ub = np.zeros(ni), np.zeros(nu)
+    with SgdPlan(idx, r, nu, ni, k, storage="f32") as p:
+        p.set_factors(u, v, ib, ub)
+        rm = p.run_kmf(0, E, 0.01, 0.1, 0.1, 0.007)
+        p.get_factors(u, v, ib, ub)
+    rmse = O.rmse(O.RMSE_KMF_LINEAR, u, v, idx, r, ib, ub)
+    assert abs(rmse - float(g["out_lin_final_rmse"])) <= 1e-5
+    assert np.max(np.abs(rm - g["out_lin_rmse"])) <= 1e-5
+    assert not np.array_equal(u, g["out_lin_u"])                 # it is NOT the exact mode
+    np.testing.assert_allclose(u, g["out_lin_u"], rtol=0, atol=2e-5)
+    with pytest.raises(ValueError):
+        SgdPlan(idx, r, nu, ni, k, storage="bf16")

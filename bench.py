@@ -217,7 +217,7 @@ def main():
             "device_ms_per_step": tm.ms / a.steps,
             "schedule_build_ms": info["schedule_us"] / 1e3,
         }
-        if not a.no_cpu:
+        if not a.no_cpu and world == 1:          # rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(idx, r, nu, ni, k)
         print(json.dumps(line), flush=True)
     plan.close()

@@ -10,7 +10,8 @@ from mfrec_amd.lib.als_implicit import als_wrmf
 from mfrec_amd.lib.datasets import create_bool_sparse_col, create_bool_sparse_row
 S.init(0)
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-nu, ni, nnz = 100000, 20000, 10000000
+swap = len(sys.argv) > 2 and sys.argv[2] == "swap"      # last launch then covers the low-degree side
+nu, ni, nnz = (20000, 100000, 10000000) if swap else (100000, 20000, 10000000)
 idx, _ = synth.make_ratings(nu, ni, nnz)
 M = sp.csr_matrix((np.ones(nnz), (idx[:, 0], idx[:, 1])), shape=(nu, ni)); M.sum_duplicates()
 urow, ucol = create_bool_sparse_row(M); irow, icol = create_bool_sparse_col(M)
@@ -21,5 +22,5 @@ st = np.zeros(4096 * 8, dtype=np.uint64)
 assert S.lib().mfx_debug_als_stamps(st.ctypes.data_as(C.c_void_p)) == 0
 st = st.reshape(4096, 8).astype(np.float64)
 d = np.diff(st[:, :5], axis=1)
-print("k=%d, item pass (last launch; deg ~500): median ticks  syrk+gather %.0f | write A %.0f | cholesky %.0f | back-subst %.0f | total %.0f"
-      % ((k,) + tuple(np.median(d, axis=0)) + (np.median(st[:, 4] - st[:, 0]),)))
+print("k=%d, last launch (rows of degree ~%d): median ticks  syrk+gather %.0f | write A %.0f | cholesky %.0f | back-subst %.0f | total %.0f"
+      % ((k, nnz // ni) + tuple(np.median(d, axis=0)) + (np.median(st[:, 4] - st[:, 0]),)))

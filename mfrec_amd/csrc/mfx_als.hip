@@ -188,9 +188,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 ? 2 : (NT >= 5 ? 2 : 3))) void k_
     const int region = (A_ELEMS > stage_elems ? A_ELEMS : stage_elems) + 1 & ~1;
     double *A = lds;                                 // packed lower triangle + border row
     double *ych = lds;                               // aliases A while Y_N^T Y_N is accumulated
-    constexpr int DINV = KP > 80 ? KP : 80;          // [KP] 1 / L[c][c]; later [NW+1][16] scratch
-    double *dinv = lds + region;
-    int *cidx = (int *)(dinv + DINV);                // [2][CH2] neighbour ids of two chunks
+    double *dinv = lds + region;                     // [KP]  1 / L[c][c]
+    int *cidx = (int *)(dinv + KP);                  // [2][CH2] neighbour ids of two chunks
     int *bad = cidx + 2 * CH2;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -327,32 +326,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 ? 2 : (NT >= 5 ? 2 : 3))) void k_
             dinv[c0 + r] = myinv;
         }
         if (!ok && lane == 0) *bad = 1;
-        // W = L11^{-1} (lower triangular) replaces L11 in LDS: the panel solve X = A21 * W^T is then
-        // four MFMAs per tile and the back substitution a 16x16 mat-vec per block.  Columns of W
-        // are independent: lane c runs the forward substitution L11 w = e_c, L11 broadcast from LDS.
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        {
-            const int c = lane & 15;
-            const int lbase = als_row_off<NT>(c0) + c0;          // L11[rr][m] = A[lbase + rr*lstr + m]
-            const int lstr = 16 * (c0 / 16 + 1) + 2;
-            double w[16];
-#pragma unroll
-            for (int rr = 0; rr < 16; ++rr) {
-                double acc = (rr == c) ? 1.0 : 0.0;
-#pragma unroll
-                for (int m = 0; m < rr; ++m) acc -= A[lbase + rr * lstr + m] * w[m];
-                w[rr] = (rr >= c) ? acc * dinv[c0 + rr] : 0.0;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();                     // every lane has read L11
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (lane < 16) {
-#pragma unroll
-                for (int rr = 0; rr < 16; ++rr) A[lbase + rr * lstr + c] = w[rr];   // zeros above the diagonal
-            }
-        }
     };
     auto trailing_tile = [&](int Jb, int tt) {
         const int c0 = Jb * 16;
@@ -378,28 +351,25 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 ? 2 : (NT >= 5 ? 2 : 3))) void k_
     __syncthreads();
     for (int Jb = 0; Jb < NT; ++Jb) {
         const int c0 = Jb * 16;
-        // (b) panel: rows below the block and the border row:  X = A21 * W^T  (W = L11^{-1})
+        // (b) panel: rows below the block and the border row:  X = A21 * L11^{-T}
         {
-            const double *pb = A + als_row_off<NT>(c0 + (lane & 15)) + c0 + (lane >> 4);   // W[j][m]
-            for (int I = Jb + 1 + wid; I < NT; I += NW) {
-                const double *pa = A + als_row_off<NT>(I * 16 + (lane & 15)) + c0 + (lane >> 4);
-                double4_t x = (double4_t){0.0, 0.0, 0.0, 0.0};
+            const int pr = c0 + 16 + tid;            // physical row; pr == KP is the border row
+            if (pr <= KP) {
+                const int prow = als_row_off<NT>(pr) + c0;
+                const int lrow = als_row_off<NT>(c0) + c0;       // L11; its rows share one stride
+                const int lstride = 16 * (Jb + 1) + 2;
+                double a[16];
 #pragma unroll
-                for (int s4 = 0; s4 < 16; s4 += 4)
-                    x = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[s4], pb[s4], x, 0, 0, 0);
+                for (int c = 0; c < 16; ++c) a[c] = A[prow + c];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    A[als_row_off<NT>(I * 16 + (lane >> 4) + 4 * q) + c0 + (lane & 15)] = x[q];
-            }
-            if (tid < 16) {                          // border row: x_b[j] = sum_m b[m] W[j][m]
-                double bm[16];
+                for (int jj = 0; jj < 16; ++jj) {
+                    double x = a[jj];
 #pragma unroll
-                for (int m = 0; m < 16; ++m) bm[m] = A[BORDER + c0 + m];
-                const int wrow = als_row_off<NT>(c0 + tid) + c0;
-                double xb = 0.0;
+                    for (int m = 0; m < jj; ++m) x -= a[m] * A[lrow + jj * lstride + m];
+                    a[jj] = x * dinv[c0 + jj];
+                }
 #pragma unroll
-                for (int m = 0; m < 16; ++m) xb += bm[m] * A[wrow + m];
-                A[BORDER + c0 + tid] = xb;           // same wave: all 16 lanes have loaded bm
+                for (int c = 0; c < 16; ++c) A[prow + c] = a[c];
             }
         }
         __syncthreads();
@@ -445,43 +415,41 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 ? 2 : (NT >= 5 ? 2 : 3))) void k_
     }
     ALS_STAMP(3);
 
-    // ---- back substitution, blocked:  x_J = W_J^T (z_J - sum_{I>J} L_IJ^T x_I); x overwrites z ----
-    {
-        constexpr int PARTS = NTHR / 16;             // row slices summed in parallel
-        const int jcol = tid & 15, part = tid >> 4;
-        double *scratch = dinv;                      // [NW][16]; dinv is dead once every W is built
-        for (int Jb = NT - 1; Jb >= 0; --Jb) {
-            const int c0 = Jb * 16;
-            double acc = 0.0;
-            for (int rr = c0 + 16 + part; rr < KP; rr += PARTS)
-                acc += A[als_row_off<NT>(rr) + c0 + jcol] * A[BORDER + rr];
-            // the 4 parts that share a wave: lanes differ by 16 and 32
-            {
-                int lo = __double2loint(acc), hi = __double2hiint(acc);
-                acc += __hiloint2double(__shfl_xor(hi, 16, 64), __shfl_xor(lo, 16, 64));
-                lo = __double2loint(acc); hi = __double2hiint(acc);
-                acc += __hiloint2double(__shfl_xor(hi, 32, 64), __shfl_xor(lo, 32, 64));
-            }
-            if (lane < 16) scratch[wid * 16 + lane] = acc;
-            __syncthreads();
-            if (tid < 16) {
-                double rhs = A[BORDER + c0 + tid];
+    // ---- back substitution L^T x = z (z = border row) by wave 0, x in registers; the rows
+    //      of L and the reciprocal pivots of 16 steps are fetched ahead of the serial chain ---
+    if (wid == 0) {
+        double z0 = A[BORDER + (lane < KP ? lane : 0)];
+        double z1 = (KP > 64) ? A[BORDER + 64 + (lane < KP - 64 ? lane : 0)] : 0.0;
+        if (KP <= 64 && lane >= KP) z0 = 0.0;
+        if (KP > 64 && lane >= KP - 64) z1 = 0.0;
+        constexpr int PB = 8;                        // steps fetched ahead (register budget)
+        for (int cb = KP - PB; cb >= 0; cb -= PB) {
+            double lo[PB], hi[KP > 64 ? PB : 1], dv[PB];
 #pragma unroll
-                for (int w = 0; w < NW; ++w) rhs -= scratch[w * 16 + tid];
-                scratch[NW * 16 + tid] = rhs;        // rhs_J, read by the other 15 lanes below
+            for (int i = 0; i < PB; ++i) {
+                const int c = cb + i;
+                const int crow = als_row_off<NT>(c);
+                lo[i] = (lane < c) ? A[crow + lane] : 0.0;
+                if constexpr (KP > 64) hi[i] = (lane + 64 < c) ? A[crow + lane + 64] : 0.0;
+                dv[i] = dinv[c];
             }
-            __syncthreads();
-            if (tid < 16) {                          // x_J[j] = sum_{m >= j} W[m][j] * rhs[m]
-                double x = 0.0;
-                const int wbase = als_row_off<NT>(c0) + c0;
-                const int wstr = 16 * (Jb + 1) + 2;
 #pragma unroll
-                for (int m = 0; m < 16; ++m) x += A[wbase + m * wstr + tid] * scratch[NW * 16 + m];
-                A[BORDER + c0 + tid] = x;
+            for (int i = PB - 1; i >= 0; --i) {
+                const int c = cb + i;
+                double x;
+                if (cb >= 64) {                      // wave-uniform: pivots owned by z1
+                    x = readlane_f64(z1, c - 64) * dv[i];
+                    if (lane == c - 64) z1 = x;
+                } else {
+                    x = readlane_f64(z0, c) * dv[i];
+                    if (lane == c) z0 = x;
+                }
+                z0 -= lo[i] * x;
+                if constexpr (KP > 64) z1 -= hi[i] * x;
             }
-            __syncthreads();
         }
-        for (int f = tid; f < k; f += NTHR) xrow[f] = A[BORDER + f];
+        if (lane < k) xrow[lane] = z0;
+        if (lane + 64 < k) xrow[lane + 64] = z1;
     }
     ALS_STAMP(4);
 }
@@ -534,7 +502,7 @@ size_t rows2_lds_bytes(int KP)
     const int NTv = KP / 16;
     const size_t a = (size_t)(128 * NTv * (NTv + 1) + 32 * NTv) + KP + 2, st = (size_t)CH2 * ych_stride(KP);
     const size_t region = ((a > st ? a : st) + 1) & ~(size_t)1;
-    return (region + (KP > 80 ? KP : 80)) * sizeof(double) + (2 * CH2 + 2) * sizeof(int);
+    return (region + KP) * sizeof(double) + (2 * CH2 + 2) * sizeof(int);
 }
 
 AlsKernels als_kernels(int nt)

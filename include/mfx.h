@@ -70,6 +70,11 @@ int mfx_schedule_levels(const int32_t *ratings_index, int64_t nnz, int nu, int n
                         int32_t *level_out, int64_t *n_levels_out);
 int mfx_schedule_permutation(const int32_t *level, int64_t nnz, int64_t n_levels,
                              int64_t *perm_out, int64_t *level_off_out);
+/* The same ordering applied directly: recs_out[j] = 16-byte record {int32 user, int32 item,
+ * f64 rating} of the j-th rating in level-major order (threaded stable counting sort; this is
+ * what a plan uploads).  level_off_out has n_levels+1 entries. */
+int mfx_schedule_pack(const int32_t *ratings_index, const double *ratings, const int32_t *level,
+                      int64_t nnz, int64_t n_levels, void *recs_out, int64_t *level_off_out);
 
 /* ------------------------------------------- one-shot drop-ins (host arrays)
  * Replace, argument for argument, the Cython `def` functions.  Arguments the

@@ -7,6 +7,7 @@
 // sequential result exactly ("Hard parts").
 #include <stdlib.h>
 #include <string.h>
+#include <thread>
 #include <vector>
 #include "mfx_common.h"
 
@@ -66,5 +67,74 @@ extern "C" int mfx_schedule_permutation(const int32_t *level, int64_t nnz, int64
         return mfx::fail(MFX_E_NOMEM, "mfx_schedule_permutation: out of host memory");
     }
     for (int64_t t = 0; t < nnz; ++t) perm_out[cur[level[t] - 1]++] = t;
+    return MFX_OK;
+}
+
+// Stable counting sort by level straight into 16-byte records {int32 user, int32 item, f64 r}
+// (the device layout), on up to 16 host threads: per-thread histograms over contiguous slices
+// of the rating sequence, then every thread scatters its slice.  No permutation array, no gather.
+// Output order == mfx_schedule_permutation's order.
+namespace {
+struct PackRec {
+    int32_t user, item;
+    double r;
+};
+}  // namespace
+
+extern "C" int mfx_schedule_pack(const int32_t *idx, const double *r, const int32_t *level,
+                                 int64_t nnz, int64_t n_levels, void *recs_out,
+                                 int64_t *level_off_out)
+{
+    if (!level_off_out || nnz < 0 || n_levels < 0 || (nnz > 0 && (!idx || !r || !level || !recs_out)))
+        return mfx::fail(MFX_E_ARG, "mfx_schedule_pack: bad argument");
+    PackRec *recs = (PackRec *)recs_out;
+    for (int64_t t = 0; t < nnz; ++t)
+        if (level[t] < 1 || level[t] > n_levels)
+            return mfx::fail(MFX_E_RANGE, "mfx_schedule_pack: level %d outside [1,%lld]", level[t],
+                             (long long)n_levels);
+    try {
+        unsigned hw = std::thread::hardware_concurrency();
+        int T = (int)(hw ? hw : 1);
+        if (T > 16) T = 16;
+        if (nnz < (1 << 20)) T = 1;
+        const size_t NL = (size_t)n_levels + 1;
+        while (T > 1 && (size_t)T * NL > ((size_t)1 << 26)) T /= 2;
+        std::vector<int64_t> hist((size_t)T * NL, 0);
+        auto slice = [&](int i, int64_t &a, int64_t &b) { a = nnz * i / T; b = nnz * (i + 1) / T; };
+        auto run = [&](auto &&fn) {
+            if (T == 1) { fn(0); return; }
+            std::vector<std::thread> th;
+            for (int i = 0; i < T; ++i) th.emplace_back(fn, i);
+            for (auto &x : th) x.join();
+        };
+        run([&](int i) {
+            int64_t a, b; slice(i, a, b);
+            int64_t *h = hist.data() + (size_t)i * NL;
+            for (int64_t t = a; t < b; ++t) ++h[level[t]];
+        });
+        // level_off[l] = start of level l+1 (levels are 1-based); one cursor per (thread, level)
+        int64_t acc = 0;
+        for (size_t L = 1; L < NL; ++L) {
+            level_off_out[L - 1] = acc;
+            for (int i = 0; i < T; ++i) {
+                const int64_t c = hist[(size_t)i * NL + L];
+                hist[(size_t)i * NL + L] = acc;
+                acc += c;
+            }
+        }
+        level_off_out[NL - 1] = acc;
+        run([&](int i) {
+            int64_t a, b; slice(i, a, b);
+            int64_t *cur = hist.data() + (size_t)i * NL;
+            for (int64_t t = a; t < b; ++t) {
+                PackRec &q = recs[cur[level[t]]++];
+                q.user = idx[2 * t];
+                q.item = idx[2 * t + 1];
+                q.r = r[t];
+            }
+        });
+    } catch (...) {
+        return mfx::fail(MFX_E_NOMEM, "mfx_schedule_pack: out of host memory / threads");
+    }
     return MFX_OK;
 }

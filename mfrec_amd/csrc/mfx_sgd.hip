@@ -405,53 +405,11 @@ mfx_sgd_plan *mfx_sgd_plan_create(const int32_t *idx, const double *r, int64_t n
         const auto t0 = std::chrono::steady_clock::now();
         std::vector<int32_t> level((size_t)(nnz ? nnz : 1));
         if (mfx_schedule_levels(idx, nnz, nu, ni, level.data(), &p->n_levels)) return bail();
-        // stable counting sort by level straight into the 16-byte device records, on T host
-        // threads: per-thread histograms over contiguous slices of the rating sequence, then
-        // every thread scatters its slice (no permutation array, no gather)
         p->level_off.assign((size_t)p->n_levels + 1, 0);
         std::vector<Rec> recs((size_t)(nnz ? nnz : 1));
-        {
-            unsigned hw = std::thread::hardware_concurrency();
-            int T = (int)(hw ? hw : 1);
-            if (T > 16) T = 16;
-            if (nnz < (1 << 20)) T = 1;
-            while (T > 1 && (size_t)T * (size_t)(p->n_levels + 1) > ((size_t)1 << 26)) T /= 2;
-            const size_t NL = (size_t)p->n_levels + 1;
-            std::vector<int64_t> hist((size_t)T * NL, 0);
-            auto slice = [&](int i, int64_t &a, int64_t &b) { a = nnz * i / T; b = nnz * (i + 1) / T; };
-            auto run = [&](auto &&fn) {
-                if (T == 1) { fn(0); return; }
-                std::vector<std::thread> th;
-                for (int i = 0; i < T; ++i) th.emplace_back(fn, i);
-                for (auto &x : th) x.join();
-            };
-            run([&](int i) {
-                int64_t a, b; slice(i, a, b);
-                int64_t *h = hist.data() + (size_t)i * NL;
-                for (int64_t t = a; t < b; ++t) ++h[level[t]];
-            });
-            // level_off[l] = start of level l+1 (levels are 1-based); cursors per (thread, level)
-            int64_t acc = 0;
-            for (size_t L = 1; L < NL; ++L) {
-                p->level_off[L - 1] = acc;
-                for (int i = 0; i < T; ++i) {
-                    const int64_t c = hist[(size_t)i * NL + L];
-                    hist[(size_t)i * NL + L] = acc;
-                    acc += c;
-                }
-            }
-            p->level_off[NL - 1] = acc;
-            run([&](int i) {
-                int64_t a, b; slice(i, a, b);
-                int64_t *cur = hist.data() + (size_t)i * NL;
-                for (int64_t t = a; t < b; ++t) {
-                    Rec &q = recs[cur[level[t]]++];
-                    q.user = idx[2 * t];
-                    q.item = idx[2 * t + 1];
-                    q.r = r[t];
-                }
-            });
-        }
+        static_assert(sizeof(Rec) == 16, "Rec is the 16-byte record of mfx_schedule_pack");
+        if (mfx_schedule_pack(idx, r, level.data(), nnz, p->n_levels, recs.data(), p->level_off.data()))
+            return bail();
         p->k1_wave_off.assign((size_t)p->n_levels + 1, 0);
         p->k2_wave_off.assign((size_t)p->n_levels + 1, 0);
         for (int64_t l = 0; l < p->n_levels; ++l) {

@@ -109,3 +109,20 @@ def test_scheduler_properties_random(lib):
     bad = np.array([[0, 5]], dtype=np.int32)
     with pytest.raises(ValueError, match="outside"):
         _levels(lib, bad, 3, 3)
+
+
+def test_threaded_pack_equals_permutation_gather(lib):
+    """mfx_schedule_pack (what a plan uploads) == gathering with mfx_schedule_permutation, on a
+    problem big enough (> 2^20 ratings) for the multi-threaded path."""
+    rs = np.random.RandomState(5)
+    n = (1 << 20) + 12345
+    idx = np.stack([rs.randint(0, 20000, n), rs.randint(0, 9000, n)], 1).astype(np.int32)
+    r = rs.randint(1, 6, n).astype(np.float64)
+    lev, perm, off = _levels(lib, idx, 20000, 9000)
+    rec = np.zeros(n, dtype=np.dtype([("user", np.int32), ("item", np.int32), ("r", np.float64)]))
+    off2 = np.zeros(len(off), dtype=np.int64)
+    S.check(lib.mfx_schedule_pack(S.i32(idx, "idx", 2), S.f64(r, "r", 1), lev.ctypes.data_as(S._ip), n,
+                                  len(off) - 1, rec.ctypes.data_as(C.c_void_p), off2.ctypes.data_as(S._lp)))
+    assert np.array_equal(off2, off)
+    assert np.array_equal(rec["user"], idx[perm, 0]) and np.array_equal(rec["item"], idx[perm, 1])
+    assert np.array_equal(rec["r"], r[perm])

@@ -89,7 +89,7 @@ def main():
     ap.add_argument("--items", type=int, default=50000)
     ap.add_argument("--nnz", type=int, default=10000000, help="ratings per GPU")
     ap.add_argument("--k", type=int, default=64)
-    ap.add_argument("--order", choices=["shuffled", "user-major"], default="shuffled")
+    ap.add_argument("--order", choices=["shuffled", "user-major", "balanced"], default="shuffled")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--storage", choices=["f64", "f32"], default="f64",
                     help="f32 = NOT the reference's precision: rows stored as f32 (measured option only)")
@@ -130,6 +130,10 @@ def main():
     idx, r = synth.make_ratings(nu, ni, nnz, t0=rank * nnz, user_base=0)
     if a.order == "user-major":
         idx, r = synth.user_major(idx, r)
+    elif a.order == "balanced":
+        from mfrec_amd.lib.datasets import balanced_order
+        perm, _ = balanced_order(idx, nu, ni, seed=11)
+        idx, r = np.ascontiguousarray(idx[perm]), np.ascontiguousarray(r[perm])
     u0 = synth.init_normal(k, ni, synth.SEED_INIT)
     v0 = synth.init_normal(k, nu, synth.SEED_INIT + 1 + rank)
     plan = SgdPlan(idx, r, nu, ni, k, storage=a.storage)

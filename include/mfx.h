@@ -76,6 +76,14 @@ int mfx_schedule_permutation(const int32_t *level, int64_t nnz, int64_t n_levels
 int mfx_schedule_pack(const int32_t *ratings_index, const double *ratings, const int32_t *level,
                       int64_t nnz, int64_t n_levels, void *recs_out, int64_t *level_off_out);
 
+/* An input ORDER with close to the minimum number of dependency levels (first-fit edge colouring
+ * over a seeded random visiting order; round-major).  The reference shuffles the ratings with an
+ * unseeded RNG before every train() (base.py:1127-1129), so any permutation is a legitimate order;
+ * this one roughly halves the level count of an i.i.d. shuffle.  perm_out[j] = index of the j-th
+ * rating of the new order.  Host code. */
+int mfx_schedule_balanced_order(const int32_t *ratings_index, int64_t nnz, int nu, int ni,
+                                uint64_t seed, int64_t *perm_out, int64_t *n_rounds_out);
+
 /* ------------------------------------------- one-shot drop-ins (host arrays)
  * Replace, argument for argument, the Cython `def` functions.  Arguments the
  * reference accepts but never reads (f_init, learning_rate_users/items and

@@ -138,3 +138,81 @@ extern "C" int mfx_schedule_pack(const int32_t *idx, const double *r, const int3
     }
     return MFX_OK;
 }
+
+// A rating ORDER with (close to) the minimum number of dependency levels.  The reference shuffles
+// the ratings with an unseeded RNG before every train() (base.py:1127-1129), so any permutation
+// is a legitimate input order; this one is a first-fit edge colouring of the bipartite
+// user-item multigraph taken over a seeded random visiting order: every rating gets the smallest
+// round in which neither its user nor its item is already busy, and the order is round-major.
+// Rounds ~ max degree + a few (the level schedule of an i.i.d. shuffle needs ~2.3x max degree).
+extern "C" int mfx_schedule_balanced_order(const int32_t *idx, int64_t nnz, int nu, int ni,
+                                           uint64_t seed, int64_t *perm_out, int64_t *n_rounds_out)
+{
+    if (nnz < 0 || nu < 0 || ni < 0 || (nnz > 0 && (!idx || !perm_out)))
+        return mfx::fail(MFX_E_ARG, "mfx_schedule_balanced_order: bad argument");
+    try {
+        std::vector<int32_t> du((size_t)nu, 0), di((size_t)ni, 0);
+        for (int64_t t = 0; t < nnz; ++t) {
+            const int32_t a = idx[2 * t], b = idx[2 * t + 1];
+            if (a < 0 || a >= nu || b < 0 || b >= ni)
+                return mfx::fail(MFX_E_RANGE, "rating %lld: (user %d, item %d) outside [0,%d) x [0,%d)",
+                                 (long long)t, a, b, nu, ni);
+            ++du[a];
+            ++di[b];
+        }
+        // seeded Fisher-Yates visiting order (xorshift64*)
+        std::vector<int64_t> visit((size_t)nnz);
+        for (int64_t t = 0; t < nnz; ++t) visit[t] = t;
+        uint64_t s = seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+        auto rnd = [&]() { s ^= s >> 12; s ^= s << 25; s ^= s >> 27; return s * 0x2545F4914F6CDD1Dull; };
+        for (int64_t t = nnz - 1; t > 0; --t) {
+            const int64_t j = (int64_t)(rnd() % (uint64_t)(t + 1));
+            std::swap(visit[t], visit[j]);
+        }
+        // busy-round bitsets per user / item.  First fit never needs a round >= deg(user) + deg(item),
+        // so a node's bitset covers its own degree + the largest degree of the other side.  On very
+        // skewed data that is too much memory: refuse (the caller then keeps a plain shuffle).
+        int64_t mdu = 0, mdi = 0;
+        for (int a = 0; a < nu; ++a) mdu = du[a] > mdu ? du[a] : mdu;
+        for (int b = 0; b < ni; ++b) mdi = di[b] > mdi ? di[b] : mdi;
+        std::vector<int64_t> ou((size_t)nu + 1, 0), oi((size_t)ni + 1, 0);
+        for (int a = 0; a < nu; ++a) ou[a + 1] = ou[a] + (du[a] ? ((int64_t)du[a] + mdi + 64) / 64 : 0);
+        for (int b = 0; b < ni; ++b) oi[b + 1] = oi[b] + (di[b] ? ((int64_t)di[b] + mdu + 64) / 64 : 0);
+        if ((ou[nu] + oi[ni]) * 8 > ((int64_t)1 << 30))
+            return mfx::fail(MFX_E_STATE, "mfx_schedule_balanced_order: degrees too skewed (bitsets would need "
+                             "%lld MB); use a plain shuffle", (long long)((ou[nu] + oi[ni]) * 8 >> 20));
+        std::vector<uint64_t> bu((size_t)ou[nu], 0), bi((size_t)oi[ni], 0);
+        std::vector<int32_t> round((size_t)nnz);
+        int64_t top = 0;
+        for (int64_t v = 0; v < nnz; ++v) {
+            const int64_t t = visit[v];
+            const int32_t a = idx[2 * t], b = idx[2 * t + 1];
+            uint64_t *wa = bu.data() + ou[a], *wb = bi.data() + oi[b];
+            const int64_t na = ou[a + 1] - ou[a], nb = oi[b + 1] - oi[b];
+            int64_t c = -1;
+            for (int64_t w = 0;; ++w) {
+                const uint64_t ma = w < na ? wa[w] : 0, mb = w < nb ? wb[w] : 0;
+                const uint64_t freebits = ~(ma | mb);
+                if (freebits) { c = w * 64 + __builtin_ctzll(freebits); break; }
+            }
+            if (c / 64 >= na || c / 64 >= nb)
+                return mfx::fail(MFX_E_STATE, "mfx_schedule_balanced_order: internal bitset overflow");
+            wa[c / 64] |= 1ull << (c % 64);
+            wb[c / 64] |= 1ull << (c % 64);
+            round[t] = (int32_t)c + 1;
+            if (c + 1 > top) top = c + 1;
+        }
+        // round-major, visiting order inside a round (already random)
+        std::vector<int64_t> off((size_t)top + 2, 0);
+        for (int64_t t = 0; t < nnz; ++t) ++off[round[t] + 1];
+        for (int64_t l = 1; l <= top + 1; ++l) off[l] += off[l - 1];
+        for (int64_t v = 0; v < nnz; ++v) {
+            const int64_t t = visit[v];
+            perm_out[off[round[t]]++] = t;
+        }
+        if (n_rounds_out) *n_rounds_out = top;
+    } catch (...) {
+        return mfx::fail(MFX_E_NOMEM, "mfx_schedule_balanced_order: out of host memory");
+    }
+    return MFX_OK;
+}

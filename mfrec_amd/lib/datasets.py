@@ -24,3 +24,19 @@ def create_bool_sparse_row(sparse_matrix):
 def create_bool_sparse_col(sparse_matrix):
     """Same on the transpose: per item, the users that rated it."""
     return _run_length(sp.csr_matrix(sparse_matrix).T)
+
+
+def balanced_order(ratings_index, nbr_users, nbr_items, seed=0):
+    """Permutation of the ratings with (close to) the minimum number of dependency levels for
+    the exact GPU schedule: a seeded first-fit edge colouring, round-major (libmfx host code,
+    mfx_schedule_balanced_order).  A legitimate stand-in for the reference's random shuffle
+    (base.py:1127-1129).  Raises MfxError if the degree distribution is too skewed."""
+    import ctypes as C
+    from .. import _shim as S
+    idx = np.ascontiguousarray(ratings_index, dtype=np.int32)
+    perm = np.empty(idx.shape[0], dtype=np.int64)
+    n = C.c_int64(0)
+    S.check(S.lib().mfx_schedule_balanced_order(S.i32(idx, "ratings_index", 2), idx.shape[0],
+                                                int(nbr_users), int(nbr_items), int(seed) & (2 ** 63 - 1),
+                                                perm.ctypes.data_as(S._lp), C.byref(n)))
+    return perm, n.value

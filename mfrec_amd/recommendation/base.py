@@ -68,7 +68,17 @@ class BaseRecommender(object):
         ratings_index = np.stack([coo.row[keep], coo.col[keep]], axis=1).astype(np.int32)
         ratings = coo.data[keep].astype(np.float64)
         order = np.arange(ratings.shape[0])
-        if randomize_order:
+        if isinstance(randomize_order, str) and randomize_order == "balanced":
+            # extension: a random order with the fewest dependency levels (seeded from the same
+            # global numpy RNG the reference's shuffle uses); falls back to the plain shuffle
+            from ..lib.datasets import balanced_order
+            from .._shim import MfxError
+            try:
+                order, _ = balanced_order(ratings_index, self.nbr_users, self.nbr_items,
+                                          seed=int(np.random.randint(0, 2 ** 31 - 1)))
+            except MfxError:
+                np.random.shuffle(order)
+        elif randomize_order:
             np.random.shuffle(order)
         return np.ascontiguousarray(ratings_index[order]), np.ascontiguousarray(ratings[order])
 

@@ -44,13 +44,14 @@ class KMFRecommender(MFRecommender):
 
     predict = predict_logistic                                               # kmf.py:106
 
-    def train(self, initialize_model=True, verbose=False, kernel="train_logistic_kernel"):
+    def train(self, initialize_model=True, verbose=False, kernel="train_logistic_kernel", order=True):
         """kmf.py:197-220: N(0, 0.1) init, shuffled ratings, zero biases, one kernel call."""
         if kernel not in ("train_logistic_kernel", "train_linear_kernel"):
             raise NameError("name '%s' is not defined" % kernel)     # the reference eval()s the name
         if initialize_model:
             self.init_feature_normal(0.0, 0.1)
-        ratings_index, ratings = self.get_ratings(randomize_order=True)
+        # order=True: the reference's shuffle; order="balanced": fewest dependency levels (extension)
+        ratings_index, ratings = self.get_ratings(randomize_order=order)
         self.compute_overall_avg()
         self.items_bias = np.zeros(self.nbr_items)
         self.users_bias = np.zeros(self.nbr_users)

@@ -126,3 +126,21 @@ def test_threaded_pack_equals_permutation_gather(lib):
     assert np.array_equal(off2, off)
     assert np.array_equal(rec["user"], idx[perm, 0]) and np.array_equal(rec["item"], idx[perm, 1])
     assert np.array_equal(rec["r"], r[perm])
+
+
+def test_balanced_order_is_a_permutation_with_max_degree_levels(lib):
+    from mfrec_amd.lib.datasets import balanced_order
+    rs = np.random.RandomState(1)
+    n, nu, ni = 200000, 3000, 1500
+    idx = np.stack([rs.randint(0, nu, n), rs.randint(0, ni, n)], 1).astype(np.int32)
+    perm, rounds = balanced_order(idx, nu, ni, seed=3)
+    assert sorted(perm.tolist()) == list(range(n))
+    maxdeg = max(np.bincount(idx[:, 0]).max(), np.bincount(idx[:, 1]).max())
+    assert maxdeg <= rounds <= maxdeg + 8                       # first fit lands on (almost) Delta
+    lev, _, off = _levels(lib, np.ascontiguousarray(idx[perm]), nu, ni)
+    assert len(off) - 1 == rounds                                # the level schedule keeps the rounds
+    plain, _, off2 = _levels(lib, idx, nu, ni)
+    assert len(off2) - 1 > 1.5 * rounds                          # an i.i.d. order needs far more levels
+    perm2, _ = balanced_order(idx, nu, ni, seed=3)
+    assert np.array_equal(perm, perm2)                           # seeded, deterministic
+    assert not np.array_equal(perm, balanced_order(idx, nu, ni, seed=4)[0])

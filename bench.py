@@ -63,14 +63,26 @@ def cpu_baseline(idx, r, nu, ni, k, budget_s=12.0):
         t0 = time.perf_counter(); fn(n2); dt = time.perf_counter() - t0
         return n2 / dt, n2, dt
 
+    def host_info():
+        model = "unknown"
+        try:
+            for ln in open("/proc/cpuinfo"):
+                if ln.startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+        except OSError:
+            pass
+        return {"cpu_model": model, "nproc": os.cpu_count()}
+
     p_rate, p_n, p_dt = timed(port, budget_s if ref_fn is None else 5.0)
-    out = {"value": p_rate, "unit": "rating-updates/s", "cores": 1, "kind": "port",
+    out = {"value": p_rate, "unit": "rating-updates/s", "cores": 1, "kind": "port", "host": host_info(),
            "sample": "first %d of %d ratings (%s), 1 epoch, full-size factors, "
                      "oracle/mfx_oracle.c single thread, %.1f s" % (p_n, idx.shape[0], "bench order", p_dt)}
     if ref_fn is not None:
         try:
             r_rate, r_n, r_dt = timed(ref_fn, budget_s)
             out = {"value": r_rate, "unit": "rating-updates/s", "cores": 1, "kind": "reference",
+                   "host": host_info(),
                    "sample": "first %d of %d ratings (bench order), 1 epoch, full-size factors, the "
                              "reference's Cython train_linear_kernel (oracle/_ref), single thread, "
                              "%.1f s" % (r_n, idx.shape[0], r_dt),

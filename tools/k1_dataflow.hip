@@ -36,6 +36,12 @@ __device__ __forceinline__ void st_sc1_i32(int *p, int v) { __hip_atomic_store(p
 constexpr int B = 8;        // ratings per chunk
 constexpr int K = 64;
 constexpr int SPIN_LIMIT = 1 << 14;
+#ifndef FLOW_SLEEP
+#define FLOW_SLEEP 2
+#endif
+#ifndef FLOW_PREFETCH
+#define FLOW_PREFETCH 0
+#endif
 
 __global__ __launch_bounds__(64) void k1_flow(const Rec *recs, const int2 *seq, const Chunk *chunks, int n_chunks,
                                               double *U, double *V, double *ib, double *ub, int *cnt_u, int *cnt_i,
@@ -44,12 +50,30 @@ __global__ __launch_bounds__(64) void k1_flow(const Rec *recs, const int2 *seq, 
     __shared__ __attribute__((aligned(16))) double prod[B * 66];
     const int lane = threadIdx.x;
     const int W = gridDim.x;
+#if FLOW_PREFETCH
+    Chunk nch = chunks[blockIdx.x < n_chunks ? blockIdx.x : 0];
+    Rec nrec; nrec.user = 0; nrec.item = 0; nrec.r = 0.0;
+    int2 nsq = make_int2(0, 0);
+    if (blockIdx.x < n_chunks && lane < nch.cnt) { nrec = recs[nch.start + lane]; nsq = seq[nch.start + lane]; }
+#endif
     for (int c = blockIdx.x; c < n_chunks; c += W) {
+#if FLOW_PREFETCH
+        const Chunk ch = nch;
+        const int cnt = ch.cnt;
+        Rec rec = nrec;
+        int2 sq = nsq;
+        if (c + W < n_chunks) {                       // next chunk's record: off the critical path
+            nch = chunks[c + W];
+            nrec.user = 0; nrec.item = 0; nrec.r = 0.0; nsq = make_int2(0, 0);
+            if (lane < nch.cnt) { nrec = recs[nch.start + lane]; nsq = seq[nch.start + lane]; }
+        }
+#else
         const Chunk ch = chunks[c];
         const int cnt = ch.cnt;
         Rec rec; rec.user = 0; rec.item = 0; rec.r = 0.0;
         int2 sq = make_int2(0, 0);
         if (lane < cnt) { rec = recs[ch.start + lane]; sq = seq[ch.start + lane]; }
+#endif
         // ---- wait for both chains (bounded) ----------------------------------------------
         bool ready = lane >= cnt;
         int spins = 0;
@@ -60,7 +84,7 @@ __global__ __launch_bounds__(64) void k1_flow(const Rec *recs, const int2 *seq, 
             }
             if (__all(ready)) break;
             if (++spins > SPIN_LIMIT) { if (lane == 0) atomicOr(err, 1); break; }
-            __builtin_amdgcn_s_sleep(2);
+            if (FLOW_SLEEP) __builtin_amdgcn_s_sleep(FLOW_SLEEP);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // ---- gather rows (sc1), products, in-order sums -------------------------------------

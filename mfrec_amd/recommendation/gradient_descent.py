@@ -25,11 +25,13 @@ class GDRecommender(MFRecommender):
         if parameters:
             self.set_parameters(parameters)
 
-    def feature_training(self, initialize_model=True, handle_bias=False, verbose=False):
-        """gradient_descent.py:506-542."""
+    def feature_training(self, initialize_model=True, handle_bias=False, verbose=False, order=True):
+        """gradient_descent.py:506-542.  order=True: the reference's shuffle; order="balanced"
+        (extension): a random order with the fewest dependency levels -- the Funk pass costs one
+        short launch per level, so this is ~2x faster on the GPU."""
         if initialize_model:
             self.init_feature_const()
-        ratings_index, ratings = self.get_ratings(randomize_order=True)
+        ratings_index, ratings = self.get_ratings(randomize_order=order)
         if handle_bias:
             self.compute_overall_avg()
             self.compute_items_bias_bk()

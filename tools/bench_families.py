@@ -18,6 +18,10 @@ from mfrec_amd.plan import SgdPlan, Timer  # noqa: E402
 def funk(a):
     nu, ni, nnz, k = a.users, a.items, a.nnz, a.k
     idx, r = synth.make_ratings(nu, ni, nnz)
+    if a.balanced:
+        from mfrec_amd.lib.datasets import balanced_order
+        perm, _ = balanced_order(idx, nu, ni, seed=11)
+        idx, r = np.ascontiguousarray(idx[perm]), np.ascontiguousarray(r[perm])
     plan = SgdPlan(idx, r, nu, ni, k)
     plan.set_factors(synth.init_const(k, ni), synth.init_const(k, nu))
     E = a.epochs
@@ -70,6 +74,7 @@ if __name__ == "__main__":
     ap.add_argument("--nnz", type=int, default=10000000)
     ap.add_argument("--k", type=int, default=64)
     ap.add_argument("--epochs", type=int, default=2)
+    ap.add_argument("--balanced", action="store_true", help="balanced input order (fewest levels)")
     a = ap.parse_args()
     S.init(0)
     funk(a) if a.family == "funk" else als(a)

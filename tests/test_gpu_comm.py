@@ -34,6 +34,9 @@ def test_forced_single_rank_comm_matches_simulation():
         u, v, ib, ub = T.get_local()
         T.close()
         S.check(S.lib().mfx_comm_barrier())
+        w = C.c_double(3.25)                                  # bench.py's max-over-ranks reduction
+        S.check(S.lib().mfx_comm_allreduce_max(C.byref(w)))
+        assert w.value == 3.25
     finally:
         S.check(S.lib().mfx_comm_destroy())
         del os.environ["MFX_FORCE_COMM"]

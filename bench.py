@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--k", type=int, default=64)
     ap.add_argument("--order", choices=["shuffled", "user-major", "balanced"], default="shuffled")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary balanced-order data point")
     ap.add_argument("--storage", choices=["f64", "f32"], default="f64",
                     help="f32 = NOT the reference's precision: rows stored as f32 (measured option only)")
     a = ap.parse_args()
@@ -233,6 +234,22 @@ def main():
             "device_ms_per_step": tm.ms / a.steps,
             "schedule_build_ms": info["schedule_us"] / 1e3,
         }
+        if world == 1 and a.order == "shuffled" and a.storage == "f64" and not a.no_extra:
+            # secondary, clearly labelled data point (not `value`): the same exact kernel on a
+            # balanced input order (fewest dependency levels)
+            try:
+                from mfrec_amd.lib.datasets import balanced_order
+                perm, rounds = balanced_order(idx, nu, ni, seed=11)
+                with SgdPlan(np.ascontiguousarray(idx[perm]), np.ascontiguousarray(r[perm]), nu, ni, k) as p2:
+                    p2.set_factors(u0, v0, np.zeros(ni), np.zeros(nu))
+                    p2.run_kmf(LINEAR, 1, LR, KU, KI, KB, want_rmse=False)
+                    with Timer() as t2:
+                        p2.run_kmf(LINEAR, a.steps, LR, KU, KI, KB, want_rmse=False)
+                line["also"] = {"balanced_input_order": {"value": nnz * a.steps / (t2.ms * 1e-3),
+                                                         "unit": "rating-updates/s", "levels": rounds,
+                                                         "ms_per_step": t2.ms / a.steps}}
+            except Exception as e:                  # never let the extra break the bench line
+                line["also"] = {"balanced_input_order_error": repr(e)}
         if not a.no_cpu and world == 1:          # rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(idx, r, nu, ni, k)
         print(json.dumps(line), flush=True)

@@ -5,9 +5,9 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 R=${1:-r1}
 O=gpurun_out/prof_$R
 rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 5 --warmup 1 --no-cpu --no-extra > $O/bench_trace.json 2> $O/trace.log
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-extra > $O/bench_fetch.json 2> $O/fetch.log
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-extra > $O/bench_write.json 2> $O/write.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 5 --warmup 1 --no-cpu > $O/bench_trace.json 2> $O/trace.log
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu > $O/bench_fetch.json 2> $O/fetch.log
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --steps 2 --warmup 1 --no-cpu > $O/bench_write.json 2> $O/write.log
 python3 - "$O" <<'PY'
 import csv, glob, sys, collections, json
 O = sys.argv[1]

@@ -593,22 +593,24 @@ int mfx_sgd_profile_kmf(mfx_sgd_plan *p, int mode, double lr, double Ku, double 
     K1Params P = k1_params(p, lr, Ku, Ki, Kb, 1, 1);
     const int64_t launches = (int64_t)p->segs.size();
     std::vector<hipEvent_t> ev((size_t)launches * 2, nullptr);
+    struct EvGuard {
+        std::vector<hipEvent_t> &v;
+        ~EvGuard() { for (auto &e : v) if (e) (void)hipEventDestroy(e); }
+    } guard{ev};
     for (auto &e : ev) MFX_HIP(hipEventCreate(&e));
     MFX_HIP(hipMemsetAsync(p->d_counter, 0, sizeof(int), stream()));
     rc = enqueue_k1_epoch(p, mode, P, &ev);
-    if (!rc) {
-        MFX_HIP(hipStreamSynchronize(stream()));
-        double tot = 0.0;
-        for (int64_t i = 0; i < launches; ++i) {
-            float ms = 0.f;
-            MFX_HIP(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
-            tot += ms;
-        }
-        if (kernel_ms) *kernel_ms = tot;
-        if (n_launches) *n_launches = launches;
+    if (rc) return rc;
+    MFX_HIP(hipStreamSynchronize(stream()));
+    double tot = 0.0;
+    for (int64_t i = 0; i < launches; ++i) {
+        float ms = 0.f;
+        MFX_HIP(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+        tot += ms;
     }
-    for (auto &e : ev) (void)hipEventDestroy(e);
-    return rc;
+    if (kernel_ms) *kernel_ms = tot;
+    if (n_launches) *n_launches = launches;
+    return MFX_OK;
 }
 
 // ---- Funk: per-feature passes with the data-dependent stopping rule (host-driven) ----

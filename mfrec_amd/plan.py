@@ -30,7 +30,11 @@ class SgdPlan(object):
             S.lib().mfx_sgd_plan_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:          # interpreter shutdown: the library may already be gone
+            pass
 
     def __enter__(self):
         return self

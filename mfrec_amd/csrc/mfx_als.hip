@@ -110,18 +110,28 @@ constexpr int CH2 = 32;                // neighbour rows per chunk
 
 // Diagnostic builds only (-DMFX_ALS_STAMPS): s_memtime at phase boundaries of the first rows.
 #ifdef MFX_ALS_STAMPS
-__device__ unsigned long long g_als_stamps[4096 * 8];
+__device__ unsigned long long g_als_stamps[4096 * 16];
 #define ALS_STAMP(i)                                                                        \
     do {                                                                                    \
         __syncthreads();                                                                    \
         if (threadIdx.x == 0 && blockIdx.x < 4096) {                                        \
             unsigned long long t_;                                                          \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");     \
-            g_als_stamps[blockIdx.x * 8 + (i)] = t_;                                        \
+            g_als_stamps[blockIdx.x * 16 + (i)] = t_;                                        \
+        }                                                                                   \
+    } while (0)
+// wave-local stamp (no barrier): thread 0 only
+#define ALS_STAMP_W0(i)                                                                     \
+    do {                                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) {                                        \
+            unsigned long long t_;                                                          \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");     \
+            g_als_stamps[blockIdx.x * 16 + (i)] = t_;                                       \
         }                                                                                   \
     } while (0)
 #else
 #define ALS_STAMP(i) do { } while (0)
+#define ALS_STAMP_W0(i) do { } while (0)
 #endif
 
 __device__ __forceinline__ void tile_ij(int tt, int &I, int &J)
@@ -147,6 +157,48 @@ __device__ __forceinline__ double rsqrt_nr(double d)
     const double h = 0.5 * d;
     y = y * (1.5 - h * y * y);
     y = y * (1.5 - h * y * y);
+    return y;
+}
+
+// ---- f64 DPP row_newbcast (gfx90a+): operand = lane N of the caller's own 16-lane row ----------
+// One VALU instruction replaces two v_readlane + the arithmetic.  All 64 lanes must be active.
+// "s_nop 1" covers the VALU-write -> DPP-read hazard, which the compiler cannot see inside asm.
+template <int N>
+__device__ __forceinline__ double dpp_bcast(double v)
+{
+    double r;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
+                 : "=v"(r) : "v"(v), "n"(N));
+    return r;
+}
+// acc -= l[lane N] * a  (fused).  NOP = false only where l was not written by the two
+// preceding instructions (a run of updates with the same l).
+template <int N, bool NOP = true>
+__device__ __forceinline__ void dpp_fnma(double &acc, double l, double a)
+{
+    if constexpr (NOP)
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                     : "+v"(acc) : "v"(l), "v"(a), "n"(N));
+    else
+        asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                     : "+v"(acc) : "v"(l), "v"(a), "n"(N));
+}
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+// 1/sqrt(d), fused Newton steps
+__device__ __forceinline__ double rsqrt_fma(double d)
+{
+    double y = __builtin_amdgcn_rsq(d);
+    double e = __builtin_fma(-(d * y), y, 1.0);
+    y = __builtin_fma(0.5 * y, e, y);
+    e = __builtin_fma(-(d * y), y, 1.0);
+    y = __builtin_fma(0.5 * y, e, y);
     return y;
 }
 
@@ -454,10 +506,350 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 ? 2 : (NT >= 5 ? 2 : 3))) void k_
     ALS_STAMP(4);
 }
 
+// ------------------------------------------------------------------------------------
+// rows3: the same algorithm with the lower-triangle tiles of A kept IN REGISTERS (MFMA C layout)
+// through the whole factorisation.  LDS then only holds the current 16-wide panel (Xs), the
+// factored diagonal blocks (Dg) and the right-hand side: 37 KB instead of 77 KB at k = 128, so
+// three workgroups share a CU and the serial phases of one row hide behind the MFMA phases of
+// the others.  Wave 0 owns the diagonal tiles (it also does the serial block factorisation),
+// waves 1-3 own the off-diagonal tiles column by column.  Used for k > 64.
+// ------------------------------------------------------------------------------------
+// Which wave holds which 16x16 tile of the lower block triangle.  Role 0: the diagonal tiles.
+// Roles 1-3: whole block rows (tiles of a row share their A operand), rows dealt greedily,
+// longest first, to the lightest role -- NT = 8: {7,2,1} {6,3} {5,4}.
+template <int NT>
+struct Rows3Map {
+    static constexpr int NOFF = NT * (NT - 1) / 2;
+    static constexpr int TS = NT > (NOFF + 2) / 3 + 1 ? NT : (NOFF + 2) / 3 + 1;
+    int I[4][TS] = {}, J[4][TS] = {}, n[4] = {};
+    constexpr Rows3Map()
+    {
+        for (int s = 0; s < NT; ++s) { I[0][s] = s; J[0][s] = s; }
+        n[0] = NT;
+        for (int r = NT - 1; r >= 1; --r) {
+            int g = 1;
+            for (int w = 2; w <= 3; ++w) if (n[w] < n[g]) g = w;
+            for (int c = 0; c < r; ++c) { I[g][n[g]] = r; J[g][n[g]] = c; ++n[g]; }
+        }
+    }
+    constexpr int slots(int role) const { return n[role]; }
+};
+
+template <int NT, int ROLE>
+__device__ __forceinline__ void als_rows3_body(const double *__restrict__ Y, int k,
+                                               const double *__restrict__ G,
+                                               const int64_t *__restrict__ off,
+                                               const int32_t *__restrict__ col, double c_pos,
+                                               double one_plus_c, double lambda, double *X,
+                                               int *status)
+{
+    constexpr int KP = NT * 16;
+    constexpr Rows3Map<NT> TM{};
+    constexpr int TS = TM.slots(ROLE);               // tile slots of this wave
+    constexpr int wid = ROLE;
+    constexpr int PF = CH2 * KP / 256;
+    constexpr int XS = 18;                           // row stride of Xs / Dg: conflict-free MFMA operands
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int S = ych_stride(KP);
+    const int stage_elems = CH2 * S;
+    const int region = (stage_elems > 2 * KP * XS ? stage_elems : 2 * KP * XS);
+    double *ych = lds;                               // SYRK staging; later:
+    double *Xs = lds;                                //   [KP][XS] current panel (rows below the block)
+    double *Dg = lds + KP * XS;                      //   [KP][XS] factored diagonal blocks, block J at rows 16J..
+    double *dinv = lds + region;                     // [KP]
+    double *bz = dinv + KP;                          // [KP] right-hand side -> z -> x
+    double *scratch = bz + KP;                       // [4][16]
+    int *cidx = (int *)(scratch + 64);               // [2][CH2]
+    int *bad = cidx + 2 * CH2;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int j = blockIdx.x;
+    const int64_t start = off[j];
+    const int span = (int)(off[j + 1] - start);
+    double *xrow = X + (size_t)j * k;
+    if (span == 0) {
+        for (int f = tid; f < k; f += 256) xrow[f] = 0.0;
+        return;
+    }
+    if (tid == 0) *bad = 0;
+
+#define sI(s) (TM.I[ROLE][s])
+#define sJ(s) (TM.J[ROLE][s])
+    const bool from_g = (c_pos != 0.0);
+    const double inv_c = from_g ? 1.0 / c_pos : 0.0;
+    double4_t acc[TS];
+#pragma unroll
+    for (int s = 0; s < TS; ++s) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = sI(s) * 16 + (lane >> 4) + 4 * q, c = sJ(s) * 16 + (lane & 15);
+            acc[s][q] = from_g ? G[r * KP + c] * inv_c : 0.0;
+        }
+    }
+    double bsum = 0.0;
+
+    ALS_STAMP(0);
+    // ---- Y_N^T Y_N and b (identical to rows2) ----------------------------------------------------
+    const int nchunks = (span + CH2 - 1) / CH2;
+    if (tid < CH2) cidx[tid] = (tid < span) ? col[start + tid] : -1;
+    __syncthreads();
+    double pre[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+        const int e = tid + 256 * i, n = e / KP, f = e % KP;
+        const int id = cidx[n];
+        pre[i] = (id >= 0 && f < k) ? Y[(size_t)id * k + f] : 0.0;
+    }
+    int cnext = (tid < CH2 && CH2 + tid < span) ? col[start + CH2 + tid] : -1;
+    for (int c = 0; c < nchunks; ++c) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int e = tid + 256 * i, n = e / KP, f = e % KP;
+            ych[n * S + f] = pre[i];
+        }
+        const int nb = ((c + 1) & 1) * CH2;
+        if (tid < CH2) cidx[nb + tid] = cnext;
+        __syncthreads();
+        if (c + 1 < nchunks) {
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const int e = tid + 256 * i, n = e / KP, f = e % KP;
+                const int id = cidx[nb + n];
+                pre[i] = (id >= 0 && f < k) ? Y[(size_t)id * k + f] : 0.0;
+            }
+            const int t2 = (c + 2) * CH2 + tid;
+            cnext = (tid < CH2 && t2 < span) ? col[start + t2] : -1;
+        }
+        if (tid < KP) {
+#pragma unroll
+            for (int n = 0; n < CH2; ++n) bsum += ych[n * S + tid] * one_plus_c;
+        }
+#pragma unroll
+        for (int n0 = 0; n0 < CH2; n0 += 4) {
+            const double *base = ych + (n0 + (lane >> 4)) * S + (lane & 15);
+#pragma unroll
+            for (int s = 0; s < TS; ++s)
+                                    acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(base[sI(s) * 16], base[sJ(s) * 16], acc[s], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    ALS_STAMP(1);
+    // ---- A = c * acc + lambda I (identity on the padding), in registers; b -> LDS -----------------
+#pragma unroll
+    for (int s = 0; s < TS; ++s) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = sI(s) * 16 + (lane >> 4) + 4 * q, c = sJ(s) * 16 + (lane & 15);
+            double a;
+            if (r < k && c < k) {
+                a = from_g ? acc[s][q] * c_pos : G[r * KP + c];
+                if (r == c) a += lambda;
+            } else {
+                a = (r == c) ? 1.0 : 0.0;
+            }
+            acc[s][q] = a;
+        }
+    }
+    if (tid < KP) bz[tid] = (tid < k) ? bsum : 0.0;
+
+    auto wave_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    // C-layout register tile -> Dg block Jd, then factor it in row-per-lane registers (wave 0)
+    auto factor_block = [&](const double4_t &t, int Jd) {
+        double *blk = Dg + Jd * 16 * XS;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) blk[((lane >> 4) + 4 * q) * XS + (lane & 15)] = t[q];
+        wave_sync();
+        const int r = lane & 15;
+        double d[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) d[c] = blk[r * XS + c];
+        double myinv = 1.0;
+        bool ok = true;
+        static_for<0, 16>([&](auto JJ) {
+            constexpr int jj = JJ;
+            const double pj = dpp_bcast<jj>(d[jj]);              // pivot, in every lane
+            ok = ok && (pj > 0.0);
+            const double inv = rsqrt_fma(pj);
+            if (r == jj) myinv = inv;
+            d[jj] *= inv;                                        // column jj of L (lane = row)
+            static_for<jj + 1, 16>([&](auto C) {                 // d[.][c] -= L[.][jj] * L[c][jj]
+                constexpr int c = C;
+                dpp_fnma<c, c == jj + 1>(d[c], d[jj], d[jj]);
+            });
+        });
+        wave_sync();                                 // all lanes have read the raw block
+        if (lane < 16) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                if (c <= r) blk[r * XS + c] = d[c];
+            dinv[Jd * 16 + r] = myinv;
+        }
+        if (!ok && lane == 0) *bad = 1;
+    };
+    auto trailing_reg = [&](double4_t &t, int I, int J2) {
+        const double *pa = Xs + (I * 16 + (lane & 15)) * XS + (lane >> 4);
+        const double *pb = Xs + (J2 * 16 + (lane & 15)) * XS + (lane >> 4);
+#pragma unroll
+        for (int s4 = 0; s4 < 16; s4 += 4)
+            t = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[s4], pb[s4], t, 0, 0, 0);
+    };
+
+    ALS_STAMP(2);
+    // ---- blocked Cholesky on the register tiles ----------------------------------------------------
+    if constexpr (wid == 0) factor_block(acc[0], 0);
+#pragma unroll
+    for (int Jb = 0; Jb < NT; ++Jb) {
+        const int c0 = Jb * 16;
+        __syncthreads();                             // Dg[Jb], dinv ready; Xs free
+        if (Jb == 0) ALS_STAMP_W0(5);
+        if (Jb == 1) ALS_STAMP_W0(11);
+        if constexpr (wid != 0) {
+#pragma unroll
+            for (int s = 0; s < TS; ++s)
+                if (sJ(s) == Jb) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        Xs[(sI(s) * 16 + (lane >> 4) + 4 * q) * XS + (lane & 15)] = acc[s][q];
+                }
+        }
+        __syncthreads();
+        if (Jb == 0) ALS_STAMP_W0(6);
+        // panel rows and the border row: x = a * L11^{-T}, one lane per row.  L11 sits in registers,
+        // lane = its row, and reaches the other lanes by DPP broadcast (every lane of a taking-part
+        // wave stays active: surplus lanes redo the border row and skip the store).
+        if (c0 + 16 + wid * 64 <= KP) {                  // wave-uniform
+            const int pr = c0 + 16 + tid;
+            const bool mine = pr <= KP;
+            double *row = (pr < KP) ? Xs + pr * XS : bz + c0;
+            const double *L11 = Dg + (c0 + (lane & 15)) * XS;
+            double Lr[16], a[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) Lr[c] = L11[c];
+            const double dv = dinv[c0 + (lane & 15)];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) a[c] = row[c];
+            static_for<0, 16>([&](auto JJ) {
+                constexpr int jj = JJ;
+                a[jj] *= dpp_bcast<jj>(dv);
+                static_for<jj + 1, 16>([&](auto M) {             // a[m] -= L[m][jj] * x_jj
+                    constexpr int m = M;
+                    dpp_fnma<m, false>(a[m], Lr[jj], a[jj]);
+                });
+            });
+            if (mine) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) row[c] = a[c];
+            }
+        }
+        if (Jb == 0) ALS_STAMP_W0(7);
+        __syncthreads();
+        if (Jb == 0) ALS_STAMP_W0(8);
+        {   // border row of the trailing update
+            const int c = c0 + 16 + tid;
+            if (c < KP) {
+                double sum = 0.0;
+#pragma unroll
+                for (int m = 0; m < 16; ++m) sum += bz[c0 + m] * Xs[c * XS + m];
+                bz[c] -= sum;
+            }
+        }
+        if constexpr (wid != 0) {
+#pragma unroll
+            for (int s = 0; s < TS; ++s) {
+                if (sJ(s) == Jb) {         // the solved panel tile comes back to registers
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        acc[s][q] = Xs[(sI(s) * 16 + (lane >> 4) + 4 * q) * XS + (lane & 15)];
+                } else if (sJ(s) > Jb) {
+                    trailing_reg(acc[s], sI(s), sJ(s));
+                }
+            }
+        } else if (Jb + 1 < NT) {   // role 0
+            trailing_reg(acc[Jb + 1], Jb + 1, Jb + 1);   // next diagonal tile first ...
+            if (Jb == 0) ALS_STAMP_W0(9);
+            factor_block(acc[Jb + 1], Jb + 1);           // ... and factor it while waves 1-3 update
+            if (Jb == 0) ALS_STAMP_W0(10);
+#pragma unroll
+            for (int J2 = Jb + 2; J2 < NT; ++J2) trailing_reg(acc[J2], J2, J2);
+        }
+    }
+    __syncthreads();
+    if (*bad) {
+        if (tid == 0) atomicExch(status, j + 1);
+        return;
+    }
+
+    ALS_STAMP(3);
+    // ---- back substitution: x_J = L_JJ^{-T} (z_J - sum_{I>J} L_IJ^T x_I), L_IJ in registers -------
+#pragma unroll
+    for (int Jb = NT - 1; Jb >= 0; --Jb) {
+        const int c0 = Jb * 16;
+        double cs = 0.0;
+        if constexpr (wid != 0) {
+#pragma unroll
+            for (int s = 0; s < TS; ++s)
+                if (sJ(s) == Jb) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) cs += acc[s][q] * bz[sI(s) * 16 + (lane >> 4) + 4 * q];
+                }
+        }
+        {
+            int lo = __double2loint(cs), hi = __double2hiint(cs);
+            cs += __hiloint2double(__shfl_xor(hi, 16, 64), __shfl_xor(lo, 16, 64));
+            lo = __double2loint(cs); hi = __double2hiint(cs);
+            cs += __hiloint2double(__shfl_xor(hi, 32, 64), __shfl_xor(lo, 32, 64));
+        }
+        if (lane < 16) scratch[wid * 16 + lane] = cs;
+        __syncthreads();
+        if constexpr (wid == 0) {
+            const int m = lane & 15;
+            double rhs = bz[c0 + m] - scratch[16 + m] - scratch[32 + m] - scratch[48 + m];
+            double Lc[16];                                       // lane = column m of L11
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) Lc[jj] = Dg[(c0 + jj) * XS + m];
+            const double dv = dinv[c0 + m];
+            static_for<0, 16>([&](auto T) {
+                constexpr int jj = 15 - T;
+                const double x = dpp_bcast<jj>(rhs) * dpp_bcast<jj>(dv);
+                const double upd = __builtin_fma(-Lc[jj], x, rhs);
+                rhs = (m < jj) ? upd : (m == jj ? x : rhs);
+            });
+            if (lane < 16) bz[c0 + lane] = rhs;
+        }
+        __syncthreads();
+    }
+    ALS_STAMP(4);
+    for (int f = tid; f < k; f += 256) xrow[f] = bz[f];
+}
+#undef sI
+#undef sJ
+
+template <int NT, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_als_rows3(const double *__restrict__ Y, int k,
+                                                      const double *__restrict__ G,
+                                                      const int64_t *__restrict__ off,
+                                                      const int32_t *__restrict__ col, double c_pos,
+                                                      double one_plus_c, double lambda, double *X,
+                                                      int *status)
+{
+    // every wave runs the same sequence of barriers; only its tile set differs
+    switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
+    case 0: als_rows3_body<NT, 0>(Y, k, G, off, col, c_pos, one_plus_c, lambda, X, status); break;
+    case 1: als_rows3_body<NT, 1>(Y, k, G, off, col, c_pos, one_plus_c, lambda, X, status); break;
+    case 2: als_rows3_body<NT, 2>(Y, k, G, off, col, c_pos, one_plus_c, lambda, X, status); break;
+    default: als_rows3_body<NT, 3>(Y, k, G, off, col, c_pos, one_plus_c, lambda, X, status); break;
+    }
+}
+
 #ifdef MFX_ALS_STAMPS
 extern "C" int mfx_debug_als_stamps(unsigned long long *out)
 {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_als_stamps), sizeof(unsigned long long) * 4096 * 8) == hipSuccess ? 0 : -4;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_als_stamps), sizeof(unsigned long long) * 4096 * 16) == hipSuccess ? 0 : -4;
 }
 #endif
 
@@ -482,7 +874,14 @@ struct AlsKernels {
     void *gram;
     void *rows2;
     int rows_waves;     // waves per workgroup of the row kernel
+    bool reg_tiles = false;   // k_als_rows3: tiles in registers, small LDS
 };
+
+size_t rows3_lds_bytes(int KP)
+{
+    const size_t st = (size_t)CH2 * ych_stride(KP), xd = (size_t)2 * KP * 18;
+    return ((st > xd ? st : xd) + 2 * KP + 64) * sizeof(double) + (2 * CH2 + 2) * sizeof(int);
+}
 
 template <int NT>
 AlsKernels als_kernels_nt()
@@ -494,6 +893,15 @@ AlsKernels als_kernels_nt()
         if (nw == 1) return {(void *)k_gram_partial<NT>, (void *)k_als_rows2<NT, 1>, 1};
         if (nw == 4) return {(void *)k_gram_partial<NT>, (void *)k_als_rows2<NT, 4>, 4};
         return {(void *)k_gram_partial<NT>, (void *)k_als_rows2<NT, 2>, 2};
+    } else if constexpr (NT >= 5) {
+        const char *e = getenv("MFX_ALS_ROWS2");              // tuning / cross-check hook
+        if (e && e[0] == '1') return {(void *)k_gram_partial<NT>, (void *)k_als_rows2<NT, 4>, 4, false};
+        // occupancy hint: k = 128 needs the cap to fit three workgroups per CU; below that the
+        // kernel fits anyway and the uncapped schedule measured 4 % faster
+        const char *o = getenv("MFX_ALS_OCC");
+        const bool occ3 = o ? o[0] == '3' : NT == 8;
+        if (!occ3) return {(void *)k_gram_partial<NT>, (void *)k_als_rows3<NT, 2>, 4, true};
+        return {(void *)k_gram_partial<NT>, (void *)k_als_rows3<NT, 3>, 4, true};
     } else return {(void *)k_gram_partial<NT>, (void *)k_als_rows2<NT, 4>, 4};
 }
 
@@ -560,7 +968,7 @@ int als_half(int k, int NT, const AlsKernels &K, const double *dY, int ny, doubl
         MFX_HIP(hipGetLastError());
     }
     if (n_active > 0) {
-        const size_t lds = rows2_lds_bytes(KP);
+        const size_t lds = K.reg_tiles ? rows3_lds_bytes(KP) : rows2_lds_bytes(KP);
         void *rows_fn = K.rows2;
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute(rows_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -577,7 +577,7 @@ __device__ __forceinline__ void als_rows3_body(const double *__restrict__ Y, int
 #define sJ(s) (TM.J[ROLE][s])
     const bool from_g = (c_pos != 0.0);
     const double inv_c = from_g ? 1.0 / c_pos : 0.0;
-    double4_t acc[TS];
+    double4_t acc[TS > 0 ? TS : 1];
 #pragma unroll
     for (int s = 0; s < TS; ++s) {
 #pragma unroll
@@ -670,17 +670,24 @@ __device__ __forceinline__ void als_rows3_body(const double *__restrict__ Y, int
         for (int c = 0; c < 16; ++c) d[c] = blk[r * XS + c];
         double myinv = 1.0;
         bool ok = true;
+        // software-pipelined: the next pivot's rsqrt chain starts as soon as its column is
+        // updated and runs under the remaining updates of the current step
+        double pj = dpp_bcast<0>(d[0]);
+        double inv = rsqrt_fma(pj);
         static_for<0, 16>([&](auto JJ) {
             constexpr int jj = JJ;
-            const double pj = dpp_bcast<jj>(d[jj]);              // pivot, in every lane
             ok = ok && (pj > 0.0);
-            const double inv = rsqrt_fma(pj);
             if (r == jj) myinv = inv;
             d[jj] *= inv;                                        // column jj of L (lane = row)
-            static_for<jj + 1, 16>([&](auto C) {                 // d[.][c] -= L[.][jj] * L[c][jj]
-                constexpr int c = C;
-                dpp_fnma<c, c == jj + 1>(d[c], d[jj], d[jj]);
-            });
+            if constexpr (jj < 15) {
+                dpp_fnma<jj + 1>(d[jj + 1], d[jj], d[jj]);       // d[.][c] -= L[.][jj] * L[c][jj]
+                pj = dpp_bcast<jj + 1>(d[jj + 1]);
+                inv = rsqrt_fma(pj);
+                static_for<jj + 2, 16>([&](auto C) {
+                    constexpr int c = C;
+                    dpp_fnma<c, false>(d[c], d[jj], d[jj]);
+                });
+            }
         });
         wave_sync();                                 // all lanes have read the raw block
         if (lane < 16) {
@@ -749,8 +756,8 @@ __device__ __forceinline__ void als_rows3_body(const double *__restrict__ Y, int
         if (Jb == 0) ALS_STAMP_W0(7);
         __syncthreads();
         if (Jb == 0) ALS_STAMP_W0(8);
-        {   // border row of the trailing update
-            const int c = c0 + 16 + tid;
+        if constexpr (wid >= 2) {   // border row of the trailing update (waves 2-3: off wave 0's chain)
+            const int c = c0 + 16 + tid - 128;
             if (c < KP) {
                 double sum = 0.0;
 #pragma unroll
@@ -893,13 +900,13 @@ AlsKernels als_kernels_nt()
         if (nw == 1) return {(void *)k_gram_partial<NT>, (void *)k_als_rows2<NT, 1>, 1};
         if (nw == 4) return {(void *)k_gram_partial<NT>, (void *)k_als_rows2<NT, 4>, 4};
         return {(void *)k_gram_partial<NT>, (void *)k_als_rows2<NT, 2>, 2};
-    } else if constexpr (NT >= 5) {
+    } else if constexpr (NT >= 5 || NT == 3) {
         const char *e = getenv("MFX_ALS_ROWS2");              // tuning / cross-check hook
         if (e && e[0] == '1') return {(void *)k_gram_partial<NT>, (void *)k_als_rows2<NT, 4>, 4, false};
         // occupancy hint: k = 128 needs the cap to fit three workgroups per CU; below that the
         // kernel fits anyway and the uncapped schedule measured 4 % faster
         const char *o = getenv("MFX_ALS_OCC");
-        const bool occ3 = o ? o[0] == '3' : NT == 8;
+        const bool occ3 = o ? o[0] == '3' : (NT == 8 || NT <= 4);
         if (!occ3) return {(void *)k_gram_partial<NT>, (void *)k_als_rows3<NT, 2>, 4, true};
         return {(void *)k_gram_partial<NT>, (void *)k_als_rows3<NT, 3>, 4, true};
     } else return {(void *)k_gram_partial<NT>, (void *)k_als_rows2<NT, 4>, 4};

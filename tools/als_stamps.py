@@ -23,6 +23,7 @@ als_wrmf(1, k, u, v, None, None, urow, ucol, irow, icol, nu, ni)
 st = np.zeros(4096 * 16, dtype=np.uint64)
 assert S.lib().mfx_debug_als_stamps(st.ctypes.data_as(C.c_void_p)) == 0
 st = st.reshape(4096, 16).astype(np.float64)
+st = st[st[:, 4] > 0]                                   # workgroups that ran
 d = np.diff(st[:, :5], axis=1)
 print("k=%d, last launch (rows of degree ~%d): median ticks  syrk+gather %.0f | write A %.0f | cholesky %.0f | back-subst %.0f | total %.0f"
       % ((k, nnz // ni) + tuple(np.median(d, axis=0)) + (np.median(st[:, 4] - st[:, 0]),)))

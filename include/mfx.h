@@ -68,6 +68,12 @@ double mfx_last_compute_ms(void);
  */
 int mfx_schedule_levels(const int32_t *ratings_index, int64_t nnz, int nu, int ni,
                         int32_t *level_out, int64_t *n_levels_out);
+/* The same levels computed on the GPU (host arrays in and out): radix-sorted user / item chains +
+ * one frontier launch per level (replaces the marshalling loops of
+ * base.py:1115-1131 at sizes where the sequential host pass dominates).  nnz < 2^31, at most 2^22
+ * levels.  Result identical to mfx_schedule_levels. */
+int mfx_schedule_levels_gpu(const int32_t *ratings_index, int64_t nnz, int nu, int ni,
+                            int32_t *level_out, int64_t *n_levels_out);
 int mfx_schedule_permutation(const int32_t *level, int64_t nnz, int64_t n_levels,
                              int64_t *perm_out, int64_t *level_off_out);
 /* The same ordering applied directly: recs_out[j] = 16-byte record {int32 user, int32 item,
@@ -162,6 +168,15 @@ typedef struct mfx_sgd_plan mfx_sgd_plan;
 
 mfx_sgd_plan *mfx_sgd_plan_create(const int32_t *ratings_index, const double *ratings,
                                   int64_t nnz, int nu, int ni, int dim);
+/* The same with the schedule builder chosen: MFX_SCHED_HOST (mfx_schedule_levels + _pack, then one
+ * upload), MFX_SCHED_DEVICE (raw arrays uploaded, levels + level-major records built in HBM; fails
+ * beyond 2^22 levels) or MFX_SCHED_AUTO (device from 2^20 ratings on, falling back to the host when
+ * the data needs more than nnz/1000 levels).  Both builders give the same records in the same order. */
+enum { MFX_SCHED_AUTO = 0, MFX_SCHED_HOST = 1, MFX_SCHED_DEVICE = 2 };
+mfx_sgd_plan *mfx_sgd_plan_create2(const int32_t *ratings_index, const double *ratings,
+                                   int64_t nnz, int nu, int ni, int dim, int sched);
+/* MFX_SCHED_HOST or MFX_SCHED_DEVICE: which builder produced this plan's schedule */
+int mfx_sgd_plan_schedule_builder(const mfx_sgd_plan *p);
 void mfx_sgd_plan_destroy(mfx_sgd_plan *p);
 /* info[0]=n_levels, [1]=max level size, [2]=launches per epoch (full-k), [3]=tail launches,
  * [4]=ratings per wave batch, [5]=device bytes held, [6]=schedule build microseconds,

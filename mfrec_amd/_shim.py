@@ -33,6 +33,7 @@ SIGNATURES = {
     "mfx_timer_stop": (C.c_int, [_dp]),
     "mfx_last_compute_ms": (C.c_double, []),
     "mfx_schedule_levels": (C.c_int, [_ip, C.c_int64, C.c_int, C.c_int, _ip, _lp]),
+    "mfx_schedule_levels_gpu": (C.c_int, [_ip, C.c_int64, C.c_int, C.c_int, _ip, _lp]),
     "mfx_schedule_permutation": (C.c_int, [_ip, C.c_int64, C.c_int64, _lp, _lp]),
     "mfx_schedule_pack": (C.c_int, [_ip, _dp, _ip, C.c_int64, C.c_int64, C.c_void_p, _lp]),
     "mfx_schedule_balanced_order": (C.c_int, [_ip, C.c_int64, C.c_int, C.c_int, C.c_uint64, _lp, _lp]),
@@ -60,6 +61,8 @@ SIGNATURES = {
     "mfx_predict_rmse": (C.c_int, [C.c_int, C.c_int, _dp, _dp, _ip, _dp, _dp, _dp, C.c_double,
                                    C.c_int64, C.c_int, C.c_int, _dp, _dp]),
     "mfx_sgd_plan_create": (C.c_void_p, [_ip, _dp, C.c_int64, C.c_int, C.c_int, C.c_int]),
+    "mfx_sgd_plan_create2": (C.c_void_p, [_ip, _dp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mfx_sgd_plan_schedule_builder": (C.c_int, [C.c_void_p]),
     "mfx_sgd_plan_destroy": (None, [C.c_void_p]),
     "mfx_sgd_plan_info": (C.c_int, [C.c_void_p, _lp]),
     "mfx_sgd_plan_set_storage": (C.c_int, [C.c_void_p, C.c_int]),

@@ -25,6 +25,12 @@ void set_last_compute_ms(double ms);
         }                                                                               \
     } while (0)
 
+struct Rec {        // one rating in level-major order: 16 B, one dwordx4 load
+    int32_t user;
+    int32_t item;
+    double r;
+};
+
 template <typename T>
 static inline T ceil_div(T a, T b) { return (a + b - 1) / b; }
 

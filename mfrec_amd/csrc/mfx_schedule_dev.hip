@@ -1,0 +1,275 @@
+// Device-side dependency-level schedule: the same levels and the
+// same level-major record order as the host builder (mfx_schedule.cpp), computed on the GPU
+// straight from the (user, item, rating) arrays.
+//
+//   level(t) = 1 + max(level(previous rating of the same user), level(previous rating of the same item))
+//
+// is a longest-path layering of a DAG in which every node has at most two predecessors and two
+// successors (its neighbours in the user's chain and in the item's chain).  Steps:
+//   1. stable radix sort of t by user, and of t by item  -> the chains (next_u, next_i, in-degree)
+//   2. Kahn's algorithm, one launch per level: a rating joins the frontier when its last
+//      predecessor has been levelled; cost O(nnz) in total, ~3 us per level
+//   3. stable radix sort of t by level -> level-major order, ascending t inside a level (the order
+//      of the host's stable counting sort), gather into the 16-byte records
+// The host pass is sequential (3 ns per rating, cache-missing); this one wins while the level count
+// stays below ~nnz/1000 and gives up (caller falls back to the host) beyond a level budget, which
+// is what heavily skewed data (a user with 10^5 ratings) produces.
+// Radix sort: hipCUB (rocPRIM) DeviceRadixSort -- a library primitive, not part of the hot path.
+#include <hipcub/hipcub.hpp>
+#include <vector>
+#include "mfx_common.h"
+
+namespace mfx {
+namespace {
+
+constexpr int kBfsBlocks = 1024;
+constexpr int kBfsThreads = 256;
+
+__global__ void k_split_check(const int2 *__restrict__ idx, int64_t nnz, int nu, int ni,
+                              int32_t *users, int32_t *items, int32_t *tvals,
+                              unsigned long long *first_bad)
+{
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < nnz;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int2 p = idx[t];
+        users[t] = p.x;
+        items[t] = p.y;
+        tvals[t] = (int32_t)t;
+        if (p.x < 0 || p.x >= nu || p.y < 0 || p.y >= ni) atomicMin(first_bad, (unsigned long long)t);
+    }
+}
+
+// sorted (key, t) pairs -> chain links.  Thread p owns t = vals[p], so no two threads write the
+// same slot; the second call (items) adds to the in-degree the first one stored.
+__global__ void k_link(const int32_t *__restrict__ keys, const int32_t *__restrict__ vals,
+                       int64_t nnz, int32_t *next, int32_t *indeg, int first)
+{
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < nnz;
+         p += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t key = keys[p], t = vals[p];
+        const int pred = (p > 0 && keys[p - 1] == key) ? 1 : 0;
+        next[t] = (p + 1 < nnz && keys[p + 1] == key) ? vals[p + 1] : -1;
+        indeg[t] = first ? pred : indeg[t] + pred;
+    }
+}
+
+// append with one atomic per wave
+__device__ __forceinline__ void push(int32_t *out, unsigned long long *cnt, bool have, int32_t v)
+{
+    const unsigned long long m = __ballot(have);
+    if (!m) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(cnt, (unsigned long long)__popcll(m));
+    base = __shfl(base, leader, 64);
+    if (have) out[base + __popcll(m & ((1ull << lane) - 1))] = v;
+}
+
+__global__ void k_seed(const int32_t *__restrict__ indeg, int64_t nnz, int32_t *out,
+                       unsigned long long *cnt)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t rounds = (nnz + stride - 1) / stride;          // whole waves stay together
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    for (int64_t i = 0; i < rounds; ++i, t += stride) {
+        const bool have = t < nnz && indeg[t] == 0;
+        push(out, cnt, have, (int32_t)t);
+    }
+}
+
+// one level of Kahn's algorithm.  cnt[3] rotate: read cnt[L%3], append to cnt[(L+1)%3], clear
+// cnt[(L+2)%3] (read by the previous launch, appended to by the next).
+__global__ void k_bfs_level(int32_t L, const int32_t *__restrict__ fr_in, int32_t *fr_out,
+                            unsigned long long *cnt, const int32_t *__restrict__ next_u,
+                            const int32_t *__restrict__ next_i, int32_t *indeg, int32_t *level,
+                            unsigned long long *sizes, unsigned long long *total)
+{
+    const unsigned long long n = cnt[L % 3];
+    unsigned long long *cnt_out = cnt + (L + 1) % 3;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sizes[L - 1] = n;
+        *total += n;
+        cnt[(L + 2) % 3] = 0;
+    }
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t rounds = ((int64_t)n + stride - 1) / stride;
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    for (int64_t q = 0; q < rounds; ++q, i += stride) {
+        int32_t a = -1, b = -1;
+        if (i < (int64_t)n) {
+            const int32_t t = fr_in[i];
+            level[t] = L;
+            a = next_u[t];
+            b = next_i[t];
+            if (a >= 0 && atomicSub(&indeg[a], 1) != 1) a = -1;
+            if (b >= 0 && atomicSub(&indeg[b], 1) != 1) b = -1;
+        }
+        push(fr_out, cnt_out, a >= 0, a);
+        push(fr_out, cnt_out, b >= 0, b);
+    }
+}
+
+__global__ void k_gather_recs(const int32_t *__restrict__ order, const int2 *__restrict__ idx,
+                              const double *__restrict__ r, int64_t nnz, Rec *recs)
+{
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < nnz;
+         p += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t t = order[p];
+        const int2 q = idx[t];
+        Rec o;
+        o.user = q.x;
+        o.item = q.y;
+        o.r = r[t];
+        recs[p] = o;
+    }
+}
+
+int bits_for(int64_t n)      // radix bits that cover keys 0 .. n-1
+{
+    int b = 1;
+    while (b < 32 && ((int64_t)1 << b) < n) ++b;
+    return b;
+}
+
+struct Scratch {
+    std::vector<void *> ptrs;
+    ~Scratch()
+    {
+        for (void *p : ptrs) (void)hipFree(p);
+    }
+    template <typename T>
+    int get(T **out, size_t n)
+    {
+        void *q = nullptr;
+        if (hipMalloc(&q, (n ? n : 1) * sizeof(T)) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(MFX_E_NOMEM, "device schedule: out of device memory (%zu bytes)", n * sizeof(T));
+        }
+        ptrs.push_back(q);
+        *out = (T *)q;
+        return MFX_OK;
+    }
+};
+
+}  // namespace
+
+// Returns MFX_OK and fills level_off (n_levels + 1 entries, level l+1 = [level_off[l], level_off[l+1]))
+// and, when given, d_recs (device, nnz records, level-major) and h_level (host, nnz entries, 1-based).
+// *over_budget = true (with MFX_OK) when the level count exceeded level_budget: nothing was produced.
+int schedule_device(const int32_t *h_idx, const double *h_r, int64_t nnz, int nu, int ni,
+                    Rec *d_recs, int32_t *h_level, std::vector<int64_t> &level_off,
+                    int64_t *n_levels, int64_t level_budget, bool *over_budget)
+{
+    *over_budget = false;
+    *n_levels = 0;
+    level_off.assign(1, 0);
+    if (nnz == 0) return MFX_OK;
+    if (nnz >= ((int64_t)1 << 31) - 1)
+        return fail(MFX_E_ARG, "device schedule: nnz must be < 2^31 (use the host builder)");
+    if (level_budget < 1) level_budget = 1;
+    hipStream_t st = stream();
+    Scratch S;
+    int2 *d_idx = nullptr;
+    double *d_r = nullptr;
+    int32_t *users, *items, *tvals, *ka, *va, *next_u, *next_i, *indeg, *level, *fr2;
+    unsigned long long *ctl, *sizes;
+    const size_t n = (size_t)nnz;
+    if (S.get(&d_idx, n) || S.get(&users, n) || S.get(&items, n) || S.get(&tvals, n) || S.get(&ka, n) ||
+        S.get(&va, n) || S.get(&next_u, n) || S.get(&next_i, n) || S.get(&indeg, n) ||
+        S.get(&level, n) || S.get(&fr2, n) || S.get(&ctl, 8) || S.get(&sizes, (size_t)level_budget + 1))
+        return last_code();
+    if (d_recs && S.get(&d_r, n)) return last_code();
+    MFX_HIP(hipMemcpyAsync(d_idx, h_idx, n * sizeof(int2), hipMemcpyHostToDevice, st));
+    if (d_recs) MFX_HIP(hipMemcpyAsync(d_r, h_r, n * sizeof(double), hipMemcpyHostToDevice, st));
+    // ctl: [0..2] frontier counters, [3] total levelled, [4] first out-of-range rating
+    MFX_HIP(hipMemsetAsync(ctl, 0, 8 * sizeof(unsigned long long), st));
+    MFX_HIP(hipMemsetAsync(ctl + 4, 0xff, sizeof(unsigned long long), st));
+    const int blocks = (int)std::min<int64_t>(ceil_div<int64_t>(nnz, kBfsThreads), 8192);
+    k_split_check<<<blocks, kBfsThreads, 0, st>>>(d_idx, nnz, nu, ni, users, items, tvals, ctl + 4);
+    unsigned long long bad = 0;
+    MFX_HIP(hipMemcpyAsync(&bad, ctl + 4, sizeof bad, hipMemcpyDeviceToHost, st));
+    MFX_HIP(hipStreamSynchronize(st));
+    if (bad != ~0ull) {
+        const int32_t a = h_idx[2 * bad], b = h_idx[2 * bad + 1];
+        return fail(MFX_E_RANGE, "rating %llu: (user %d, item %d) outside [0,%d) x [0,%d)", bad, a, b, nu, ni);
+    }
+
+    // ---- chains -------------------------------------------------------------------------------
+    size_t tmp_bytes = 0, tb2 = 0;
+    MFX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, users, ka, tvals, va, (int)nnz, 0, 32, st));
+    MFX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, level, ka, tvals, va, (int)nnz, 0, 32, st));
+    if (tb2 > tmp_bytes) tmp_bytes = tb2;
+    char *tmp = nullptr;
+    if (S.get(&tmp, tmp_bytes)) return last_code();
+    MFX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, users, ka, tvals, va, (int)nnz, 0, bits_for(nu), st));
+    k_link<<<blocks, kBfsThreads, 0, st>>>(ka, va, nnz, next_u, indeg, 1);
+    MFX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, items, ka, tvals, va, (int)nnz, 0, bits_for(ni), st));
+    k_link<<<blocks, kBfsThreads, 0, st>>>(ka, va, nnz, next_i, indeg, 0);
+
+    // ---- levels (frontier buffers rotate over ka / va / fr2, like the counters) ----------------
+    int32_t *fr[3] = {fr2, ka, va};          // level L reads fr[L%3], writes fr[(L+1)%3]
+    k_seed<<<blocks, kBfsThreads, 0, st>>>(indeg, nnz, fr[1], ctl + 1);
+    int64_t L = 1;
+    unsigned long long total = 0;
+    while (true) {
+        int64_t batch = 128;
+        if (L + batch > level_budget + 1) batch = level_budget + 1 - L;
+        for (int64_t q = 0; q < batch; ++q, ++L)
+            k_bfs_level<<<kBfsBlocks, kBfsThreads, 0, st>>>((int32_t)L, fr[L % 3], fr[(L + 1) % 3], ctl,
+                                                             next_u, next_i, indeg, level, sizes, ctl + 3);
+        MFX_HIP(hipMemcpyAsync(&total, ctl + 3, sizeof total, hipMemcpyDeviceToHost, st));
+        MFX_HIP(hipStreamSynchronize(st));
+        if ((int64_t)total >= nnz) break;
+        if (L > level_budget) {
+            *over_budget = true;
+            return MFX_OK;
+        }
+    }
+    std::vector<unsigned long long> hs((size_t)(L - 1));
+    MFX_HIP(hipMemcpy(hs.data(), sizes, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    int64_t nl = 0;
+    while (nl < (int64_t)hs.size() && hs[(size_t)nl] > 0) ++nl;
+    level_off.assign((size_t)nl + 1, 0);
+    for (int64_t l = 0; l < nl; ++l) level_off[(size_t)l + 1] = level_off[(size_t)l] + (int64_t)hs[(size_t)l];
+    if (level_off[(size_t)nl] != nnz)
+        return fail(MFX_E_STATE, "device schedule: levelled %lld of %lld ratings", (long long)level_off[(size_t)nl],
+                    (long long)nnz);
+    *n_levels = nl;
+    if (h_level) MFX_HIP(hipMemcpyAsync(h_level, level, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+
+    // ---- level-major order and records -----------------------------------------------------------
+    if (d_recs) {
+        MFX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, level, ka, tvals, va, (int)nnz, 0,
+                                                   bits_for(nl + 1), st));
+        k_gather_recs<<<blocks, kBfsThreads, 0, st>>>(va, d_idx, d_r, nnz, d_recs);
+    }
+    MFX_HIP(hipGetLastError());
+    MFX_HIP(hipStreamSynchronize(st));
+    return MFX_OK;
+}
+
+}  // namespace mfx
+
+// include/mfx.h: the GPU counterpart of mfx_schedule_levels (same arguments, same result)
+extern "C" int mfx_schedule_levels_gpu(const int32_t *idx, int64_t nnz, int nu, int ni,
+                                       int32_t *level_out, int64_t *n_levels_out)
+{
+    if (!idx || !level_out || nnz < 0 || nu <= 0 || ni <= 0)
+        return mfx::fail(MFX_E_ARG, "mfx_schedule_levels_gpu: bad argument");
+    if (mfx::ensure_init()) return mfx::last_code();
+    std::vector<int64_t> off;
+    int64_t nl = 0;
+    bool over = false;
+    try {
+        const int64_t cap = (int64_t)1 << 22;
+        const int rc = mfx::schedule_device(idx, nullptr, nnz, nu, ni, nullptr, level_out, off, &nl,
+                                            nnz < cap ? (nnz > 0 ? nnz : 1) : cap, &over);
+        if (rc) return rc;
+        if (over) return mfx::fail(MFX_E_STATE, "mfx_schedule_levels_gpu: more than %lld levels; use mfx_schedule_levels", (long long)cap);
+    } catch (const std::bad_alloc &) {
+        return mfx::fail(MFX_E_NOMEM, "mfx_schedule_levels_gpu: out of host memory");
+    }
+    if (n_levels_out) *n_levels_out = nl;
+    return MFX_OK;
+}

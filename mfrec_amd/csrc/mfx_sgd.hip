@@ -10,6 +10,12 @@
 
 using namespace mfx;
 
+namespace mfx {
+int schedule_device(const int32_t *h_idx, const double *h_r, int64_t nnz, int nu, int ni, Rec *d_recs,
+                    int32_t *h_level, std::vector<int64_t> &level_off, int64_t *n_levels,
+                    int64_t level_budget, bool *over_budget);   // mfx_schedule_dev.hip
+}
+
 // ------------------------------------------------------------------------------------
 // plan
 // ------------------------------------------------------------------------------------
@@ -31,6 +37,7 @@ struct mfx_sgd_plan {
     std::vector<int64_t> k2_wave_off;    // per level (Funk kernels)
     int64_t k1_waves = 0, k2_waves = 0;
     int64_t sched_us = 0;
+    bool sched_device = false;   // schedule built by mfx_schedule_dev.hip
     size_t dev_bytes = 0;
 
     Rec *d_recs = nullptr;               // level-major
@@ -381,10 +388,21 @@ extern "C" {
 mfx_sgd_plan *mfx_sgd_plan_create(const int32_t *idx, const double *r, int64_t nnz, int nu, int ni,
                                   int dim)
 {
-    if (!idx || !r || nnz < 0 || nu <= 0 || ni <= 0 || dim < 1 || dim > kMaxK) {
-        fail(MFX_E_ARG, "mfx_sgd_plan_create: bad argument (nnz=%lld nu=%d ni=%d k=%d; 1 <= k <= %d)",
-             (long long)nnz, nu, ni, dim, kMaxK);
+    return mfx_sgd_plan_create2(idx, r, nnz, nu, ni, dim, MFX_SCHED_AUTO);
+}
+
+mfx_sgd_plan *mfx_sgd_plan_create2(const int32_t *idx, const double *r, int64_t nnz, int nu, int ni,
+                                   int dim, int sched)
+{
+    if (!idx || !r || nnz < 0 || nu <= 0 || ni <= 0 || dim < 1 || dim > kMaxK ||
+        sched < MFX_SCHED_AUTO || sched > MFX_SCHED_DEVICE) {
+        fail(MFX_E_ARG, "mfx_sgd_plan_create: bad argument (nnz=%lld nu=%d ni=%d k=%d sched=%d; 1 <= k <= %d)",
+             (long long)nnz, nu, ni, dim, sched, kMaxK);
         return nullptr;
+    }
+    if (const char *e = getenv("MFX_SCHED")) {               // tuning / test hook
+        if (e[0] == 'h') sched = MFX_SCHED_HOST;
+        else if (e[0] == 'd') sched = MFX_SCHED_DEVICE;
     }
     if (ensure_init()) return nullptr;
     mfx_sgd_plan *p = new (std::nothrow) mfx_sgd_plan();
@@ -403,13 +421,39 @@ mfx_sgd_plan *mfx_sgd_plan_create(const int32_t *idx, const double *r, int64_t n
     };
     try {
         const auto t0 = std::chrono::steady_clock::now();
-        std::vector<int32_t> level((size_t)(nnz ? nnz : 1));
-        if (mfx_schedule_levels(idx, nnz, nu, ni, level.data(), &p->n_levels)) return bail();
-        p->level_off.assign((size_t)p->n_levels + 1, 0);
-        std::vector<Rec> recs((size_t)(nnz ? nnz : 1));
         static_assert(sizeof(Rec) == 16, "Rec is the 16-byte record of mfx_schedule_pack");
-        if (mfx_schedule_pack(idx, r, level.data(), nnz, p->n_levels, recs.data(), p->level_off.data()))
-            return bail();
+        if (dev_alloc(p, &p->d_recs, (size_t)nnz)) return bail();
+        // Schedule builder.  Device: O(nnz) + ~3 us per level, gives up beyond a level budget (heavily
+        // skewed data) -> host.  Auto: device from 2^20 ratings on, budget nnz/1000 levels (the point
+        // where the host's 3 ns per rating is cheaper).
+        bool on_device = false;
+        if (sched == MFX_SCHED_DEVICE || (sched == MFX_SCHED_AUTO && nnz >= (1 << 20) && nnz < ((int64_t)1 << 31) - 1)) {
+            const int64_t budget = sched == MFX_SCHED_DEVICE ? ((int64_t)1 << 22) : nnz / 1000;
+            bool over = false;
+            if (schedule_device(idx, r, nnz, nu, ni, p->d_recs, nullptr, p->level_off, &p->n_levels, budget, &over)) {
+                if (sched == MFX_SCHED_DEVICE || last_code() == MFX_E_RANGE) return bail();
+                over = true;                                   // e.g. scratch did not fit: host path
+            }
+            if (over && sched == MFX_SCHED_DEVICE) {
+                fail(MFX_E_STATE, "mfx_sgd_plan_create: more than %lld levels, use the host schedule builder",
+                     (long long)budget);
+                return bail();
+            }
+            on_device = !over;
+        }
+        p->sched_device = on_device;
+        if (!on_device) {
+            std::vector<int32_t> level((size_t)(nnz ? nnz : 1));
+            if (mfx_schedule_levels(idx, nnz, nu, ni, level.data(), &p->n_levels)) return bail();
+            p->level_off.assign((size_t)p->n_levels + 1, 0);
+            std::vector<Rec> recs((size_t)(nnz ? nnz : 1));
+            if (mfx_schedule_pack(idx, r, level.data(), nnz, p->n_levels, recs.data(), p->level_off.data()))
+                return bail();
+            if (hipMemcpy(p->d_recs, recs.data(), (size_t)nnz * sizeof(Rec), hipMemcpyHostToDevice) != hipSuccess) {
+                fail(MFX_E_HIP, "mfx_sgd_plan_create: upload failed: %s", hipGetErrorString(hipGetLastError()));
+                return bail();
+            }
+        }
         p->k1_wave_off.assign((size_t)p->n_levels + 1, 0);
         p->k2_wave_off.assign((size_t)p->n_levels + 1, 0);
         for (int64_t l = 0; l < p->n_levels; ++l) {
@@ -459,7 +503,6 @@ mfx_sgd_plan *mfx_sgd_plan_create(const int32_t *idx, const double *r, int64_t n
         p->sched_us = std::chrono::duration_cast<std::chrono::microseconds>(
                           std::chrono::steady_clock::now() - t0).count();
 
-        if (dev_alloc(p, &p->d_recs, (size_t)nnz)) return bail();
         if (dev_alloc(p, &p->d_level_off, (size_t)p->n_levels + 1) ||
             dev_alloc(p, &p->d_k1_wave_off, (size_t)p->n_levels + 1) ||
             dev_alloc(p, &p->d_k2_wave_off, (size_t)p->n_levels + 1))
@@ -478,8 +521,7 @@ mfx_sgd_plan *mfx_sgd_plan_create(const int32_t *idx, const double *r, int64_t n
         const int64_t np = p->k1_waves > p->k2_waves ? p->k1_waves : p->k2_waves;
         if (dev_alloc(p, &p->d_se_partial, (size_t)np)) return bail();
         // slots of waves that exit early (block padding) must read as 0
-        if (hipMemset(p->d_se_partial, 0, (size_t)(np ? np : 1) * sizeof(double)) != hipSuccess ||
-            hipMemcpy(p->d_recs, recs.data(), (size_t)nnz * sizeof(Rec), hipMemcpyHostToDevice) != hipSuccess) {
+        if (hipMemset(p->d_se_partial, 0, (size_t)(np ? np : 1) * sizeof(double)) != hipSuccess) {
             fail(MFX_E_HIP, "mfx_sgd_plan_create: upload failed: %s", hipGetErrorString(hipGetLastError()));
             return bail();
         }
@@ -502,6 +544,12 @@ void mfx_sgd_plan_destroy(mfx_sgd_plan *p)
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     delete p;
+}
+
+int mfx_sgd_plan_schedule_builder(const mfx_sgd_plan *p)
+{
+    if (!p) return MFX_E_ARG;
+    return p->sched_device ? MFX_SCHED_DEVICE : MFX_SCHED_HOST;
 }
 
 int mfx_sgd_plan_info(const mfx_sgd_plan *p, int64_t info[8])

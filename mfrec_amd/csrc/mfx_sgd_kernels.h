@@ -30,12 +30,6 @@
 
 namespace mfx {
 
-struct Rec {        // one rating in level-major order: 16 B, one dwordx4 load
-    int32_t user;
-    int32_t item;
-    double r;
-};
-
 enum { K1_LINEAR = 0, K1_LOGISTIC = 1, K1_LEARNED = 2 };
 
 struct K1Params {

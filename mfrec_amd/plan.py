@@ -12,10 +12,17 @@ LINEAR, LOGISTIC = 0, 1
 
 
 class SgdPlan(object):
-    def __init__(self, ratings_index, ratings, nbr_users, nbr_items, dim, storage="f64"):
+    SCHEDULE = {"auto": 0, "host": 1, "device": 2}
+
+    def __init__(self, ratings_index, ratings, nbr_users, nbr_items, dim, storage="f64", schedule="auto"):
+        """schedule: who builds the dependency-level schedule -- "host" (sequential pass + threaded
+        counting sort), "device" (radix sorts + one frontier launch per level in HBM) or "auto"
+        (device for >= 2^20 ratings unless the data needs more than nnz/1000 levels).  Same result."""
+        if schedule not in self.SCHEDULE:
+            raise ValueError("schedule must be 'auto', 'host' or 'device'")
         pi, pr, nnz = S.ratings_args(ratings_index, ratings)
         self.nu, self.ni, self.k, self.nnz = int(nbr_users), int(nbr_items), int(dim), nnz
-        self._h = S.lib().mfx_sgd_plan_create(pi, pr, nnz, self.nu, self.ni, self.k)
+        self._h = S.lib().mfx_sgd_plan_create2(pi, pr, nnz, self.nu, self.ni, self.k, self.SCHEDULE[schedule])
         if not self._h:
             msg = S.last_error()
             raise (ValueError if ("outside" in msg or "bad argument" in msg) else S.MfxError)(msg)
@@ -47,7 +54,9 @@ class SgdPlan(object):
         S.check(S.lib().mfx_sgd_plan_info(self._h, a))
         keys = ("n_levels", "max_level", "launches_per_epoch", "tail_launches", "ratings_per_wave",
                 "device_bytes", "schedule_us", "funk_launches_per_epoch")
-        return dict(zip(keys, [int(x) for x in a]))
+        d = dict(zip(keys, [int(x) for x in a]))
+        d["schedule_builder"] = {1: "host", 2: "device"}.get(S.lib().mfx_sgd_plan_schedule_builder(self._h), "?")
+        return d
 
     def set_factors(self, u, v, items_bias=None, users_bias=None):
         pu, pv, nu, ni = S.factor_args(u, v, self.k)

@@ -15,4 +15,14 @@ K.train_linear_kernel(1, k, 0.1, 0.01, 0, 0, 0.1, 0.1, 0.007, 0.0, u, v, idx, r,
 t0 = time.perf_counter()
 K.train_linear_kernel(E, k, 0.1, 0.01, 0, 0, 0.1, 0.1, 0.007, 0.0, u, v, idx, r, ib, ub)
 dt = time.perf_counter() - t0
-print(json.dumps({"one_shot_seconds": dt, "epochs": E, "updates_per_s_incl_schedule_and_pcie": nnz * E / dt}))
+print(json.dumps({"one_shot_seconds": dt, "epochs": E, "updates_per_s_incl_schedule_and_pcie": nnz * E / dt,
+                  "MFX_SCHED": os.environ.get("MFX_SCHED", "auto")}))
+from mfrec_amd.plan import SgdPlan
+for sched in ("host", "device"):
+    for rep in range(2):
+        t0 = time.perf_counter()
+        with SgdPlan(idx, r, nu, ni, k, schedule=sched) as p:
+            dt = time.perf_counter() - t0
+            info = p.info()
+    print(json.dumps({"plan_create_seconds": dt, "schedule": sched, "builder": info["schedule_builder"],
+                      "schedule_us": info["schedule_us"], "n_levels": info["n_levels"]}))

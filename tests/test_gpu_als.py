@@ -46,7 +46,8 @@ def _problem(nu, ni, nnz, seed):
     return create_bool_sparse_row(M) + create_bool_sparse_col(M)
 
 
-@pytest.mark.parametrize("k", [5, 20, 40, 64, 100, 128])
+# every 16-column tile count NT = 1..8 (k_als_rows2: NT 1, 2, 4; k_als_rows3: NT 3, 5..8), ragged k
+@pytest.mark.parametrize("k", [1, 5, 16, 20, 33, 40, 48, 64, 65, 72, 96, 100, 112, 127, 128])
 def test_als_vs_oracle(k):
     from mfrec_amd.lib.als_implicit import als_wrmf
     from oracle import oracle as O
@@ -75,6 +76,32 @@ def test_als_c_pos_and_lambda():
         u, v, u2, v2 = u0.copy(), v0.copy(), u0.copy(), v0.copy()
         als_wrmf(1, k, u, v, None, None, urow, ucol, irow, icol, nu, ni, c_pos, lam)
         O.als_wrmf(1, k, u2, v2, None, None, urow, ucol, irow, icol, nu, ni, c_pos, lam)
+        np.testing.assert_allclose(u, u2, rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(v, v2, rtol=1e-8, atol=1e-11)
+
+
+def test_als_ragged_spans_and_empty_rows():
+    """Spans 0, 1, 31, 32, 33 (the 32-row gather chunk), a 700-long row, unrated tails, with the
+    register-tile kernel (k=80) and the LDS kernel (k=64)."""
+    from mfrec_amd.lib.als_implicit import als_wrmf
+    from mfrec_amd.lib.datasets import create_bool_sparse_col, create_bool_sparse_row
+    from oracle import oracle as O
+    nu, ni = 40, 800
+    rs = np.random.RandomState(9)
+    spans = [0, 1, 31, 32, 33, 64, 65, 700, 0, 2] + list(rs.randint(0, 50, 20)) + [0] * 10
+    rows, cols = [], []
+    for uidx, sp_ in enumerate(spans):
+        c = rs.choice(ni - 100, sp_, replace=False)          # the last 100 items stay unrated
+        rows += [uidx] * sp_
+        cols += list(c)
+    M = sp.csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(nu, ni))
+    urow, ucol = create_bool_sparse_row(M)
+    irow, icol = create_bool_sparse_col(M)
+    for k in (64, 80):
+        u0, v0 = rs.normal(0, 0.1, (k, ni)), rs.normal(0, 0.1, (k, nu))
+        u, v, u2, v2 = u0.copy(), v0.copy(), u0.copy(), v0.copy()
+        als_wrmf(2, k, u, v, None, None, urow, ucol, irow, icol, nu, ni, 1, 0.015)
+        O.als_wrmf(2, k, u2, v2, None, None, urow, ucol, irow, icol, nu, ni, 1, 0.015)
         np.testing.assert_allclose(u, u2, rtol=1e-8, atol=1e-11)
         np.testing.assert_allclose(v, v2, rtol=1e-8, atol=1e-11)
 

@@ -1,0 +1,35 @@
+"""CPU: the hand-written f64 DPP instructions of the ALS kernels (inline asm, invisible to the
+compiler's hazard recogniser) must never read a VGPR written by the two preceding instructions
+without an s_nop.  Cross-compiles mfx_als.hip for gfx950 and scans the ISA (no GPU needed)."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not installed")
+def test_dpp_hazard_lint():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_dpp_hazard.py")],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "0 hazards" in out.stdout
+    n = int(out.stdout.split("checked")[1].split()[0])
+    assert n > 1000          # the lint really saw the DPP code
+
+
+def test_lint_detects_a_planted_hazard():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_dpp_hazard as L
+    ok = ["v_mul_f64 v[2:3], v[4:5], v[6:7]", "v_add_f64 v[8:9], v[8:9], v[4:5]", "v_add_f64 v[10:11], v[8:9], v[4:5]",
+          "v_fmac_f64_dpp v[0:1], -v[2:3], v[4:5] row_newbcast:3 row_mask:0xf bank_mask:0xf"]
+    assert L.scan(ok, verbose=False) == (1, 0)
+    bad = ["v_mul_f64 v[2:3], v[4:5], v[6:7]",
+           "v_fmac_f64_dpp v[0:1], -v[2:3], v[4:5] row_newbcast:3 row_mask:0xf bank_mask:0xf"]
+    assert L.scan(bad, verbose=False) == (1, 1)
+    nop = ["v_mul_f64 v[2:3], v[4:5], v[6:7]", "s_nop 1",
+           "v_fmac_f64_dpp v[0:1], -v[2:3], v[4:5] row_newbcast:3 row_mask:0xf bank_mask:0xf"]
+    assert L.scan(nop, verbose=False) == (1, 0)

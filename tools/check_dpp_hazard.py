@@ -5,34 +5,59 @@ separates them (VALU-write -> DPP-read needs 2 wait states and the compiler cann
 inline asm).  Usage: python tools/check_dpp_hazard.py   (compiles to a temp dir with -save-temps)"""
 import os, re, subprocess, sys, tempfile
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tmp = tempfile.mkdtemp()
-subprocess.check_call(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-I" + root + "/include",
-                       "-I" + root + "/mfrec_amd/csrc", "-c", root + "/mfrec_amd/csrc/mfx_als.hip", "-save-temps", "-o", "als.o"], cwd=tmp)
-asm = [f for f in os.listdir(tmp) if f.endswith("gfx950.s")][0]
+
+
 def regs(tok):
     m = re.match(r"-?\|?v\[(\d+):(\d+)\]", tok)
-    if m: return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
     m = re.match(r"-?\|?v(\d+)$", tok)
     return {int(m.group(1))} if m else set()
-hist, bad, n = [], 0, 0          # hist: (writes, is_nop) of preceding instructions
-for line in open(os.path.join(tmp, asm)):
-    t = line.strip()
-    if not t or t.startswith((";", ".", "//")) or t.endswith(":"): continue
-    op, _, rest = t.partition(" ")
-    ops = [x.strip() for x in rest.split(";")[0].split(",")]
-    if op.startswith("s_nop"):
-        hist.append((set(), int(ops[0]) + 1)); continue
-    if "_dpp" in op and len(ops) >= 2:
-        n += 1
-        src0 = regs(ops[1].split()[0])
-        wait = 0
-        for w, nop in reversed(hist[-4:]):
-            if nop: wait += nop; continue
-            if wait >= 2: break
-            if w & src0:
-                bad += 1; print("HAZARD:", t); break
-            wait += 1
-    w = regs(ops[0].split()[0]) if op.startswith(("v_", "ds_read", "global_load", "buffer_load")) and ops else set()
-    hist.append((w, 0))
-print("checked %d DPP instructions, %d hazards" % (n, bad))
-sys.exit(1 if bad else 0)
+
+
+def scan(lines, verbose=True):
+    """-> (number of DPP instructions seen, number of hazards)"""
+    hist, bad, n = [], 0, 0          # hist: (VGPRs written, wait states if s_nop) of preceding instructions
+    for line in lines:
+        t = line.strip()
+        if not t or t.startswith((";", ".", "//")) or t.endswith(":"):
+            continue
+        op, _, rest = t.partition(" ")
+        ops = [x.strip() for x in rest.split(";")[0].split(",")]
+        if op.startswith("s_nop"):
+            hist.append((set(), int(ops[0]) + 1))
+            continue
+        if "_dpp" in op and len(ops) >= 2:
+            n += 1
+            src0 = regs(ops[1].split()[0])
+            wait = 0
+            for w, nop in reversed(hist[-4:]):
+                if nop:
+                    wait += nop
+                    continue
+                if wait >= 2:
+                    break
+                if w & src0:
+                    bad += 1
+                    if verbose:
+                        print("HAZARD:", t)
+                    break
+                wait += 1
+        w = regs(ops[0].split()[0]) if op.startswith(("v_", "ds_read", "global_load", "buffer_load")) and ops else set()
+        hist.append((w, 0))
+    return n, bad
+
+
+def main():
+    tmp = tempfile.mkdtemp()
+    subprocess.check_call(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off",
+                           "-I" + root + "/include", "-I" + root + "/mfrec_amd/csrc", "-c",
+                           root + "/mfrec_amd/csrc/mfx_als.hip", "-save-temps", "-o", "als.o"], cwd=tmp)
+    asm = [f for f in os.listdir(tmp) if f.endswith("gfx950.s")][0]
+    n, bad = scan(open(os.path.join(tmp, asm)))
+    print("checked %d DPP instructions, %d hazards" % (n, bad))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -106,6 +106,18 @@ def test_als_ragged_spans_and_empty_rows():
         np.testing.assert_allclose(v, v2, rtol=1e-8, atol=1e-11)
 
 
+@pytest.mark.parametrize("k", [8, 24, 64, 80, 128])
+def test_als_singular_system_raises_like_numpy_inv(k):
+    """lambda = 0 with all-zero factors: A = 0, np.linalg.inv in the reference raises LinAlgError
+    (als_implicit.pyx:296); every row kernel must report it instead of returning NaNs."""
+    from mfrec_amd.lib.als_implicit import als_wrmf
+    nu, ni = 50, 40
+    urow, ucol, irow, icol = _problem(nu, ni, 600, 1)
+    u, v = np.zeros((k, ni)), np.zeros((k, nu))
+    with pytest.raises(np.linalg.LinAlgError, match="not positive definite"):
+        als_wrmf(1, k, u, v, None, None, urow, ucol, irow, icol, nu, ni, 1, 0.0)
+
+
 def test_als_errors():
     from mfrec_amd.lib.als_implicit import als_wrmf
     u, v = np.ones((4, 3)), np.ones((4, 5))

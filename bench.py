@@ -124,22 +124,28 @@ def main():
     from mfrec_amd import build as B
     from mfrec_amd import synth
     from mfrec_amd.plan import SgdPlan, Timer, LINEAR
+    uid = None
+    if world > 1:
+        # torch.distributed.run is only the launcher: no torch import in the ranks (see
+        # mfrec_amd/rendezvous.py); the RCCL unique id travels through a file.  Rank 0 builds (a
+        # no-op when libmfx.so is current) before it publishes the id, the other ranks wait for the
+        # id before they touch the library: eight ranks never compile into the same files at once.
+        import ctypes as C
+        from mfrec_amd import rendezvous
+        if rank != 0:
+            uid = rendezvous.exchange_unique_id(rank, world, None)
     B.build(verbose=False)
     # MFX_BENCH_DEVICE: rehearsal hook (several ranks on one GPU); the driver never sets it
     S.init(int(os.environ.get("MFX_BENCH_DEVICE", local)))
 
     if world > 1:
-        # torch.distributed.run is only the launcher: no torch import in the ranks (see
-        # mfrec_amd/rendezvous.py); the RCCL unique id travels through a file.
-        import ctypes as C
-        from mfrec_amd import rendezvous
-
         def make_id():
             idbuf = C.create_string_buffer(S.UNIQUE_ID_BYTES)
             S.check(S.lib().mfx_comm_unique_id(idbuf))
             return idbuf.raw
 
-        uid = rendezvous.exchange_unique_id(rank, world, make_id)
+        if rank == 0:
+            uid = rendezvous.exchange_unique_id(rank, world, make_id)
         S.check(S.lib().mfx_comm_init(rank, world, uid))
 
     nu, ni, nnz, k = a.users, a.items, a.nnz, a.k

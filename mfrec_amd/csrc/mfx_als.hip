@@ -956,6 +956,7 @@ int als_half(int k, int NT, const AlsKernels &K, const double *dY, int ny, doubl
              double *d_partial, double *dG, int *d_status, int rank = 0, int world = 1,
              bool gather = false)
 {
+    mfx::TraceRange trace_("mfx:als_half (Gramian + row solves)");
     const int KP = NT * 16;
     hipStream_t s = mfx::stream();
     {   // Gramian over ALL rows of Y (als_implicit.pyx:257-262)

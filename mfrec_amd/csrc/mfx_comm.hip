@@ -260,6 +260,7 @@ int mfx_sgd_run_funk_sharded(mfx_sgd_plan *p, int min_epochs, double min_improve
                              double lr, double K, double mu, int use_bias, int epoch_cap,
                              double scale, double *rmse_hist, int64_t hist_cap, int64_t *n_hist)
 {
+    mfx::TraceRange trace_("mfx:run_funk_sharded");
     if (!p) return mfx::fail(MFX_E_ARG, "mfx_sgd_run_funk_sharded: NULL plan");
     if (g_world > 1 && !g_comm) return mfx::fail(MFX_E_STATE, "mfx_comm_init has not been called");
     FunkShard c{scale, nullptr, nullptr};
@@ -278,6 +279,7 @@ int mfx_sgd_run_funk_sharded(mfx_sgd_plan *p, int min_epochs, double min_improve
 int mfx_sgd_run_kmf_sharded(mfx_sgd_plan *p, int mode, int nbr_epochs, double lr, double Ku,
                             double Ki, double Kb, double scale, double *rmse_out, double *se_out)
 {
+    mfx::TraceRange trace_("mfx:run_kmf_sharded (epochs + RCCL all-reduce)");
     if (!p) return mfx::fail(MFX_E_ARG, "mfx_sgd_run_kmf_sharded: NULL plan");
     if (g_world > 1 && !g_comm) return mfx::fail(MFX_E_STATE, "mfx_comm_init has not been called");
     ShardCtx c{scale, nullptr, nullptr};

@@ -31,6 +31,16 @@ struct Rec {        // one rating in level-major order: 16 B, one dwordx4 load
     double r;
 };
 
+// roctx range for rocprofv3 --marker-trace (SURVEY section 5 "tracing"): the profiler's roctx
+// library is looked up lazily with dlopen; without it (or with MFX_ROCTX=0) ranges are no-ops.
+struct TraceRange {
+    explicit TraceRange(const char *name);
+    ~TraceRange();
+    TraceRange(const TraceRange &) = delete;
+    TraceRange &operator=(const TraceRange &) = delete;
+    bool on;
+};
+
 template <typename T>
 static inline T ceil_div(T a, T b) { return (a + b - 1) / b; }
 

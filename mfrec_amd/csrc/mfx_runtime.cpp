@@ -1,4 +1,6 @@
 // Runtime plumbing of libmfx.so: error string, device binding, stream, event stopwatch.
+#include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 #include "mfx_common.h"
 
@@ -34,6 +36,44 @@ void set_last_compute_ms(double ms) { g_last_ms = ms; }
 hipStream_t stream() { return g_stream; }
 bool ready() { return g_ready; }
 int ensure_init() { return g_ready ? MFX_OK : mfx_init(0); }
+
+namespace {
+typedef int (*roctx_push_t)(const char *);
+typedef int (*roctx_pop_t)(void);
+roctx_push_t g_push = nullptr;
+roctx_pop_t g_pop = nullptr;
+int g_roctx_state = 0;          // 0 = not looked up, 1 = available, -1 = absent / disabled
+bool roctx_ready()
+{
+    if (g_roctx_state == 0) {
+        g_roctx_state = -1;
+        const char *e = getenv("MFX_ROCTX");
+        if (!(e && e[0] == '0')) {
+            const char *names[] = {"librocprofiler-sdk-roctx.so", "libroctx64.so"};
+            for (const char *n : names) {
+                void *h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+                if (!h) continue;
+                g_push = (roctx_push_t)dlsym(h, "roctxRangePushA");
+                g_pop = (roctx_pop_t)dlsym(h, "roctxRangePop");
+                if (g_push && g_pop) {
+                    g_roctx_state = 1;
+                    break;
+                }
+            }
+        }
+    }
+    return g_roctx_state == 1;
+}
+}  // namespace
+
+TraceRange::TraceRange(const char *name) : on(roctx_ready())
+{
+    if (on) (void)g_push(name);
+}
+TraceRange::~TraceRange()
+{
+    if (on) (void)g_pop();
+}
 }  // namespace mfx
 
 extern "C" {

@@ -161,6 +161,7 @@ int schedule_device(const int32_t *h_idx, const double *h_r, int64_t nnz, int nu
                     Rec *d_recs, int32_t *h_level, std::vector<int64_t> &level_off,
                     int64_t *n_levels, int64_t level_budget, bool *over_budget)
 {
+    mfx::TraceRange trace_("mfx:schedule_device (sorts + frontier levels)");
     *over_budget = false;
     *n_levels = 0;
     level_off.assign(1, 0);

@@ -394,6 +394,7 @@ mfx_sgd_plan *mfx_sgd_plan_create(const int32_t *idx, const double *r, int64_t n
 mfx_sgd_plan *mfx_sgd_plan_create2(const int32_t *idx, const double *r, int64_t nnz, int nu, int ni,
                                    int dim, int sched)
 {
+    mfx::TraceRange trace_("mfx:plan_create (schedule + upload)");
     if (!idx || !r || nnz < 0 || nu <= 0 || ni <= 0 || dim < 1 || dim > kMaxK ||
         sched < MFX_SCHED_AUTO || sched > MFX_SCHED_DEVICE) {
         fail(MFX_E_ARG, "mfx_sgd_plan_create: bad argument (nnz=%lld nu=%d ni=%d k=%d sched=%d; 1 <= k <= %d)",
@@ -583,6 +584,7 @@ int mfx_sgd_plan_set_storage(mfx_sgd_plan *p, int bits)
 int mfx_sgd_set_factors(mfx_sgd_plan *p, const double *u, const double *v, const double *ib,
                         const double *ub)
 {
+    mfx::TraceRange trace_("mfx:set_factors (H2D + transpose)");
     if (!p || !u || !v) {
         return fail(MFX_E_ARG, "mfx_sgd_set_factors: NULL argument");
     }
@@ -602,6 +604,7 @@ int mfx_sgd_set_factors(mfx_sgd_plan *p, const double *u, const double *v, const
 
 int mfx_sgd_get_factors(mfx_sgd_plan *p, double *u, double *v, double *ib, double *ub)
 {
+    mfx::TraceRange trace_("mfx:get_factors (transpose + D2H)");
     int rc = check_plan(p, "mfx_sgd_get_factors");
     if (rc) return rc;
     rc = to_km(p);
@@ -617,6 +620,7 @@ int mfx_sgd_get_factors(mfx_sgd_plan *p, double *u, double *v, double *ib, doubl
 int mfx_sgd_run_kmf(mfx_sgd_plan *p, int mode, int nbr_epochs, double lr, double Ku, double Ki,
                     double Kb, int upd_u, int upd_i, double *rmse_out)
 {
+    mfx::TraceRange trace_("mfx:run_kmf (full-k SGD epochs)");
     int rc = check_plan(p, "mfx_sgd_run_kmf");
     if (rc) return rc;
     if (mode != MFX_MODE_LINEAR && mode != MFX_MODE_LOGISTIC) {
@@ -791,6 +795,7 @@ int mfx_sgd_run_funk(mfx_sgd_plan *p, int min_epochs, double min_improvement, do
                      double lr, double K, double mu, int use_bias, int upd_u, int upd_i,
                      int epoch_cap, double *rmse_hist, int64_t hist_cap, int64_t *n_hist)
 {
+    mfx::TraceRange trace_("mfx:run_funk (per-feature SGD)");
     return mfx::funk_core(p, min_epochs, min_improvement, f_init, lr, K, mu, use_bias, upd_u, upd_i,
                           epoch_cap, rmse_hist, hist_cap, n_hist, nullptr);
 }
@@ -800,6 +805,7 @@ int mfx_sgd_run_learned_bias(mfx_sgd_plan *p, int min_epochs, double min_improve
                              double K_feature, double K_bias, double mu, int epoch_cap,
                              double *rmse_hist, int64_t hist_cap, int64_t *n_hist)
 {
+    mfx::TraceRange trace_("mfx:run_learned_bias");
     int rc = check_plan(p, "mfx_sgd_run_learned_bias");
     if (rc) return rc;
     rc = to_nk(p);

@@ -900,16 +900,27 @@ AlsKernels als_kernels_nt()
         if (nw == 1) return {(void *)k_gram_partial<NT>, (void *)k_als_rows2<NT, 1>, 1};
         if (nw == 4) return {(void *)k_gram_partial<NT>, (void *)k_als_rows2<NT, 4>, 4};
         return {(void *)k_gram_partial<NT>, (void *)k_als_rows2<NT, 2>, 2};
-    } else if constexpr (NT >= 5 || NT == 3) {
+    } else if constexpr (NT >= 5) {
         const char *e = getenv("MFX_ALS_ROWS2");              // tuning / cross-check hook
         if (e && e[0] == '1') return {(void *)k_gram_partial<NT>, (void *)k_als_rows2<NT, 4>, 4, false};
         // occupancy hint: k = 128 needs the cap to fit three workgroups per CU; below that the
         // kernel fits anyway and the uncapped schedule measured 4 % faster
         const char *o = getenv("MFX_ALS_OCC");
-        const bool occ3 = o ? o[0] == '3' : (NT == 8 || NT <= 4);
+        const bool occ3 = o ? o[0] == '3' : NT == 8;
         if (!occ3) return {(void *)k_gram_partial<NT>, (void *)k_als_rows3<NT, 2>, 4, true};
         return {(void *)k_gram_partial<NT>, (void *)k_als_rows3<NT, 3>, 4, true};
-    } else return {(void *)k_gram_partial<NT>, (void *)k_als_rows2<NT, 4>, 4};
+    } else {                                                  // NT = 3, 4
+        const char *e = getenv("MFX_ALS_ROWS2");
+        const bool r2 = e && e[0] == '1';
+        if (r2) return {(void *)k_gram_partial<NT>, (void *)k_als_rows2<NT, 4>, 4, false};
+        const char *o = getenv("MFX_ALS_OCC");
+        switch (o ? o[0] - '0' : (NT == 4 ? 4 : 3)) {   // measured: k=64 5.6 (rows2) / 5.9 / 5.2 / 5.3 / 5.7 ms at 3..6
+        case 4: return {(void *)k_gram_partial<NT>, (void *)k_als_rows3<NT, 4>, 4, true};
+        case 5: return {(void *)k_gram_partial<NT>, (void *)k_als_rows3<NT, 5>, 4, true};
+        case 6: return {(void *)k_gram_partial<NT>, (void *)k_als_rows3<NT, 6>, 4, true};
+        default: return {(void *)k_gram_partial<NT>, (void *)k_als_rows3<NT, 3>, 4, true};
+        }
+    }
 }
 
 size_t rows2_lds_bytes(int KP)

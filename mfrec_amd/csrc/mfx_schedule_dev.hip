@@ -22,7 +22,7 @@
 namespace mfx {
 namespace {
 
-constexpr int kBfsBlocks = 1024;
+constexpr int kBfsBlocks = 256;      // 64 K threads cover a typical frontier; grid-stride beyond
 constexpr int kBfsThreads = 256;
 
 __global__ void k_split_check(const int2 *__restrict__ idx, int64_t nnz, int nu, int ni,

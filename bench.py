@@ -32,6 +32,16 @@ def algorithmic_bytes(k, nnz, nu, s=8, rec=16):
     return b_read, b_total
 
 
+def kernel_label(k, batch, storage):
+    """Name of the k1_level instantiation mfx_sgd.hip's k1_pick selects (KP lanes per rating, features
+    per lane, ratings per wave; 'vec16+wt' = 16-byte accesses per lane with write-through row stores)."""
+    vec = int(os.environ.get("MFX_K1_VEC", "2") or 0)
+    if storage == "f64" and vec and k % 2 == 0 and 32 < k <= 128 and batch == 8:
+        return "k1_level<%d,2,8,linear,%s>" % (32 if k <= 64 else 64, "vec16+wt" if vec == 2 else "vec16")
+    return "k1_level<%d,%d,%d,linear>" % ((8 if k <= 8 else 16 if k <= 16 else 32 if k <= 32 else 64),
+                                          (1 if k <= 64 else 2 if k <= 128 else 4 if k <= 256 else 8), batch)
+
+
 def cpu_baseline(idx, r, nu, ni, k, budget_s=12.0):
     """The reference CPU path timed on this host, 1 thread (the reference is single-threaded:
     GIL held, no OpenMP), on a bounded prefix of the same workload with the full-size factor
@@ -233,10 +243,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
                          "traffic_unit": "bytes per launch (PMC, %s)" % traffic_src,
                          "algorithmic_bytes_per_launch": b_read * nnz / launches,
-                         "kernel": "k1_level<%d,%d,%d,linear>" % (
-                             (8 if k <= 8 else 16 if k <= 16 else 32 if k <= 32 else 64),
-                             (1 if k <= 64 else 2 if k <= 128 else 4 if k <= 256 else 8),
-                             info["ratings_per_wave"]),
+                         "kernel": kernel_label(k, info["ratings_per_wave"], a.storage),
                          "bytes_per_update_read": b_read, "bytes_per_update_total": b_total,
                          "avg_launch_us": avg_launch_s * 1e6, "launches_per_epoch": launches,
                          "event_pair_avg_launch_us": kern_ms * 1e3 / launches,

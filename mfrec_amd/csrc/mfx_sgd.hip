@@ -145,11 +145,32 @@ size_t k1_lds_bytes(int k, int batch)
     return (size_t)kWaves * batch * (size_t)k1_stride(k) * sizeof(double);
 }
 
+int k1_vec_mode()
+{
+    const char *e = getenv("MFX_K1_VEC");      // tuning hook: 0 = 8 bytes per lane, 1 / 2 see k1_pick
+    return (e && *e) ? atoi(e) : 2;
+}
+
 // pick the kernel instantiation for (k, mode, batch, storage type)
 template <int MODE, typename TS, bool TAIL>
 void *k1_pick(int k, int batch)
 {
 #define MFX_K1(KP, FPL, B) (TAIL ? (void *)k1_tail<KP, FPL, B, MODE, 0, TS> : (void *)k1_level<KP, FPL, B, MODE, 0, TS>)
+    // 16 bytes per lane (contiguous feature pair), f64 rows, even k in (32, 128]: vec = 1 plain
+    // stores, vec = 2 (default) write-through stores -- no dirty lines left for the end-of-kernel
+    // write-back.  cfg 2: 1.68 (8 B per lane) / 1.75 / 1.88 G updates/s; 16 or 4 ratings per wave,
+    // and write-through bias stores, measured slower.
+    if constexpr (sizeof(TS) == 8 && MODE != K1_LEARNED) {
+        const int vec = k1_vec_mode();
+        if (vec && k % 2 == 0 && k > 32 && k <= 128 && batch == 8) {
+// (the tail kernel runs several levels in one launch: it keeps plain stores, which the compiler
+// drains before the workgroup barrier between levels -- an asm store would slip past it)
+#define MFX_K1V(KP, NTF) (TAIL ? (void *)k1_tail<KP, 2, 8, MODE, 0, TS, true> : (void *)k1_level<KP, 2, 8, MODE, NTF, TS, true>)
+            if (k <= 64) return vec == 2 ? MFX_K1V(32, 2) : MFX_K1V(32, 0);
+            return vec == 2 ? MFX_K1V(64, 2) : MFX_K1V(64, 0);
+#undef MFX_K1V
+        }
+    }
     if (k <= 8) return MFX_K1(8, 1, 16);
     if (k <= 16) return MFX_K1(16, 1, 16);
     if (k <= 32) return MFX_K1(32, 1, 16);

@@ -102,7 +102,20 @@ __device__ __forceinline__ double wave_sum_fixed(double x)
 // TS = storage type of the factor rows: double (exact), or float ("f32 storage, f64
 // arithmetic" fast mode: rows are widened on load and rounded once on store -- NOT bit-exact,
 // measured RMSE delta in DESIGN.md)
-template <int KP, int FPL, int BATCH, int MODE, int NT, bool FULL, typename TS>
+// VEC = each lane owns the CONTIGUOUS feature pair (2q, 2q+1) and moves it with one 16-byte
+// access (k even, FPL == 2, f64 rows): half the memory instructions per row, and 16-byte
+// write-through (sc1) stores cost what plain stores cost (8-byte ones are 2.7x dearer per byte,
+// MI355X_MICROARCH.md price list), so NT == 2 then leaves no dirty L2 lines for the
+// end-of-kernel write-back.  The arithmetic and the summation order do not change.
+typedef double v2f64_a8 __attribute__((ext_vector_type(2), aligned(8)));
+__device__ __forceinline__ void store16_sc1(double *p, double a, double b)
+{
+    typedef double v2f64 __attribute__((ext_vector_type(2)));
+    v2f64 v = {a, b};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+
+template <int KP, int FPL, int BATCH, int MODE, int NT, bool FULL, typename TS, bool VEC = false>
 __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cnt, int64_t base,
                                         int64_t slot, double *prod, int lane)
 {
@@ -143,17 +156,34 @@ __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cn
         ur[s] = (TS *)P.U + (size_t)itm * k;
         vr[s] = (TS *)P.V + (size_t)usr * k;
     }
+    static_assert(!VEC || (FPL == 2 && sizeof(TS) == 8), "VEC: one 16-byte f64 pair per lane");
+    if constexpr (VEC) {
 #pragma unroll
-    for (int j = 0; j < FPL; ++j) {
-        const int f = j * KP + q;
-#pragma unroll
-        for (int s = 0; s < NR; ++s) { uval[s][j] = 0.0; vval[s][j] = 0.0; }
-        if (f < k) {
+        for (int s = 0; s < NR; ++s) { uval[s][0] = uval[s][1] = 0.0; vval[s][0] = vval[s][1] = 0.0; }
+        if (2 * q < k) {                                  // k is even
 #pragma unroll
             for (int s = 0; s < NR; ++s) {
                 if (FULL || (s * SPW + g < cnt)) {
-                    uval[s][j] = (double)ur[s][f];
-                    vval[s][j] = (double)vr[s][f];
+                    const v2f64_a8 a = *reinterpret_cast<const v2f64_a8 *>((const double *)ur[s] + 2 * q);
+                    const v2f64_a8 b = *reinterpret_cast<const v2f64_a8 *>((const double *)vr[s] + 2 * q);
+                    uval[s][0] = a.x; uval[s][1] = a.y;
+                    vval[s][0] = b.x; vval[s][1] = b.y;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) {
+            const int f = j * KP + q;
+    #pragma unroll
+            for (int s = 0; s < NR; ++s) { uval[s][j] = 0.0; vval[s][j] = 0.0; }
+            if (f < k) {
+    #pragma unroll
+                for (int s = 0; s < NR; ++s) {
+                    if (FULL || (s * SPW + g < cnt)) {
+                        uval[s][j] = (double)ur[s][f];
+                        vval[s][j] = (double)vr[s][f];
+                    }
                 }
             }
         }
@@ -169,12 +199,22 @@ __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cn
     MFX_STAMP(2);
 
     // ---- products to LDS: prod[n][f] -------------------------------------------------
+    if constexpr (VEC) {
+        if (2 * q < k) {
 #pragma unroll
-    for (int j = 0; j < FPL; ++j) {
-        const int f = j * KP + q;
-        if (f < k) {
+            for (int s = 0; s < NR; ++s) {
+                double *pp = prod + (s * SPW + g) * stride + 2 * q;          // rows 16-B aligned
+                *reinterpret_cast<double2 *>(pp) = make_double2(uval[s][0] * vval[s][0], uval[s][1] * vval[s][1]);
+            }
+        }
+    } else {
 #pragma unroll
-            for (int s = 0; s < NR; ++s) prod[(s * SPW + g) * stride + f] = uval[s][j] * vval[s][j];
+        for (int j = 0; j < FPL; ++j) {
+            const int f = j * KP + q;
+            if (f < k) {
+    #pragma unroll
+                for (int s = 0; s < NR; ++s) prod[(s * SPW + g) * stride + f] = uval[s][j] * vval[s][j];
+            }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -221,8 +261,11 @@ __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cn
             P.ib[rec.item] = ibv + P.lr_i * (err - P.Kb * ibv);
         } else {
             // linear: unconditional (kmf_train.pyx:259-260); logistic: gated (:168-171)
-            if (FULL || MODE == K1_LINEAR || P.upd_u) P.ub[rec.user] = ubv + P.lr * (grad - P.Kb * ubv);
-            if (FULL || MODE == K1_LINEAR || P.upd_i) P.ib[rec.item] = ibv + P.lr * (grad - P.Kb * ibv);
+            const double ubn = ubv + P.lr * (grad - P.Kb * ubv), ibn = ibv + P.lr * (grad - P.Kb * ibv);
+            {
+                if (FULL || MODE == K1_LINEAR || P.upd_u) P.ub[rec.user] = ubn;
+                if (FULL || MODE == K1_LINEAR || P.upd_i) P.ib[rec.item] = ibn;
+            }
         }
     }
     MFX_STAMP(3);
@@ -239,9 +282,33 @@ __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cn
             gr[s] = shfl_f64(grad, s * SPW + g);
         }
     }
+    if constexpr (VEC && MODE != K1_LEARNED) {
+        if (2 * q < k) {
+#pragma unroll
+            for (int s = 0; s < NR; ++s) {
+                if (FULL || (s * SPW + g < cnt)) {
+                    const double mf0 = uval[s][0], mf1 = uval[s][1], cf0 = vval[s][0], cf1 = vval[s][1];
+                    const double un0 = mf0 + P.lr * (gr[s] * cf0 - P.Ki * mf0);   // kmf_train.pyx:267-270
+                    const double un1 = mf1 + P.lr * (gr[s] * cf1 - P.Ki * mf1);
+                    const double vn0 = cf0 + P.lr * (gr[s] * mf0 - P.Ku * cf0);
+                    const double vn1 = cf1 + P.lr * (gr[s] * mf1 - P.Ku * cf1);
+                    double *up = (double *)ur[s] + 2 * q, *vp = (double *)vr[s] + 2 * q;
+                    if constexpr (NT == 2) {               // 16-byte write-through stores
+                        if (FULL || P.upd_i) store16_sc1(up, un0, un1);
+                        if (FULL || P.upd_u) store16_sc1(vp, vn0, vn1);
+                    } else {
+                        v2f64_a8 a, b;
+                        a.x = un0; a.y = un1; b.x = vn0; b.y = vn1;
+                        if (FULL || P.upd_i) *reinterpret_cast<v2f64_a8 *>(up) = a;
+                        if (FULL || P.upd_u) *reinterpret_cast<v2f64_a8 *>(vp) = b;
+                    }
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int j = 0; j < FPL; ++j) {
-        const int f = j * KP + q;
+        const int f = VEC ? (q * FPL + j) : (j * KP + q);
         if constexpr (MODE == K1_LEARNED) {
             if (f == P.f) {                                           // gd_estimator.pyx:476-477
 #pragma unroll
@@ -277,6 +344,7 @@ __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cn
             }
         }
     }
+    }
     MFX_STAMP(4);
 #ifdef MFX_K1_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -288,7 +356,7 @@ __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cn
     if (lane == 0) P.se_partial[slot] = wsum;
 }
 
-template <int KP, int FPL, int BATCH, int MODE, int NT, typename TS = double>
+template <int KP, int FPL, int BATCH, int MODE, int NT, typename TS = double, bool VEC = false>
 __global__ __launch_bounds__(kWaves * 64) void k1_level(K1Params P, int64_t start, int count,
                                                        int64_t wave_off)
 {
@@ -304,9 +372,9 @@ __global__ __launch_bounds__(kWaves * 64) void k1_level(K1Params P, int64_t star
     const int cnt = (count - base) < BATCH ? (int)(count - base) : BATCH;
     double *prod = lds + (size_t)wid * BATCH * k1_stride(P.k);
     if (cnt == BATCH && P.upd_u && P.upd_i)
-        k1_body<KP, FPL, BATCH, MODE, NT, true, TS>(P, start, cnt, base, wave_off + wave_g, prod, lane);
+        k1_body<KP, FPL, BATCH, MODE, NT, true, TS, VEC>(P, start, cnt, base, wave_off + wave_g, prod, lane);
     else
-        k1_body<KP, FPL, BATCH, MODE, NT, false, TS>(P, start, cnt, base, wave_off + wave_g, prod, lane);
+        k1_body<KP, FPL, BATCH, MODE, NT, false, TS, VEC>(P, start, cnt, base, wave_off + wave_g, prod, lane);
 }
 
 // Tail kernel: a run of consecutive SMALL levels (each <= kTailWaves*BATCH ratings) in ONE
@@ -315,7 +383,7 @@ __global__ __launch_bounds__(kWaves * 64) void k1_level(K1Params P, int64_t star
 // chain of a few hot items/users with a handful of ratings each; a launch per level would
 // cost ~9 us for ~no work.
 static constexpr int kTailWaves = 16;
-template <int KP, int FPL, int BATCH, int MODE, int NT, typename TS = double>
+template <int KP, int FPL, int BATCH, int MODE, int NT, typename TS = double, bool VEC = false>
 __global__ __launch_bounds__(kTailWaves * 64) void k1_tail(K1Params P, const int64_t *level_off,
                                                           const int64_t *wave_off, int l0, int l1)
 {
@@ -335,9 +403,9 @@ __global__ __launch_bounds__(kTailWaves * 64) void k1_tail(K1Params P, const int
             } else {
                 const int cnt = (count - base) < BATCH ? (count - base) : BATCH;
                 if (cnt == BATCH && P.upd_u && P.upd_i)
-                    k1_body<KP, FPL, BATCH, MODE, NT, true, TS>(P, start, cnt, base, woff + wid, prod, lane);
+                    k1_body<KP, FPL, BATCH, MODE, NT, true, TS, VEC>(P, start, cnt, base, woff + wid, prod, lane);
                 else
-                    k1_body<KP, FPL, BATCH, MODE, NT, false, TS>(P, start, cnt, base, woff + wid, prod, lane);
+                    k1_body<KP, FPL, BATCH, MODE, NT, false, TS, VEC>(P, start, cnt, base, woff + wid, prod, lane);
             }
         }
         __syncthreads();

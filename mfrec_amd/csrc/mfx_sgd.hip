@@ -156,18 +156,20 @@ template <int MODE, typename TS, bool TAIL>
 void *k1_pick(int k, int batch)
 {
 #define MFX_K1(KP, FPL, B) (TAIL ? (void *)k1_tail<KP, FPL, B, MODE, 0, TS> : (void *)k1_level<KP, FPL, B, MODE, 0, TS>)
-    // 16 bytes per lane (contiguous feature pair), f64 rows, even k in (32, 128]: vec = 1 plain
+    // (the tail kernel runs several levels in one launch: it keeps plain stores, which the compiler
+    // drains before the workgroup barrier between levels -- an asm store would slip past it)
+    // 16 bytes per lane (contiguous feature pair), f64 rows, even k in (4, 128]: vec = 1 plain
     // stores, vec = 2 (default) write-through stores -- no dirty lines left for the end-of-kernel
     // write-back.  cfg 2: 1.68 (8 B per lane) / 1.75 / 1.88 G updates/s; 16 or 4 ratings per wave,
     // and write-through bias stores, measured slower.
     if constexpr (sizeof(TS) == 8 && MODE != K1_LEARNED) {
         const int vec = k1_vec_mode();
-        if (vec && k % 2 == 0 && k > 32 && k <= 128 && batch == 8) {
-// (the tail kernel runs several levels in one launch: it keeps plain stores, which the compiler
-// drains before the workgroup barrier between levels -- an asm store would slip past it)
-#define MFX_K1V(KP, NTF) (TAIL ? (void *)k1_tail<KP, 2, 8, MODE, 0, TS, true> : (void *)k1_level<KP, 2, 8, MODE, NTF, TS, true>)
-            if (k <= 64) return vec == 2 ? MFX_K1V(32, 2) : MFX_K1V(32, 0);
-            return vec == 2 ? MFX_K1V(64, 2) : MFX_K1V(64, 0);
+        if (vec && k % 2 == 0 && k > 4 && k <= 128) {
+#define MFX_K1V(KP, B, NTF) (TAIL ? (void *)k1_tail<KP, 2, B, MODE, 0, TS, true> : (void *)k1_level<KP, 2, B, MODE, NTF, TS, true>)
+            if (k <= 16 && batch == 16) return vec == 2 ? MFX_K1V(8, 16, 2) : MFX_K1V(8, 16, 0);
+            if (k > 16 && k <= 32 && batch == 16) return vec == 2 ? MFX_K1V(16, 16, 2) : MFX_K1V(16, 16, 0);
+            if (k > 32 && k <= 64 && batch == 8) return vec == 2 ? MFX_K1V(32, 8, 2) : MFX_K1V(32, 8, 0);
+            if (k > 64 && batch == 8) return vec == 2 ? MFX_K1V(64, 8, 2) : MFX_K1V(64, 8, 0);
 #undef MFX_K1V
         }
     }

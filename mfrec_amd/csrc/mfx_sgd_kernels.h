@@ -112,7 +112,12 @@ __device__ __forceinline__ void store16_sc1(double *p, double a, double b)
 {
     typedef double v2f64 __attribute__((ext_vector_type(2)));
     v2f64 v = {a, b};
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+    // s_nop: a VMEM store of more than 8 bytes reads its data VGPRs after issue; a VALU write to them
+    // in the next wait state corrupts the stored value (gfx9 "12-dword store" hazard).  The compiler
+    // inserts that wait state for its own stores but cannot see inside inline asm -- without it the
+    // generated code had v_mul_f64 overwrite the data registers one instruction later (intermittent
+    // wrong rows at full size).  tools/check_dpp_hazard.py lints for the nop.
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
 template <int KP, int FPL, int BATCH, int MODE, int NT, bool FULL, typename TS, bool VEC = false>

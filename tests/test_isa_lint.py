@@ -16,9 +16,11 @@ def test_dpp_hazard_lint():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_dpp_hazard.py")],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert "0 hazards" in out.stdout
-    n = int(out.stdout.split("checked")[1].split()[0])
-    assert n > 1000          # the lint really saw the DPP code
+    assert "0 hazards" in out.stdout and "0 without a trailing s_nop" in out.stdout
+    import re
+    n_dpp = int(re.search(r"checked (\d+) DPP instructions", out.stdout).group(1))
+    n_st = int(re.search(r"checked (\d+) wide asm stores", out.stdout).group(1))
+    assert n_dpp > 1000 and n_st > 50          # the lint really saw the hand-written instructions
 
 
 def test_lint_detects_a_planted_hazard():
@@ -33,3 +35,12 @@ def test_lint_detects_a_planted_hazard():
     nop = ["v_mul_f64 v[2:3], v[4:5], v[6:7]", "s_nop 1",
            "v_fmac_f64_dpp v[0:1], -v[2:3], v[4:5] row_newbcast:3 row_mask:0xf bank_mask:0xf"]
     assert L.scan(nop, verbose=False) == (1, 0)
+
+
+def test_lint_detects_a_wide_asm_store_without_nop():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_dpp_hazard as L
+    bad = [";;#ASMSTART", "global_store_dwordx4 v[0:1], v[2:5], off sc0 sc1", ";;#ASMEND", "v_mul_f64 v[2:3], v[6:7], v[8:9]"]
+    assert L.scan_asm_stores(bad) == (1, 1)
+    ok = [";;#ASMSTART", "global_store_dwordx4 v[0:1], v[2:5], off sc0 sc1", "s_nop 1", ";;#ASMEND"]
+    assert L.scan_asm_stores(ok) == (1, 0)

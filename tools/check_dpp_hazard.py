@@ -48,7 +48,45 @@ def scan(lines, verbose=True):
     return n, bad
 
 
+def scan_asm_stores(lines):
+    """-> (asm stores of more than 8 bytes, those NOT followed by an s_nop inside their asm block).
+    Such a store reads its data VGPRs after issue: the next instruction must not be a VALU write to them,
+    and only the compiler's own stores get that wait state automatically."""
+    n = bad = 0
+    in_asm = False
+    pending = False
+    for line in lines:
+        t = line.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm, pending = True, False
+        elif t.startswith(";;#ASMEND"):
+            if pending:
+                bad += 1
+            in_asm = pending = False
+        elif in_asm and t:
+            if t.startswith(("global_store_dwordx4", "global_store_dwordx3", "buffer_store_dwordx4", "buffer_store_dwordx3")):
+                if pending:
+                    bad += 1
+                n += 1
+                pending = True
+            elif t.startswith("s_nop"):
+                pending = False
+    return n, bad
+
+
+def compile_isa(src):
+    tmp = tempfile.mkdtemp()
+    subprocess.check_call(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off",
+                           "-I" + root + "/include", "-I" + root + "/mfrec_amd/csrc", "-c",
+                           root + "/mfrec_amd/csrc/" + src, "-save-temps", "-o", "x.o"], cwd=tmp)
+    asm = [f for f in os.listdir(tmp) if f.endswith("gfx950.s")][0]
+    return open(os.path.join(tmp, asm)).readlines()
+
+
 def main():
+    lines = compile_isa("mfx_sgd.hip")
+    ns, bs = scan_asm_stores(lines)
+    print("checked %d wide asm stores in mfx_sgd.hip, %d without a trailing s_nop" % (ns, bs))
     tmp = tempfile.mkdtemp()
     subprocess.check_call(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off",
                            "-I" + root + "/include", "-I" + root + "/mfrec_amd/csrc", "-c",
@@ -56,7 +94,7 @@ def main():
     asm = [f for f in os.listdir(tmp) if f.endswith("gfx950.s")][0]
     n, bad = scan(open(os.path.join(tmp, asm)))
     print("checked %d DPP instructions, %d hazards" % (n, bad))
-    return 1 if bad else 0
+    return 1 if (bad or bs or ns == 0) else 0
 
 
 if __name__ == "__main__":

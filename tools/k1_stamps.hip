@@ -12,7 +12,7 @@ using namespace mfx;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
-template <int BATCH, int NT>
+template <int BATCH, int NT, int KP = 64, int FPL = 1, bool VEC = false>
 int run(int count, int nu, int ni, int uncached = 0)
 {
     const int k = 64;
@@ -45,7 +45,7 @@ int run(int count, int nu, int ni, int uncached = 0)
     for (int it = 0; it < 3; ++it) {
         CK(hipEventRecord(e0));
         for (int rep = 0; rep < 50; ++rep)
-            hipLaunchKernelGGL((k1_level<64, 1, BATCH, K1_LINEAR, NT>), dim3(blocks), dim3(kWaves * 64), lds, 0, P, (int64_t)0, count, (int64_t)0);
+            hipLaunchKernelGGL((k1_level<KP, FPL, BATCH, K1_LINEAR, NT, double, VEC>), dim3(blocks), dim3(kWaves * 64), lds, 0, P, (int64_t)0, count, (int64_t)0);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         ms /= 50;
     }
@@ -60,7 +60,7 @@ int run(int count, int nu, int ni, int uncached = 0)
     }
     auto med = [](std::vector<double> &v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
     auto mx = [](std::vector<double> &v) { return *std::max_element(v.begin(), v.end()); };
-    printf("kwaves %d uncached %d nt %d batch %2d count %d blocks %d  event %.2f us | span first-stamp..last-stamp %.0f ticks\n", kWaves, uncached, NT, BATCH, count, blocks, ms * 1e3, (double)(t1 - t0));
+    printf("KP %d vec %d kwaves %d uncached %d nt %d batch %2d count %d blocks %d  event %.2f us | span first-stamp..last-stamp %.0f ticks\n", KP, (int)VEC, kWaves, uncached, NT, BATCH, count, blocks, ms * 1e3, (double)(t1 - t0));
     printf("   median ticks: rec %.0f  rows %.0f  lds+sum+bias %.0f  update+issue-stores %.0f  drain %.0f\n",
            med(d[0]), med(d[1]), med(d[2]), med(d[3]), med(d[4]));
     hipFree(dr); hipFree(dU); hipFree(dV); hipFree(dib); hipFree(dub); hipFree(dse); hipFree(dst);
@@ -73,6 +73,9 @@ int main()
         if (run<8, 0>(count, 100000, 50000, 0)) return 1;
         if (run<8, 0>(count, 100000, 50000, 1)) return 1;
         if (run<8, 3>(count, 100000, 50000, 0)) return 1;
+        if (run<8, 0, 32, 2, true>(count, 100000, 50000, 0)) return 1;      // 16 B per lane, plain stores
+        if (run<8, 2, 32, 2, true>(count, 100000, 50000, 0)) return 1;      // 16 B per lane, write-through stores
+        if (run<8, 3, 32, 2, true>(count, 100000, 50000, 0)) return 1;      // 16 B per lane, no row stores
     }
     return 0;
 }

@@ -32,6 +32,9 @@ def test_lint_detects_a_planted_hazard():
     bad = ["v_mul_f64 v[2:3], v[4:5], v[6:7]",
            "v_fmac_f64_dpp v[0:1], -v[2:3], v[4:5] row_newbcast:3 row_mask:0xf bank_mask:0xf"]
     assert L.scan(bad, verbose=False) == (1, 1)
+    cmpx = ["v_cmpx_lt_i32_e32 15, v0", "v_mul_f64 v[8:9], v[4:5], v[6:7]",
+            "v_fmac_f64_dpp v[0:1], -v[2:3], v[4:5] row_newbcast:3 row_mask:0xf bank_mask:0xf"]
+    assert L.scan(cmpx, verbose=False) == (1, 1)
     nop = ["v_mul_f64 v[2:3], v[4:5], v[6:7]", "s_nop 1",
            "v_fmac_f64_dpp v[0:1], -v[2:3], v[4:5] row_newbcast:3 row_mask:0xf bank_mask:0xf"]
     assert L.scan(nop, verbose=False) == (1, 0)

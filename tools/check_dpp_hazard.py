@@ -17,6 +17,7 @@ def regs(tok):
 
 def scan(lines, verbose=True):
     """-> (number of DPP instructions seen, number of hazards)"""
+    hist_ops = []
     hist, bad, n = [], 0, 0          # hist: (VGPRs written, wait states if s_nop) of preceding instructions
     for line in lines:
         t = line.strip()
@@ -24,11 +25,26 @@ def scan(lines, verbose=True):
             continue
         op, _, rest = t.partition(" ")
         ops = [x.strip() for x in rest.split(";")[0].split(",")]
+        hist_ops.append(t)
         if op.startswith("s_nop"):
             hist.append((set(), int(ops[0]) + 1))
             continue
         if "_dpp" in op and len(ops) >= 2:
             n += 1
+            # VALU write of EXEC (v_cmpx*) needs 5 wait states before a DPP instruction
+            recent, ws = list(hist_ops[-6:]), 0
+            for prev in reversed(recent):
+                if prev.startswith("s_nop"):
+                    ws += int(prev.split()[1]) + 1 if len(prev.split()) > 1 else 1
+                    continue
+                if ws >= 5:
+                    break
+                if prev.startswith("v_cmpx"):
+                    bad += 1
+                    if verbose:
+                        print("HAZARD (v_cmpx -> DPP):", t)
+                    break
+                ws += 1
             src0 = regs(ops[1].split()[0])
             wait = 0
             for w, nop in reversed(hist[-4:]):

@@ -162,8 +162,9 @@ void *k1_pick(int k, int batch)
     // stores, vec = 2 (default) write-through stores -- no dirty lines left for the end-of-kernel
     // write-back.  cfg 2: 1.68 (8 B per lane) / 1.75 / 1.88 G updates/s; 16 or 4 ratings per wave,
     // and write-through bias stores, measured slower.
-    if constexpr (sizeof(TS) == 8 && MODE != K1_LEARNED) {
-        const int vec = k1_vec_mode();
+    if constexpr (sizeof(TS) == 8) {
+        // the learned-bias family stores ONE feature per row: 16-byte loads only, plain stores
+        const int vec = (MODE == K1_LEARNED && k1_vec_mode()) ? 1 : k1_vec_mode();
         if (vec && k % 2 == 0 && k > 4 && k <= 128) {
 #define MFX_K1V(KP, B, NTF) (TAIL ? (void *)k1_tail<KP, 2, B, MODE, 0, TS, true> : (void *)k1_level<KP, 2, B, MODE, NTF, TS, true>)
             if (k <= 16 && batch == 16) return vec == 2 ? MFX_K1V(8, 16, 2) : MFX_K1V(8, 16, 0);

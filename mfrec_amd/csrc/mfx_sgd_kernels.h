@@ -138,7 +138,13 @@ __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cn
     // ---- the rating owned by this lane (lanes 0..cnt-1) -------------------------------
     Rec rec;
     rec.user = 0; rec.item = 0; rec.r = 0.0;
-    if (FULL ? (lane < BATCH) : (lane < cnt)) rec = P.recs[start + base + lane];
+    if (FULL ? (lane < BATCH) : (lane < cnt)) {
+        // records are read once per epoch: non-temporal, so that the stream does not displace factor
+        // rows from L2 / Infinity Cache (cfg 2 +0.1 %, cfg-3 shard shape +2.5 %, cfg-5 shard shape +0.6 %)
+        typedef int v4i32 __attribute__((ext_vector_type(4)));
+        const v4i32 raw = __builtin_nontemporal_load(reinterpret_cast<const v4i32 *>(P.recs + start + base + lane));
+        rec = __builtin_bit_cast(Rec, raw);
+    }
 #ifdef MFX_K1_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif

@@ -164,7 +164,7 @@ void *k1_pick(int k, int batch)
     // and write-through bias stores, measured slower.
     if constexpr (sizeof(TS) == 8) {
         // the learned-bias family stores ONE feature per row: 16-byte loads only, plain stores
-        const int vec = (MODE == K1_LEARNED && k1_vec_mode()) ? 1 : k1_vec_mode();
+        const int vec = (MODE == K1_LEARNED && k1_vec_mode()) ? 1 : k1_vec_mode();   // (write-through scalars: no gain)
         if (vec && k % 2 == 0 && k > 4 && k <= 128) {
 #define MFX_K1V(KP, B, NTF) (TAIL ? (void *)k1_tail<KP, 2, B, MODE, 0, TS, true> : (void *)k1_level<KP, 2, B, MODE, NTF, TS, true>)
             if (k <= 16 && batch == 16) return vec == 2 ? MFX_K1V(8, 16, 2) : MFX_K1V(8, 16, 0);
@@ -696,8 +696,12 @@ static int enqueue_k2_epoch(mfx_sgd_plan *p, const K2Params &P)
         if (!sg.tail) {
             const int64_t start = p->level_off[sg.l0];
             const int count = (int)(p->level_off[sg.l0 + 1] - start);
-            hipLaunchKernelGGL(k2_level, dim3(ceil_div(count, kK2Block)), dim3(kK2Block), 0, stream(), P,
-                               start, count, p->k2_wave_off[sg.l0]);
+            if (count <= kK2WriteThroughMax)
+                hipLaunchKernelGGL(k2_level<true>, dim3(ceil_div(count, kK2Block)), dim3(kK2Block), 0, stream(), P,
+                                   start, count, p->k2_wave_off[sg.l0]);
+            else
+                hipLaunchKernelGGL(k2_level<false>, dim3(ceil_div(count, kK2Block)), dim3(kK2Block), 0, stream(), P,
+                                   start, count, p->k2_wave_off[sg.l0]);
         } else {
             hipLaunchKernelGGL(k2_tail, dim3(1), dim3(kTail2), 0, stream(), P,
                                (const int64_t *)p->d_level_off, (const int64_t *)p->d_k2_wave_off,

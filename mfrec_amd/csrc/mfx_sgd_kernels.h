@@ -462,6 +462,7 @@ __device__ __forceinline__ double funk_estimate(double uf, double vf, double cac
     return sum;
 }
 
+template <bool WT = false>
 __device__ __forceinline__ double k2_one(const K2Params &P, double *uf, double *vf, double trail,
                                          int64_t start, int t, int count)
 {
@@ -476,8 +477,16 @@ __device__ __forceinline__ double k2_one(const K2Params &P, double *uf, double *
         const double p = funk_estimate(mf, cf, c, base, trail, true);
         const double err = rec.r - p;
         e2 = err * err;
-        if (P.upd_i) uf[rec.item] = mf + P.lr * (err * cf - P.K * mf);
-        if (P.upd_u) vf[rec.user] = cf + P.lr * (err * mf - P.K * cf);
+        const double un = mf + P.lr * (err * cf - P.K * mf), vn = cf + P.lr * (err * mf - P.K * cf);
+        if constexpr (WT) {
+            // one launch per level: write-through (sc1) stores leave no dirty L2 lines for the
+            // end-of-kernel write-back (2.35 -> 2.08 ms per pass at cfg 2)
+            if (P.upd_i) __hip_atomic_store(uf + rec.item, un, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (P.upd_u) __hip_atomic_store(vf + rec.user, vn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (P.upd_i) uf[rec.item] = un;
+            if (P.upd_u) vf[rec.user] = vn;
+        }
     }
     return e2;
 }
@@ -486,12 +495,16 @@ __device__ __forceinline__ double k2_one(const K2Params &P, double *uf, double *
 #define MFX_K2_BLOCK 64
 #endif
 static constexpr int kK2Block = MFX_K2_BLOCK;    // threads per block of the Funk level kernel
+// WT: write-through scalar stores -- faster for small levels (16 K ratings: 2.35 -> 2.08 ms per pass),
+// slower for large ones (37 K ratings: 1.23 -> 1.34 ms per pass); the host picks per level
+static constexpr int kK2WriteThroughMax = 24576;
+template <bool WT>
 __global__ __launch_bounds__(kK2Block) void k2_level(K2Params P, int64_t start, int count,
                                                      int64_t wave_off)
 {
     const int t = blockIdx.x * kK2Block + threadIdx.x;
     double *const uf = P.dyn->uf, *const vf = P.dyn->vf;
-    const double e2 = k2_one(P, uf, vf, P.dyn->trail, start, t, count);
+    const double e2 = k2_one<WT>(P, uf, vf, P.dyn->trail, start, t, count);
     const double wsum = wave_sum_fixed(e2);
     if ((threadIdx.x & 63) == 0)
         P.se_partial[wave_off + (int64_t)blockIdx.x * (kK2Block / 64) + (threadIdx.x >> 6)] = wsum;

@@ -167,18 +167,26 @@ __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cn
         ur[s] = (TS *)P.U + (size_t)itm * k;
         vr[s] = (TS *)P.V + (size_t)usr * k;
     }
-    static_assert(!VEC || (FPL == 2 && sizeof(TS) == 8), "VEC: one 16-byte f64 pair per lane");
+    static_assert(!VEC || (FPL % 2 == 0 && sizeof(TS) == 8), "VEC: 16-byte f64 pairs per lane");
     if constexpr (VEC) {
+        // pair j of lane q = features (2q + 2*KP*j, +1): every wave instruction moves 64 x 16 contiguous bytes
 #pragma unroll
-        for (int s = 0; s < NR; ++s) { uval[s][0] = uval[s][1] = 0.0; vval[s][0] = vval[s][1] = 0.0; }
-        if (2 * q < k) {                                  // k is even
+        for (int j = 0; j < FPL; ++j) {
 #pragma unroll
-            for (int s = 0; s < NR; ++s) {
-                if (FULL || (s * SPW + g < cnt)) {
-                    const v2f64_a8 a = *reinterpret_cast<const v2f64_a8 *>((const double *)ur[s] + 2 * q);
-                    const v2f64_a8 b = *reinterpret_cast<const v2f64_a8 *>((const double *)vr[s] + 2 * q);
-                    uval[s][0] = a.x; uval[s][1] = a.y;
-                    vval[s][0] = b.x; vval[s][1] = b.y;
+            for (int s = 0; s < NR; ++s) { uval[s][j] = 0.0; vval[s][j] = 0.0; }
+        }
+#pragma unroll
+        for (int j = 0; j < FPL / 2; ++j) {
+            const int f0 = 2 * q + 2 * KP * j;
+            if (f0 < k) {                                 // k is even
+#pragma unroll
+                for (int s = 0; s < NR; ++s) {
+                    if (FULL || (s * SPW + g < cnt)) {
+                        const v2f64_a8 a = *reinterpret_cast<const v2f64_a8 *>((const double *)ur[s] + f0);
+                        const v2f64_a8 b = *reinterpret_cast<const v2f64_a8 *>((const double *)vr[s] + f0);
+                        uval[s][2 * j] = a.x; uval[s][2 * j + 1] = a.y;
+                        vval[s][2 * j] = b.x; vval[s][2 * j + 1] = b.y;
+                    }
                 }
             }
         }
@@ -211,11 +219,16 @@ __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cn
 
     // ---- products to LDS: prod[n][f] -------------------------------------------------
     if constexpr (VEC) {
-        if (2 * q < k) {
 #pragma unroll
-            for (int s = 0; s < NR; ++s) {
-                double *pp = prod + (s * SPW + g) * stride + 2 * q;          // rows 16-B aligned
-                *reinterpret_cast<double2 *>(pp) = make_double2(uval[s][0] * vval[s][0], uval[s][1] * vval[s][1]);
+        for (int j = 0; j < FPL / 2; ++j) {
+            const int f0 = 2 * q + 2 * KP * j;
+            if (f0 < k) {
+#pragma unroll
+                for (int s = 0; s < NR; ++s) {
+                    double *pp = prod + (s * SPW + g) * stride + f0;         // rows 16-B aligned, f0 even
+                    *reinterpret_cast<double2 *>(pp) = make_double2(uval[s][2 * j] * vval[s][2 * j],
+                                                                    uval[s][2 * j + 1] * vval[s][2 * j + 1]);
+                }
             }
         }
     } else {
@@ -294,24 +307,29 @@ __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cn
         }
     }
     if constexpr (VEC && MODE != K1_LEARNED) {
-        if (2 * q < k) {
 #pragma unroll
-            for (int s = 0; s < NR; ++s) {
-                if (FULL || (s * SPW + g < cnt)) {
-                    const double mf0 = uval[s][0], mf1 = uval[s][1], cf0 = vval[s][0], cf1 = vval[s][1];
-                    const double un0 = mf0 + P.lr * (gr[s] * cf0 - P.Ki * mf0);   // kmf_train.pyx:267-270
-                    const double un1 = mf1 + P.lr * (gr[s] * cf1 - P.Ki * mf1);
-                    const double vn0 = cf0 + P.lr * (gr[s] * mf0 - P.Ku * cf0);
-                    const double vn1 = cf1 + P.lr * (gr[s] * mf1 - P.Ku * cf1);
-                    double *up = (double *)ur[s] + 2 * q, *vp = (double *)vr[s] + 2 * q;
-                    if constexpr (NT == 2) {               // 16-byte write-through stores
-                        if (FULL || P.upd_i) store16_sc1(up, un0, un1);
-                        if (FULL || P.upd_u) store16_sc1(vp, vn0, vn1);
-                    } else {
-                        v2f64_a8 a, b;
-                        a.x = un0; a.y = un1; b.x = vn0; b.y = vn1;
-                        if (FULL || P.upd_i) *reinterpret_cast<v2f64_a8 *>(up) = a;
-                        if (FULL || P.upd_u) *reinterpret_cast<v2f64_a8 *>(vp) = b;
+        for (int j = 0; j < FPL / 2; ++j) {
+            const int f0 = 2 * q + 2 * KP * j;
+            if (f0 < k) {
+#pragma unroll
+                for (int s = 0; s < NR; ++s) {
+                    if (FULL || (s * SPW + g < cnt)) {
+                        const double mf0 = uval[s][2 * j], mf1 = uval[s][2 * j + 1];
+                        const double cf0 = vval[s][2 * j], cf1 = vval[s][2 * j + 1];
+                        const double un0 = mf0 + P.lr * (gr[s] * cf0 - P.Ki * mf0);   // kmf_train.pyx:267-270
+                        const double un1 = mf1 + P.lr * (gr[s] * cf1 - P.Ki * mf1);
+                        const double vn0 = cf0 + P.lr * (gr[s] * mf0 - P.Ku * cf0);
+                        const double vn1 = cf1 + P.lr * (gr[s] * mf1 - P.Ku * cf1);
+                        double *up = (double *)ur[s] + f0, *vp = (double *)vr[s] + f0;
+                        if constexpr (NT == 2) {               // 16-byte write-through stores
+                            if (FULL || P.upd_i) store16_sc1(up, un0, un1);
+                            if (FULL || P.upd_u) store16_sc1(vp, vn0, vn1);
+                        } else {
+                            v2f64_a8 a, b;
+                            a.x = un0; a.y = un1; b.x = vn0; b.y = vn1;
+                            if (FULL || P.upd_i) *reinterpret_cast<v2f64_a8 *>(up) = a;
+                            if (FULL || P.upd_u) *reinterpret_cast<v2f64_a8 *>(vp) = b;
+                        }
                     }
                 }
             }
@@ -319,7 +337,7 @@ __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cn
     } else {
 #pragma unroll
     for (int j = 0; j < FPL; ++j) {
-        const int f = VEC ? (q * FPL + j) : (j * KP + q);
+        const int f = VEC ? (2 * q + 2 * KP * (j / 2) + (j & 1)) : (j * KP + q);
         if constexpr (MODE == K1_LEARNED) {
             if (f == P.f) {                                           // gd_estimator.pyx:476-477
 #pragma unroll

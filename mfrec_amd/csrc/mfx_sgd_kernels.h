@@ -246,7 +246,7 @@ __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cn
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
     // ---- lane n: strictly sequential k-term sum, error, gradient, bias update ---------
-    double grad = 0.0, e2 = 0.0;
+    double grad = 0.0, e2 = 0.0, ubn = 0.0, ibn = 0.0;
     if (FULL ? (lane < BATCH) : (lane < cnt)) {
         double sum;
         if constexpr (MODE == K1_LEARNED) sum = P.mu + ibv + ubv;     // gd_estimator.pyx:138
@@ -284,12 +284,12 @@ __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cn
             P.ub[rec.user] = ubv + P.lr_u * (err - P.Kb * ubv);       // gd_estimator.pyx:473-474
             P.ib[rec.item] = ibv + P.lr_i * (err - P.Kb * ibv);
         } else {
-            // linear: unconditional (kmf_train.pyx:259-260); logistic: gated (:168-171)
-            const double ubn = ubv + P.lr * (grad - P.Kb * ubv), ibn = ibv + P.lr * (grad - P.Kb * ibv);
-            {
-                if (FULL || MODE == K1_LINEAR || P.upd_u) P.ub[rec.user] = ubn;
-                if (FULL || MODE == K1_LINEAR || P.upd_i) P.ib[rec.item] = ibn;
-            }
+            // linear: unconditional (kmf_train.pyx:259-260); logistic: gated (:168-171).  The stores are
+            // issued at the very end of the body: behind this branch hipcc drains the memory pipe
+            // (s_waitcnt vmcnt(0)) before it goes on -- a store round trip in the middle of the wave
+            // (+1.3 % from moving them; write-through or padded whole-granule bias stores: slower).
+            ubn = ubv + P.lr * (grad - P.Kb * ubv);
+            ibn = ibv + P.lr * (grad - P.Kb * ibv);
         }
     }
     MFX_STAMP(3);
@@ -379,6 +379,14 @@ __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cn
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     MFX_STAMP(5);
+
+    // ---- bias stores (linear / logistic), after every other memory operation of the wave ------
+    if constexpr (MODE != K1_LEARNED) {
+        if (FULL ? (lane < BATCH) : (lane < cnt)) {
+            if (FULL || MODE == K1_LINEAR || P.upd_u) P.ub[rec.user] = ubn;
+            if (FULL || MODE == K1_LINEAR || P.upd_i) P.ib[rec.item] = ibn;
+        }
+    }
 
     // ---- squared-error partial of this wave (deterministic) ---------------------------
     const double wsum = wave_sum_fixed(e2);

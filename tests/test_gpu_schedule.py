@@ -95,3 +95,18 @@ def test_auto_falls_back_to_host_when_levels_explode():
         info = p.info()
     assert info["schedule_builder"] == "host"
     assert info["n_levels"] >= nnz // 2
+
+
+def test_device_builder_refuses_more_levels_than_its_budget_and_bad_flags():
+    from mfrec_amd import _shim as S
+    from mfrec_amd.plan import SgdPlan
+    # a single user with 2^22 + 1 ratings needs that many levels: explicit "device" must fail loudly
+    nnz = (1 << 22) + 1
+    idx = np.zeros((nnz, 2), dtype=np.int32)
+    idx[:, 1] = np.arange(nnz) % 1000
+    with pytest.raises(S.MfxError, match="levels"):
+        SgdPlan(idx, np.ones(nnz), 1, 1000, 2, schedule="device")
+    with pytest.raises(ValueError, match="schedule"):
+        SgdPlan(idx[:10], np.ones(10), 1, 1000, 2, schedule="gpu")
+    h = S.lib().mfx_sgd_plan_create2(S.i32(idx[:10], "idx", 2), S.f64(np.ones(10), "r", 1), 10, 1, 1000, 2, 7)
+    assert not h and "bad argument" in S.last_error()

@@ -69,3 +69,24 @@ def test_funk_and_learned_bias_random_shapes():
             O.estimator_loop_with_learned_bias(2, 2, 1e9, k, init, 0.01, 0.008, 0.006, 0.05, 0.01, 3.0, fu2, fv2, idx, r, ib2, ub2, nu, ni)
             assert np.array_equal(ib1, ib2) and np.array_equal(ub1, ub2)
         assert np.array_equal(fu, fu2) and np.array_equal(fv, fv2), "case %d k=%d nnz=%d" % (it, k, len(r))
+
+
+def test_every_even_k_through_the_level_kernel_and_the_tail():
+    """16-byte-lane kernels (VEC): every even k up to 130 plus the wide ones, with levels large enough
+    for k1_level (first levels ~1500 ratings) and small enough for k1_tail (the last ones), both
+    update-gate settings, linear (bit-exact) -- guards the lane/feature-pair mapping of every KP/FPL."""
+    from mfrec_amd.lib import kmf_train as K
+    from oracle import oracle as O
+    rs = np.random.RandomState(99)
+    nu, ni, nnz = 2000, 1500, 4000
+    idx = np.stack([rs.randint(0, nu, nnz), rs.randint(0, ni, nnz)], 1).astype(np.int32)
+    r = rs.randint(1, 6, nnz).astype(np.float64)
+    for k in list(range(2, 132, 2)) + [200, 256, 258, 384, 512]:
+        u0, v0 = rs.normal(0, 0.1, (k, ni)), rs.normal(0, 0.1, (k, nu))
+        gates = (1, 1) if k % 4 else (1, 0)
+        u, v, ib, ub = u0.copy(), v0.copy(), np.zeros(ni), np.zeros(nu)
+        K.train_linear_kernel(2, k, 0.1, 0.02, 0, 0, 0.1, 0.05, 0.007, 0.0, u, v, idx, r, ib, ub, *gates)
+        u2, v2, ib2, ub2 = u0.copy(), v0.copy(), np.zeros(ni), np.zeros(nu)
+        O.train_linear_kernel(2, k, 0.1, 0.02, 0, 0, 0.1, 0.05, 0.007, 0.0, u2, v2, idx, r, ib2, ub2, *gates)
+        assert np.array_equal(u, u2) and np.array_equal(v, v2), "k=%d gates=%s" % (k, gates)
+        assert np.array_equal(ib, ib2) and np.array_equal(ub, ub2), "k=%d" % k

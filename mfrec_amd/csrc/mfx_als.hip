@@ -280,30 +280,44 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 ? 2 : (NT >= 5 ? 2 : 3))) void k_
     const int nchunks = (span + CH2 - 1) / CH2;
     if (tid < CH2) cidx[tid] = (tid < span) ? col[start + tid] : -1;
     __syncthreads();
-    double pre[PF];
+    // feature PAIRS: one 16-byte load per pair when k is even (see k_als_rows3), 16-byte staging stores
+    typedef double v2f64_a8 __attribute__((ext_vector_type(2), aligned(8)));
+    constexpr int PF2 = PF / 2;
+    static_assert(PF % 2 == 0, "pairs");
+    const bool keven = (k & 1) == 0;
+    double2 pre[PF2];
+    auto fetch = [&](int cbase) {
 #pragma unroll
-    for (int i = 0; i < PF; ++i) {
-        const int e = tid + NTHR * i, n = e / KP, f = e % KP;
-        const int id = cidx[n];
-        pre[i] = (id >= 0 && f < k) ? Y[(size_t)id * k + f] : 0.0;
-    }
+        for (int i = 0; i < PF2; ++i) {
+            const int e = 2 * (tid + NTHR * i), n = e / KP, f = e % KP;
+            const int id = cidx[cbase + n];
+            double2 v = make_double2(0.0, 0.0);
+            if (id >= 0 && f < k) {
+                const double *src = Y + (size_t)id * k + f;
+                if (keven) {
+                    const v2f64_a8 w = *reinterpret_cast<const v2f64_a8 *>(src);
+                    v = make_double2(w.x, w.y);
+                } else {
+                    v.x = src[0];
+                    if (f + 1 < k) v.y = src[1];
+                }
+            }
+            pre[i] = v;
+        }
+    };
+    fetch(0);
     int cnext = (tid < CH2 && CH2 + tid < span) ? col[start + CH2 + tid] : -1;
     for (int c = 0; c < nchunks; ++c) {
 #pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            const int e = tid + NTHR * i, n = e / KP, f = e % KP;
-            ych[n * S + f] = pre[i];
+        for (int i = 0; i < PF2; ++i) {
+            const int e = 2 * (tid + NTHR * i), n = e / KP, f = e % KP;
+            *reinterpret_cast<double2 *>(ych + n * S + f) = pre[i];
         }
         const int nb = ((c + 1) & 1) * CH2;
         if (tid < CH2) cidx[nb + tid] = cnext;
         __syncthreads();
         if (c + 1 < nchunks) {
-#pragma unroll
-            for (int i = 0; i < PF; ++i) {
-                const int e = tid + NTHR * i, n = e / KP, f = e % KP;
-                const int id = cidx[nb + n];
-                pre[i] = (id >= 0 && f < k) ? Y[(size_t)id * k + f] : 0.0;
-            }
+            fetch(nb);
             const int t2 = (c + 2) * CH2 + tid;
             cnext = (tid < CH2 && t2 < span) ? col[start + t2] : -1;
         }

@@ -166,8 +166,8 @@ def main():
     if a.order == "user-major":
         idx, r = synth.user_major(idx, r)
     elif a.order == "balanced":
-        from mfrec_amd.lib.datasets import balanced_order
-        perm, _ = balanced_order(idx, nu, ni, seed=11)
+        from mfrec_amd.lib.datasets import balanced_order_gpu
+        perm, _ = balanced_order_gpu(idx, nu, ni)          # recolours the (already shuffled) synthetic order
         idx, r = np.ascontiguousarray(idx[perm]), np.ascontiguousarray(r[perm])
     u0 = synth.init_normal(k, ni, synth.SEED_INIT)
     v0 = synth.init_normal(k, nu, synth.SEED_INIT + 1 + rank)
@@ -257,8 +257,8 @@ def main():
             # secondary, clearly labelled data point (not `value`): the same exact kernel on a
             # balanced input order (fewest dependency levels)
             try:
-                from mfrec_amd.lib.datasets import balanced_order
-                perm, rounds = balanced_order(idx, nu, ni, seed=11)
+                from mfrec_amd.lib.datasets import balanced_order_gpu
+                perm, rounds = balanced_order_gpu(idx, nu, ni)
                 with SgdPlan(np.ascontiguousarray(idx[perm]), np.ascontiguousarray(r[perm]), nu, ni, k) as p2:
                     p2.set_factors(u0, v0, np.zeros(ni), np.zeros(nu))
                     p2.run_kmf(LINEAR, 1, LR, KU, KI, KB, want_rmse=False)

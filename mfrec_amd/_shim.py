@@ -37,6 +37,7 @@ SIGNATURES = {
     "mfx_schedule_permutation": (C.c_int, [_ip, C.c_int64, C.c_int64, _lp, _lp]),
     "mfx_schedule_pack": (C.c_int, [_ip, _dp, _ip, C.c_int64, C.c_int64, C.c_void_p, _lp]),
     "mfx_schedule_balanced_order": (C.c_int, [_ip, C.c_int64, C.c_int, C.c_int, C.c_uint64, _lp, _lp]),
+    "mfx_schedule_balanced_order_gpu": (C.c_int, [_ip, C.c_int64, C.c_int, C.c_int, _lp, _lp]),
     "mfx_kmf_train": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                 C.c_double, _dp, _dp, _ip, _dp, _dp, _dp, C.c_int64, C.c_int,
                                 C.c_int, C.c_int, C.c_int, _dp]),

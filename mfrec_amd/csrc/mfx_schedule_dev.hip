@@ -125,6 +125,39 @@ __global__ void k_gather_recs(const int32_t *__restrict__ order, const int2 *__r
     }
 }
 
+// First-fit recolouring of ONE level (= a set of ratings with pairwise distinct users and items): every
+// rating moves to the smallest colour no earlier-processed rating of its user or item holds.  Levels are
+// processed in order, so colour (level - 1) is always free: the scan ends inside the first `level` bits.
+// No two threads touch the same bitset row, so the result is deterministic.
+__global__ void k_compact_level(const int32_t *__restrict__ order, int64_t off, int count,
+                                const int32_t *__restrict__ users, const int32_t *__restrict__ items,
+                                unsigned long long *ubits, unsigned long long *ibits, int W, int32_t *colour)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= count) return;
+    const int32_t t = order[off + e];
+    unsigned long long *bu = ubits + (size_t)users[t] * W, *bi = ibits + (size_t)items[t] * W;
+    for (int w = 0; w < W; ++w) {
+        const unsigned long long a = bu[w], b = bi[w], m = ~(a | b);
+        if (m) {
+            const int bit = __ffsll((long long)m) - 1;
+            bu[w] = a | (1ull << bit);
+            bi[w] = b | (1ull << bit);
+            colour[t] = w * 64 + bit + 1;                 // colours are 1-based like levels
+            return;
+        }
+    }
+    colour[t] = W * 64;                                   // unreachable (see above)
+}
+
+// sorted keys (1-based colours, no gaps) -> start offset of every colour class
+__global__ void k_class_bounds(const int32_t *__restrict__ keys, int64_t nnz, unsigned long long *start)
+{
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < nnz;
+         p += (int64_t)gridDim.x * blockDim.x)
+        if (p == 0 || keys[p - 1] != keys[p]) start[keys[p] - 1] = (unsigned long long)p;
+}
+
 int bits_for(int64_t n)      // radix bits that cover keys 0 .. n-1
 {
     int b = 1;
@@ -157,9 +190,14 @@ struct Scratch {
 // Returns MFX_OK and fills level_off (n_levels + 1 entries, level l+1 = [level_off[l], level_off[l+1]))
 // and, when given, d_recs (device, nnz records, level-major) and h_level (host, nnz entries, 1-based).
 // *over_budget = true (with MFX_OK) when the level count exceeded level_budget: nothing was produced.
+// compact = true: the levels are first-fit recoloured (k_compact_level) -- an execution ORDER (colour-major,
+// ascending input index inside a colour) with close to max-degree classes instead of the ~2.3x max-degree
+// levels the input order forces; level_off / d_recs / h_level then describe that order and h_order
+// (nullable, nnz entries) receives it: h_order[j] = input index of the j-th rating.
 int schedule_device(const int32_t *h_idx, const double *h_r, int64_t nnz, int nu, int ni,
                     Rec *d_recs, int32_t *h_level, std::vector<int64_t> &level_off,
-                    int64_t *n_levels, int64_t level_budget, bool *over_budget)
+                    int64_t *n_levels, int64_t level_budget, bool *over_budget, bool compact,
+                    int64_t *h_order)
 {
     mfx::TraceRange trace_("mfx:schedule_device (sorts + frontier levels)");
     *over_budget = false;
@@ -236,14 +274,57 @@ int schedule_device(const int32_t *h_idx, const double *h_r, int64_t nnz, int nu
     if (level_off[(size_t)nl] != nnz)
         return fail(MFX_E_STATE, "device schedule: levelled %lld of %lld ratings", (long long)level_off[(size_t)nl],
                     (long long)nnz);
+    bool sorted = false;                    // (ka, va) = (level, t) in level-major order
+    if (compact && nl > 1) {
+        const int W = (int)ceil_div<int64_t>(nl, 64);
+        const size_t words = ((size_t)nu + (size_t)ni) * (size_t)W;
+        if (words > ((size_t)1 << 29))
+            return fail(MFX_E_NOMEM, "device schedule: colour bitsets of %zu MB", words >> 17);
+        unsigned long long *bits = nullptr, *starts = nullptr;
+        if (S.get(&bits, words) || S.get(&starts, (size_t)nl + 1)) return last_code();
+        MFX_HIP(hipMemsetAsync(bits, 0, words * sizeof(unsigned long long), st));
+        MFX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, level, ka, tvals, va, (int)nnz, 0,
+                                                   bits_for(nl + 1), st));
+        int32_t *colour = next_u;           // the chain arrays are free now
+        for (int64_t l = 0; l < nl; ++l) {
+            const int cnt = (int)(level_off[(size_t)l + 1] - level_off[(size_t)l]);
+            k_compact_level<<<ceil_div(cnt, 256), 256, 0, st>>>(va, level_off[(size_t)l], cnt, users, items, bits,
+                                                                bits + (size_t)nu * W, W, colour);
+        }
+        // colour-major order (stable: ascending input index inside a colour) and the class offsets
+        MFX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, colour, ka, tvals, va, (int)nnz, 0,
+                                                   bits_for(nl + 1), st));
+        MFX_HIP(hipMemsetAsync(starts, 0xff, ((size_t)nl + 1) * sizeof(unsigned long long), st));
+        k_class_bounds<<<blocks, kBfsThreads, 0, st>>>(ka, nnz, starts);
+        std::vector<unsigned long long> hb((size_t)nl);
+        MFX_HIP(hipMemcpyAsync(hb.data(), starts, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        MFX_HIP(hipStreamSynchronize(st));
+        int64_t nc = 0;
+        while (nc < nl && hb[(size_t)nc] != ~0ull) ++nc;                     // first-fit leaves no gaps
+        level_off.assign((size_t)nc + 1, 0);
+        for (int64_t c = 0; c < nc; ++c) level_off[(size_t)c] = (int64_t)hb[(size_t)c];
+        level_off[(size_t)nc] = nnz;
+        for (int64_t c = nc; c < nl; ++c)
+            if (hb[(size_t)c] != ~0ull) return fail(MFX_E_STATE, "device schedule: gap in the colour classes");
+        nl = nc;
+        level = colour;
+        sorted = true;
+    }
     *n_levels = nl;
     if (h_level) MFX_HIP(hipMemcpyAsync(h_level, level, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
 
     // ---- level-major order and records -----------------------------------------------------------
-    if (d_recs) {
-        MFX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, level, ka, tvals, va, (int)nnz, 0,
-                                                   bits_for(nl + 1), st));
-        k_gather_recs<<<blocks, kBfsThreads, 0, st>>>(va, d_idx, d_r, nnz, d_recs);
+    if (d_recs || h_order) {
+        if (!sorted)
+            MFX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, level, ka, tvals, va, (int)nnz, 0,
+                                                       bits_for(nl + 1), st));
+        if (d_recs) k_gather_recs<<<blocks, kBfsThreads, 0, st>>>(va, d_idx, d_r, nnz, d_recs);
+        if (h_order) {
+            std::vector<int32_t> o32(n);
+            MFX_HIP(hipMemcpyAsync(o32.data(), va, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            MFX_HIP(hipStreamSynchronize(st));
+            for (size_t j = 0; j < n; ++j) h_order[j] = o32[j];
+        }
     }
     MFX_HIP(hipGetLastError());
     MFX_HIP(hipStreamSynchronize(st));
@@ -265,12 +346,35 @@ extern "C" int mfx_schedule_levels_gpu(const int32_t *idx, int64_t nnz, int nu, 
     try {
         const int64_t cap = (int64_t)1 << 22;
         const int rc = mfx::schedule_device(idx, nullptr, nnz, nu, ni, nullptr, level_out, off, &nl,
-                                            nnz < cap ? (nnz > 0 ? nnz : 1) : cap, &over);
+                                            nnz < cap ? (nnz > 0 ? nnz : 1) : cap, &over, false, nullptr);
         if (rc) return rc;
         if (over) return mfx::fail(MFX_E_STATE, "mfx_schedule_levels_gpu: more than %lld levels; use mfx_schedule_levels", (long long)cap);
     } catch (const std::bad_alloc &) {
         return mfx::fail(MFX_E_NOMEM, "mfx_schedule_levels_gpu: out of host memory");
     }
     if (n_levels_out) *n_levels_out = nl;
+    return MFX_OK;
+}
+
+// include/mfx.h: an input order with close to the minimum number of dependency levels, built on the GPU
+extern "C" int mfx_schedule_balanced_order_gpu(const int32_t *idx, int64_t nnz, int nu, int ni,
+                                               int64_t *perm_out, int64_t *n_rounds_out)
+{
+    if (!idx || !perm_out || nnz < 0 || nu <= 0 || ni <= 0)
+        return mfx::fail(MFX_E_ARG, "mfx_schedule_balanced_order_gpu: bad argument");
+    if (mfx::ensure_init()) return mfx::last_code();
+    std::vector<int64_t> off;
+    int64_t nl = 0;
+    bool over = false;
+    try {
+        const int64_t cap = (int64_t)1 << 22;
+        const int rc = mfx::schedule_device(idx, nullptr, nnz, nu, ni, nullptr, nullptr, off, &nl,
+                                            nnz < cap ? (nnz > 0 ? nnz : 1) : cap, &over, true, perm_out);
+        if (rc) return rc;
+        if (over) return mfx::fail(MFX_E_STATE, "mfx_schedule_balanced_order_gpu: more than %lld levels; use mfx_schedule_balanced_order", (long long)cap);
+    } catch (const std::bad_alloc &) {
+        return mfx::fail(MFX_E_NOMEM, "mfx_schedule_balanced_order_gpu: out of host memory");
+    }
+    if (n_rounds_out) *n_rounds_out = nl;
     return MFX_OK;
 }

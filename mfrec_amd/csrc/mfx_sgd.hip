@@ -13,7 +13,7 @@ using namespace mfx;
 namespace mfx {
 int schedule_device(const int32_t *h_idx, const double *h_r, int64_t nnz, int nu, int ni, Rec *d_recs,
                     int32_t *h_level, std::vector<int64_t> &level_off, int64_t *n_levels,
-                    int64_t level_budget, bool *over_budget);   // mfx_schedule_dev.hip
+                    int64_t level_budget, bool *over_budget, bool compact, int64_t *h_order);   // mfx_schedule_dev.hip
 }
 
 // ------------------------------------------------------------------------------------
@@ -459,7 +459,7 @@ mfx_sgd_plan *mfx_sgd_plan_create2(const int32_t *idx, const double *r, int64_t 
         if (sched == MFX_SCHED_DEVICE || (sched == MFX_SCHED_AUTO && nnz >= (1 << 20) && nnz < ((int64_t)1 << 31) - 1)) {
             const int64_t budget = sched == MFX_SCHED_DEVICE ? ((int64_t)1 << 22) : nnz / 1000;
             bool over = false;
-            if (schedule_device(idx, r, nnz, nu, ni, p->d_recs, nullptr, p->level_off, &p->n_levels, budget, &over)) {
+            if (schedule_device(idx, r, nnz, nu, ni, p->d_recs, nullptr, p->level_off, &p->n_levels, budget, &over, false, nullptr)) {
                 if (sched == MFX_SCHED_DEVICE || last_code() == MFX_E_RANGE) return bail();
                 over = true;                                   // e.g. scratch did not fit: host path
             }

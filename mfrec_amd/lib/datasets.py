@@ -26,6 +26,21 @@ def create_bool_sparse_col(sparse_matrix):
     return _run_length(sp.csr_matrix(sparse_matrix).T)
 
 
+def balanced_order_gpu(ratings_index, nbr_users, nbr_items):
+    """The GPU builder of the same kind of order (mfx_schedule_balanced_order_gpu): the dependency
+    levels of the GIVEN order, first-fit recoloured level by level; milliseconds instead of
+    seconds.  Deterministic in the input order: shuffle first for a random one."""
+    import ctypes as C
+    from .. import _shim as S
+    idx = np.ascontiguousarray(ratings_index, dtype=np.int32)
+    perm = np.empty(idx.shape[0], dtype=np.int64)
+    n = C.c_int64(0)
+    S.check(S.lib().mfx_schedule_balanced_order_gpu(S.i32(idx, "ratings_index", 2), idx.shape[0],
+                                                    int(nbr_users), int(nbr_items),
+                                                    perm.ctypes.data_as(S._lp), C.byref(n)))
+    return perm, n.value
+
+
 def balanced_order(ratings_index, nbr_users, nbr_items, seed=0):
     """Permutation of the ratings with (close to) the minimum number of dependency levels for
     the exact GPU schedule: a seeded first-fit edge colouring, round-major (libmfx host code,

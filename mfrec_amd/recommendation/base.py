@@ -71,13 +71,18 @@ class BaseRecommender(object):
         if isinstance(randomize_order, str) and randomize_order == "balanced":
             # extension: a random order with the fewest dependency levels (seeded from the same
             # global numpy RNG the reference's shuffle uses); falls back to the plain shuffle
-            from ..lib.datasets import balanced_order
+            from ..lib.datasets import balanced_order, balanced_order_gpu
             from .._shim import MfxError
+            np.random.shuffle(order)               # the random part, from the RNG the reference uses
             try:
-                order, _ = balanced_order(ratings_index, self.nbr_users, self.nbr_items,
-                                          seed=int(np.random.randint(0, 2 ** 31 - 1)))
+                try:                               # GPU builder: milliseconds (recolours the shuffled order)
+                    perm, _ = balanced_order_gpu(ratings_index[order], self.nbr_users, self.nbr_items)
+                    order = order[perm]
+                except MfxError:                   # > 2^22 levels etc.: the host builder
+                    order, _ = balanced_order(ratings_index, self.nbr_users, self.nbr_items,
+                                              seed=int(np.random.randint(0, 2 ** 31 - 1)))
             except MfxError:
-                np.random.shuffle(order)
+                pass                               # keep the plain shuffle
         elif randomize_order:
             np.random.shuffle(order)
         return np.ascontiguousarray(ratings_index[order]), np.ascontiguousarray(ratings[order])

@@ -53,6 +53,26 @@ def test_kmf_recommender_matches_oracle():
     assert KMFRecommender.fit is KMFRecommender.train
 
 
+def test_kmf_balanced_order_is_a_replayable_exact_order():
+    """train(order="balanced"): shuffle (global numpy RNG) + GPU recolouring; replaying the RNG gives the
+    same order, and the oracle's sequential loop over it gives the same factors bit for bit."""
+    from mfrec_amd.recommendation import KMFRecommender
+    from oracle import oracle as O
+    nu, ni, k = 300, 200, 10
+    R = _fill(KMFRecommender(nu, ni, {"nbr_epochs": 3, "nbr_features": k}), nu, ni, 20000, 4)
+    np.random.seed(7)
+    R.train(kernel="train_linear_kernel", order="balanced")
+    np.random.seed(7)
+    u = np.random.normal(0.0, 0.1, [k, ni]); v = np.random.normal(0.0, 0.1, [k, nu])
+    idx, r = R.get_ratings(randomize_order="balanced")
+    plain, _ = R.get_ratings(randomize_order=False)
+    assert sorted(map(tuple, idx.tolist())) == sorted(map(tuple, plain.tolist()))      # a permutation
+    ib, ub = np.zeros(ni), np.zeros(nu)
+    O.train_linear_kernel(3, k, 0.1, 0.01, 0.01, 0.01, 0.1, 0.1, 0.007, 0.0, u, v, idx, r, ib, ub)
+    assert np.array_equal(R.svd_u, u) and np.array_equal(R.svd_v, v)
+    assert np.array_equal(R.items_bias, ib) and np.array_equal(R.users_bias, ub)
+
+
 def test_gd_recommender_matches_oracle():
     from mfrec_amd.recommendation import GDRecommender
     from oracle import oracle as O

@@ -110,3 +110,35 @@ def test_device_builder_refuses_more_levels_than_its_budget_and_bad_flags():
         SgdPlan(idx[:10], np.ones(10), 1, 1000, 2, schedule="gpu")
     h = S.lib().mfx_sgd_plan_create2(S.i32(idx[:10], "idx", 2), S.f64(np.ones(10), "r", 1), 10, 1, 1000, 2, 7)
     assert not h and "bad argument" in S.last_error()
+
+
+def test_balanced_order_gpu_is_a_permutation_with_vertex_disjoint_rounds():
+    """mfx_schedule_balanced_order_gpu: a permutation; its level schedule has (about) max-degree levels,
+    far fewer than the input order's; training on it equals the oracle's sequential loop over it."""
+    import time
+    from mfrec_amd import _shim as S
+    from mfrec_amd.lib.datasets import balanced_order_gpu
+    from mfrec_amd.lib import kmf_train as K
+    from oracle import oracle as O
+    rs = np.random.RandomState(3)
+    nu, ni, nnz, k = 3000, 2000, 300000, 16
+    idx = np.stack([rs.randint(0, nu, nnz), rs.randint(0, ni, nnz)], 1).astype(np.int32)
+    r = rs.randint(1, 6, nnz).astype(np.float64)
+    perm, rounds = balanced_order_gpu(idx, nu, ni)
+    assert np.array_equal(np.sort(perm), np.arange(nnz))
+    deg = max(np.bincount(idx[:, 0]).max(), np.bincount(idx[:, 1]).max())
+    _, n_in = _levels(S.lib().mfx_schedule_levels, idx, nu, ni)
+    bidx, br = np.ascontiguousarray(idx[perm]), np.ascontiguousarray(r[perm])
+    lev, n_bal = _levels(S.lib().mfx_schedule_levels, bidx, nu, ni)
+    assert n_bal <= rounds and deg <= rounds <= int(1.25 * deg) + 2 and rounds < 0.7 * n_in
+    # round-major with ascending input index inside a round
+    # (rounds are the colour classes; the level of a rating never exceeds its round)
+    u0, v0 = rs.normal(0, 0.1, (k, ni)), rs.normal(0, 0.1, (k, nu))
+    u, v, ib, ub = u0.copy(), v0.copy(), np.zeros(ni), np.zeros(nu)
+    K.train_linear_kernel(2, k, 0.1, 0.02, 0, 0, 0.1, 0.05, 0.007, 0.0, u, v, bidx, br, ib, ub)
+    u2, v2, ib2, ub2 = u0.copy(), v0.copy(), np.zeros(ni), np.zeros(nu)
+    O.train_linear_kernel(2, k, 0.1, 0.02, 0, 0, 0.1, 0.05, 0.007, 0.0, u2, v2, bidx, br, ib2, ub2)
+    assert np.array_equal(u, u2) and np.array_equal(v, v2) and np.array_equal(ib, ib2) and np.array_equal(ub, ub2)
+    # determinism
+    perm2, rounds2 = balanced_order_gpu(idx, nu, ni)
+    assert rounds2 == rounds and np.array_equal(perm, perm2)

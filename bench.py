@@ -36,10 +36,13 @@ def kernel_label(k, batch, storage):
     """Name of the k1_level instantiation mfx_sgd.hip's k1_pick selects (KP lanes per rating, features
     per lane, ratings per wave; 'vec16+wt' = 16-byte accesses per lane with write-through row stores)."""
     vec = int(os.environ.get("MFX_K1_VEC", "2") or 0)
+    tag = "vec16+wt" if vec == 2 else "vec16"
     if storage == "f64" and vec and k % 2 == 0 and k > 4 and batch == (16 if k <= 32 else 8 if k <= 128 else 4 if k <= 256 else 2):
         return "k1_level<%d,%d,%d,linear,%s>" % (8 if k <= 16 else 16 if k <= 32 else 32 if k <= 64 else 64,
-                                                 2 if k <= 128 else 4 if k <= 256 else 8, batch,
-                                                 "vec16+wt" if vec == 2 else "vec16")
+                                                 2 if k <= 128 else 4 if k <= 256 else 8, batch, tag)
+    if storage == "f32" and vec and k % 4 == 0 and k > 8 and batch == (16 if k <= 32 else 8 if k <= 128 else 4 if k <= 256 else 2):
+        return "k1_level<%d,%d,%d,linear,f32,%s>" % (8 if k <= 32 else 16 if k <= 64 else 32 if k <= 128 else 64,
+                                                     4 if k <= 256 else 8, batch, tag)
     return "k1_level<%d,%d,%d,linear>" % ((8 if k <= 8 else 16 if k <= 16 else 32 if k <= 32 else 64),
                                           (1 if k <= 64 else 2 if k <= 128 else 4 if k <= 256 else 8), batch)
 

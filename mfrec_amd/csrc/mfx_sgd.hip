@@ -162,22 +162,33 @@ void *k1_pick(int k, int batch)
     // stores, vec = 2 (default) write-through stores -- no dirty lines left for the end-of-kernel
     // write-back.  cfg 2: 1.68 (8 B per lane) / 1.75 / 1.88 G updates/s; 16 or 4 ratings per wave,
     // and write-through bias stores, measured slower.
-    if constexpr (sizeof(TS) == 8) {
+#define MFX_K1VF(KP, FPL, B, NTF) (TAIL ? (void *)k1_tail<KP, FPL, B, MODE, 0, TS, true> : (void *)k1_level<KP, FPL, B, MODE, NTF, TS, true>)
+    {
         // the learned-bias family stores ONE feature per row: 16-byte loads only, plain stores
         const int vec = (MODE == K1_LEARNED && k1_vec_mode()) ? 1 : k1_vec_mode();   // (write-through scalars: no gain)
-        if (vec && k % 2 == 0 && k > 4) {
-#define MFX_K1VF(KP, FPL, B, NTF) (TAIL ? (void *)k1_tail<KP, FPL, B, MODE, 0, TS, true> : (void *)k1_level<KP, FPL, B, MODE, NTF, TS, true>)
+        if constexpr (sizeof(TS) == 8) {
+            if (vec && k % 2 == 0 && k > 4) {
 #define MFX_K1V(KP, B, NTF) MFX_K1VF(KP, 2, B, NTF)
-            if (k <= 16 && batch == 16) return vec == 2 ? MFX_K1V(8, 16, 2) : MFX_K1V(8, 16, 0);
-            if (k > 16 && k <= 32 && batch == 16) return vec == 2 ? MFX_K1V(16, 16, 2) : MFX_K1V(16, 16, 0);
-            if (k > 32 && k <= 64 && batch == 8) return vec == 2 ? MFX_K1V(32, 8, 2) : MFX_K1V(32, 8, 0);
-            if (k > 64 && k <= 128 && batch == 8) return vec == 2 ? MFX_K1V(64, 8, 2) : MFX_K1V(64, 8, 0);
-            if (k > 128 && k <= 256 && batch == 4) return vec == 2 ? MFX_K1VF(64, 4, 4, 2) : MFX_K1VF(64, 4, 4, 0);
-            if (k > 256 && batch == 2) return vec == 2 ? MFX_K1VF(64, 8, 2, 2) : MFX_K1VF(64, 8, 2, 0);
+                if (k <= 16 && batch == 16) return vec == 2 ? MFX_K1V(8, 16, 2) : MFX_K1V(8, 16, 0);
+                if (k > 16 && k <= 32 && batch == 16) return vec == 2 ? MFX_K1V(16, 16, 2) : MFX_K1V(16, 16, 0);
+                if (k > 32 && k <= 64 && batch == 8) return vec == 2 ? MFX_K1V(32, 8, 2) : MFX_K1V(32, 8, 0);
+                if (k > 64 && k <= 128 && batch == 8) return vec == 2 ? MFX_K1V(64, 8, 2) : MFX_K1V(64, 8, 0);
+                if (k > 128 && k <= 256 && batch == 4) return vec == 2 ? MFX_K1VF(64, 4, 4, 2) : MFX_K1VF(64, 4, 4, 0);
+                if (k > 256 && batch == 2) return vec == 2 ? MFX_K1VF(64, 8, 2, 2) : MFX_K1VF(64, 8, 2, 0);
 #undef MFX_K1V
-#undef MFX_K1VF
+            }
+        } else {
+            // f32 storage: four features per 16-byte chunk, k a multiple of 4
+            if (vec && k % 4 == 0 && k > 8) {
+                if (k <= 32 && batch == 16) return vec == 2 ? MFX_K1VF(8, 4, 16, 2) : MFX_K1VF(8, 4, 16, 0);
+                if (k > 32 && k <= 64 && batch == 8) return vec == 2 ? MFX_K1VF(16, 4, 8, 2) : MFX_K1VF(16, 4, 8, 0);
+                if (k > 64 && k <= 128 && batch == 8) return vec == 2 ? MFX_K1VF(32, 4, 8, 2) : MFX_K1VF(32, 4, 8, 0);
+                if (k > 128 && k <= 256 && batch == 4) return vec == 2 ? MFX_K1VF(64, 4, 4, 2) : MFX_K1VF(64, 4, 4, 0);
+                if (k > 256 && batch == 2) return vec == 2 ? MFX_K1VF(64, 8, 2, 2) : MFX_K1VF(64, 8, 2, 0);
+            }
         }
     }
+#undef MFX_K1VF
     if (k <= 8) return MFX_K1(8, 1, 16);
     if (k <= 16) return MFX_K1(16, 1, 16);
     if (k <= 32) return MFX_K1(32, 1, 16);

@@ -102,16 +102,20 @@ __device__ __forceinline__ double wave_sum_fixed(double x)
 // TS = storage type of the factor rows: double (exact), or float ("f32 storage, f64
 // arithmetic" fast mode: rows are widened on load and rounded once on store -- NOT bit-exact,
 // measured RMSE delta in DESIGN.md)
-// VEC = each lane owns the CONTIGUOUS feature pair (2q, 2q+1) and moves it with one 16-byte
-// access (k even, FPL == 2, f64 rows): half the memory instructions per row, and 16-byte
+// VEC = each lane owns CONTIGUOUS 16-byte chunks of its rows (feature pairs at f64, k even) and moves
+// each with one access: half the memory instructions per row, and 16-byte
 // write-through (sc1) stores cost what plain stores cost (8-byte ones are 2.7x dearer per byte,
 // MI355X_MICROARCH.md price list), so NT == 2 then leaves no dirty L2 lines for the
 // end-of-kernel write-back.  The arithmetic and the summation order do not change.
-typedef double v2f64_a8 __attribute__((ext_vector_type(2), aligned(8)));
-__device__ __forceinline__ void store16_sc1(double *p, double a, double b)
+// (f32 storage: the 16-byte chunk is FOUR features -- VW = 16 / sizeof(TS) -- k a multiple of 4.)
+template <typename TS> struct Chunk16;
+template <> struct Chunk16<double> { typedef double type __attribute__((ext_vector_type(2), aligned(8))); };
+template <> struct Chunk16<float> { typedef float type __attribute__((ext_vector_type(4), aligned(4))); };
+template <typename TS>
+__device__ __forceinline__ void store16_sc1(TS *p, typename Chunk16<TS>::type c)
 {
-    typedef double v2f64 __attribute__((ext_vector_type(2)));
-    v2f64 v = {a, b};
+    typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+    const v4u32 v = __builtin_bit_cast(v4u32, c);
     // s_nop: a VMEM store of more than 8 bytes reads its data VGPRs after issue; a VALU write to them
     // in the next wait state corrupts the stored value (gfx9 "12-dword store" hazard).  The compiler
     // inserts that wait state for its own stores but cannot see inside inline asm -- without it the
@@ -167,25 +171,30 @@ __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cn
         ur[s] = (TS *)P.U + (size_t)itm * k;
         vr[s] = (TS *)P.V + (size_t)usr * k;
     }
-    static_assert(!VEC || (FPL % 2 == 0 && sizeof(TS) == 8), "VEC: 16-byte f64 pairs per lane");
+    constexpr int VW = 16 / (int)sizeof(TS);             // features per 16-byte chunk
+    static_assert(!VEC || FPL % VW == 0, "VEC: whole 16-byte chunks per lane");
+    typedef typename Chunk16<TS>::type chunk_t;
     if constexpr (VEC) {
-        // pair j of lane q = features (2q + 2*KP*j, +1): every wave instruction moves 64 x 16 contiguous bytes
+        // chunk j of lane q = features VW*q + VW*KP*j ...: every wave instruction moves 64 x 16 contiguous bytes
 #pragma unroll
         for (int j = 0; j < FPL; ++j) {
 #pragma unroll
             for (int s = 0; s < NR; ++s) { uval[s][j] = 0.0; vval[s][j] = 0.0; }
         }
 #pragma unroll
-        for (int j = 0; j < FPL / 2; ++j) {
-            const int f0 = 2 * q + 2 * KP * j;
-            if (f0 < k) {                                 // k is even
+        for (int j = 0; j < FPL / VW; ++j) {
+            const int f0 = VW * q + VW * KP * j;
+            if (f0 < k) {                                 // k is a multiple of VW
 #pragma unroll
                 for (int s = 0; s < NR; ++s) {
                     if (FULL || (s * SPW + g < cnt)) {
-                        const v2f64_a8 a = *reinterpret_cast<const v2f64_a8 *>((const double *)ur[s] + f0);
-                        const v2f64_a8 b = *reinterpret_cast<const v2f64_a8 *>((const double *)vr[s] + f0);
-                        uval[s][2 * j] = a.x; uval[s][2 * j + 1] = a.y;
-                        vval[s][2 * j] = b.x; vval[s][2 * j + 1] = b.y;
+                        const chunk_t a = *reinterpret_cast<const chunk_t *>(ur[s] + f0);
+                        const chunk_t b = *reinterpret_cast<const chunk_t *>(vr[s] + f0);
+#pragma unroll
+                        for (int e = 0; e < VW; ++e) {
+                            uval[s][VW * j + e] = (double)a[e];
+                            vval[s][VW * j + e] = (double)b[e];
+                        }
                     }
                 }
             }
@@ -220,14 +229,16 @@ __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cn
     // ---- products to LDS: prod[n][f] -------------------------------------------------
     if constexpr (VEC) {
 #pragma unroll
-        for (int j = 0; j < FPL / 2; ++j) {
-            const int f0 = 2 * q + 2 * KP * j;
+        for (int j = 0; j < FPL / VW; ++j) {
+            const int f0 = VW * q + VW * KP * j;
             if (f0 < k) {
 #pragma unroll
                 for (int s = 0; s < NR; ++s) {
                     double *pp = prod + (s * SPW + g) * stride + f0;         // rows 16-B aligned, f0 even
-                    *reinterpret_cast<double2 *>(pp) = make_double2(uval[s][2 * j] * vval[s][2 * j],
-                                                                    uval[s][2 * j + 1] * vval[s][2 * j + 1]);
+#pragma unroll
+                    for (int e = 0; e < VW; e += 2)
+                        *reinterpret_cast<double2 *>(pp + e) = make_double2(uval[s][VW * j + e] * vval[s][VW * j + e],
+                                                                            uval[s][VW * j + e + 1] * vval[s][VW * j + e + 1]);
                 }
             }
         }
@@ -308,27 +319,26 @@ __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cn
     }
     if constexpr (VEC && MODE != K1_LEARNED) {
 #pragma unroll
-        for (int j = 0; j < FPL / 2; ++j) {
-            const int f0 = 2 * q + 2 * KP * j;
+        for (int j = 0; j < FPL / VW; ++j) {
+            const int f0 = VW * q + VW * KP * j;
             if (f0 < k) {
 #pragma unroll
                 for (int s = 0; s < NR; ++s) {
                     if (FULL || (s * SPW + g < cnt)) {
-                        const double mf0 = uval[s][2 * j], mf1 = uval[s][2 * j + 1];
-                        const double cf0 = vval[s][2 * j], cf1 = vval[s][2 * j + 1];
-                        const double un0 = mf0 + P.lr * (gr[s] * cf0 - P.Ki * mf0);   // kmf_train.pyx:267-270
-                        const double un1 = mf1 + P.lr * (gr[s] * cf1 - P.Ki * mf1);
-                        const double vn0 = cf0 + P.lr * (gr[s] * mf0 - P.Ku * cf0);
-                        const double vn1 = cf1 + P.lr * (gr[s] * mf1 - P.Ku * cf1);
-                        double *up = (double *)ur[s] + f0, *vp = (double *)vr[s] + f0;
+                        chunk_t un, vn;
+#pragma unroll
+                        for (int e = 0; e < VW; ++e) {
+                            const double mf = uval[s][VW * j + e], cf = vval[s][VW * j + e];
+                            un[e] = (TS)(mf + P.lr * (gr[s] * cf - P.Ki * mf));       // kmf_train.pyx:267-270
+                            vn[e] = (TS)(cf + P.lr * (gr[s] * mf - P.Ku * cf));
+                        }
+                        TS *up = ur[s] + f0, *vp = vr[s] + f0;
                         if constexpr (NT == 2) {               // 16-byte write-through stores
-                            if (FULL || P.upd_i) store16_sc1(up, un0, un1);
-                            if (FULL || P.upd_u) store16_sc1(vp, vn0, vn1);
+                            if (FULL || P.upd_i) store16_sc1<TS>(up, un);
+                            if (FULL || P.upd_u) store16_sc1<TS>(vp, vn);
                         } else {
-                            v2f64_a8 a, b;
-                            a.x = un0; a.y = un1; b.x = vn0; b.y = vn1;
-                            if (FULL || P.upd_i) *reinterpret_cast<v2f64_a8 *>(up) = a;
-                            if (FULL || P.upd_u) *reinterpret_cast<v2f64_a8 *>(vp) = b;
+                            if (FULL || P.upd_i) *reinterpret_cast<chunk_t *>(up) = un;
+                            if (FULL || P.upd_u) *reinterpret_cast<chunk_t *>(vp) = vn;
                         }
                     }
                 }
@@ -337,7 +347,7 @@ __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cn
     } else {
 #pragma unroll
     for (int j = 0; j < FPL; ++j) {
-        const int f = VEC ? (2 * q + 2 * KP * (j / 2) + (j & 1)) : (j * KP + q);
+        const int f = VEC ? (VW * q + VW * KP * (j / VW) + (j % VW)) : (j * KP + q);
         if constexpr (MODE == K1_LEARNED) {
             if (f == P.f) {                                           // gd_estimator.pyx:476-477
 #pragma unroll

@@ -36,6 +36,11 @@ __device__ __forceinline__ double ld_sc1_f64(const double *p) { return __hip_ato
 #endif
 constexpr int P = 8, B = 8, K = 64, WAVES = XCD_WAVES;
 constexpr unsigned SPIN_LIMIT = 1u << 20;
+#ifdef XCD_STAMPS
+#define STAMP(i) do { if (lane == 0 && c < 4096 * 64 && (c % 64) == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); stamps[(size_t)(round * 4096 + c / 64) * 8 + (i)] = t_; } } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
 struct BlockDesc { int64_t rec_off; int chunk_ptr; int n_chunks; };
 struct Chunk { int start; int cnt; };
@@ -46,7 +51,7 @@ __global__ __launch_bounds__(WAVES * 64) void k1_xcd_round(const Rec *__restrict
                                                            const BlockDesc *__restrict__ blocks, const Chunk *__restrict__ chunks,
                                                            int round, double *U, double *V, double *ib, double *ub,
                                                            unsigned *cnt_u, unsigned *cnt_i, unsigned *ctl, double lr,
-                                                           double Ku, double Ki, double Kb)
+                                                           double Ku, double Ki, double Kb, unsigned long long *stamps)
 {
     __shared__ __attribute__((aligned(16))) double prod_all[WAVES * B * 66];
     __shared__ unsigned sh[4];
@@ -82,6 +87,7 @@ __global__ __launch_bounds__(WAVES * 64) void k1_xcd_round(const Rec *__restrict
         Rec rec; rec.user = 0; rec.item = 0; rec.r = 0.0;
         int2 sq = make_int2(0, 0);
         if (lane < cnt) { rec = recs[rbase + ch.start + lane]; sq = seq[rbase + ch.start + lane]; }
+        STAMP(0);
         // ---- wait for both chains (bounded); the counters sit in this XCD's L2 ---------------------------
         bool ready = lane >= cnt;
         unsigned spins = 0;
@@ -91,6 +97,7 @@ __global__ __launch_bounds__(WAVES * 64) void k1_xcd_round(const Rec *__restrict
             if (++spins > SPIN_LIMIT || ld_sc1_u32(ctl + 200)) { if (lane == 0) atomicExch(ctl + 200, 1u); return; }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        STAMP(1);
         double uval[B], vval[B];
         double *ur[B], *vr[B];
 #pragma unroll
@@ -105,6 +112,10 @@ __global__ __launch_bounds__(WAVES * 64) void k1_xcd_round(const Rec *__restrict
         }
         double ibv = 0.0, ubv = 0.0;
         if (lane < cnt) { ibv = ld_sc1_f64(ib + rec.item); ubv = ld_sc1_f64(ub + rec.user); }
+#ifdef XCD_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        STAMP(2);
 #pragma unroll
         for (int s = 0; s < B; ++s) prod[s * 66 + lane] = uval[s] * vval[s];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -120,6 +131,7 @@ __global__ __launch_bounds__(WAVES * 64) void k1_xcd_round(const Rec *__restrict
             ub[rec.user] = ubv + lr * (grad - Kb * ubv);
             ib[rec.item] = ibv + lr * (grad - Kb * ibv);
         }
+        STAMP(3);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int s = 0; s < B; ++s) {
@@ -132,7 +144,9 @@ __global__ __launch_bounds__(WAVES * 64) void k1_xcd_round(const Rec *__restrict
             }
         }
         // ---- publish: rows acknowledged by L2, then the chain counters (plain stores into the same L2) -------
+        STAMP(4);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(5);
         if (lane < cnt) { cnt_u[rec.user] = (unsigned)sq.x + 1u; cnt_i[rec.item] = (unsigned)sq.y + 1u; }
     }
 }
@@ -204,6 +218,7 @@ int main(int argc, char **argv)
         CK(hipMemcpy(dU[v], U0.data(), U0.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dV[v], V0.data(), V0.size() * 8, hipMemcpyHostToDevice));
         CK(hipMemset(dib[v], 0, ni * 8)); CK(hipMemset(dub[v], 0, nu * 8));
     }
+    unsigned long long *d_stamps; CK(hipMalloc(&d_stamps, (size_t)P * 4096 * 8 * 8)); CK(hipMemset(d_stamps, 0, (size_t)P * 4096 * 8 * 8));
     const double lr = 0.01, Ku = 0.1, Ki = 0.1, Kb = 0.007;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float ms_ref = 0, ms_x = 0;
@@ -229,7 +244,7 @@ int main(int argc, char **argv)
         CK(hipMemsetAsync(d_cu, 0, nu * 4)); CK(hipMemsetAsync(d_ci, 0, ni * 4));
         for (int rd = 0; rd < P; ++rd) {
             CK(hipMemsetAsync(d_ctl, 0, 32768 * 4));
-            hipLaunchKernelGGL(k1_xcd_round, dim3(grid), dim3(WAVES * 64), 0, 0, d_blk, d_seq, d_bd, d_ch, rd, dU[1], dV[1], dib[1], dub[1], d_cu, d_ci, d_ctl, lr, Ku, Ki, Kb);
+            hipLaunchKernelGGL(k1_xcd_round, dim3(grid), dim3(WAVES * 64), 0, 0, d_blk, d_seq, d_bd, d_ch, rd, dU[1], dV[1], dib[1], dub[1], d_cu, d_ci, d_ctl, lr, Ku, Ki, Kb, d_stamps);
             if (ep == 0) { CK(hipMemcpy(&err, d_ctl + 200, 4, hipMemcpyDeviceToHost)); if (err) break; }
         }
         if (ep == epochs - 1) { CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms_x, e0, e1)); }
@@ -243,6 +258,16 @@ int main(int argc, char **argv)
     size_t diffU = 0, diffV = 0;
     for (size_t i = 0; i < a.size(); ++i) diffU += (memcmp(&a[i], &b[i], 8) != 0);
     for (size_t i = 0; i < c.size(); ++i) diffV += (memcmp(&c[i], &d[i], 8) != 0);
+#ifdef XCD_STAMPS
+    {
+        std::vector<unsigned long long> hs((size_t)P * 4096 * 8);
+        CK(hipMemcpy(hs.data(), d_stamps, hs.size() * 8, hipMemcpyDeviceToHost));
+        std::vector<double> d[5];
+        for (size_t w = 0; w < (size_t)P * 4096; ++w) if (hs[w * 8 + 5]) for (int i = 0; i < 5; ++i) d[i].push_back((double)(hs[w * 8 + i + 1] - hs[w * 8 + i]));
+        auto med = [](std::vector<double> &v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+        printf("median ticks per chunk (%zu samples): wait-for-chains %.0f | row loads %.0f | lds+sum+bias %.0f | update+issue stores %.0f | store ack %.0f\n", d[0].size(), med(d[0]), med(d[1]), med(d[2]), med(d[3]), med(d[4]));
+    }
+#endif
     printf("workgroups per XCD (last round): %u %u %u %u %u %u %u %u\n", arr[0], arr[1], arr[2], arr[3], arr[4], arr[5], arr[6], arr[7]);
     printf("block order: level-per-launch %.3f ms/epoch = %.3f G/s | XCD-local dataflow rounds (grid %d): %.3f ms/epoch = %.3f G/s | error flag %u | differing U %zu V %zu\n",
            ms_ref, nnz / ms_ref / 1e6, grid, ms_x, nnz / ms_x / 1e6, err, diffU, diffV);

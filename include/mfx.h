@@ -70,7 +70,7 @@ int mfx_schedule_levels(const int32_t *ratings_index, int64_t nnz, int nu, int n
                         int32_t *level_out, int64_t *n_levels_out);
 /* The same levels computed on the GPU (host arrays in and out): radix-sorted user / item chains +
  * one frontier launch per level (replaces the marshalling loops of
- * base.py:1115-1131 at sizes where the sequential host pass dominates).  nnz < 2^31, at most 2^22
+ * base.py:1115-1131 at sizes where the sequential host pass dominates).  nnz < 2^31, at most 2^20
  * levels.  Result identical to mfx_schedule_levels. */
 int mfx_schedule_levels_gpu(const int32_t *ratings_index, int64_t nnz, int nu, int ni,
                             int32_t *level_out, int64_t *n_levels_out);
@@ -176,7 +176,7 @@ mfx_sgd_plan *mfx_sgd_plan_create(const int32_t *ratings_index, const double *ra
                                   int64_t nnz, int nu, int ni, int dim);
 /* The same with the schedule builder chosen: MFX_SCHED_HOST (mfx_schedule_levels + _pack, then one
  * upload), MFX_SCHED_DEVICE (raw arrays uploaded, levels + level-major records built in HBM; fails
- * beyond 2^22 levels) or MFX_SCHED_AUTO (device from 2^20 ratings on, falling back to the host when
+ * beyond 2^20 levels) or MFX_SCHED_AUTO (device from 2^20 ratings on, falling back to the host when
  * the data needs more than nnz/1000 levels).  Both builders give the same records in the same order. */
 enum { MFX_SCHED_AUTO = 0, MFX_SCHED_HOST = 1, MFX_SCHED_DEVICE = 2 };
 mfx_sgd_plan *mfx_sgd_plan_create2(const int32_t *ratings_index, const double *ratings,

@@ -344,7 +344,7 @@ extern "C" int mfx_schedule_levels_gpu(const int32_t *idx, int64_t nnz, int nu, 
     int64_t nl = 0;
     bool over = false;
     try {
-        const int64_t cap = (int64_t)1 << 22;
+        const int64_t cap = (int64_t)1 << 20;
         const int rc = mfx::schedule_device(idx, nullptr, nnz, nu, ni, nullptr, level_out, off, &nl,
                                             nnz < cap ? (nnz > 0 ? nnz : 1) : cap, &over, false, nullptr);
         if (rc) return rc;
@@ -367,7 +367,7 @@ extern "C" int mfx_schedule_balanced_order_gpu(const int32_t *idx, int64_t nnz, 
     int64_t nl = 0;
     bool over = false;
     try {
-        const int64_t cap = (int64_t)1 << 22;
+        const int64_t cap = (int64_t)1 << 20;
         const int rc = mfx::schedule_device(idx, nullptr, nnz, nu, ni, nullptr, nullptr, off, &nl,
                                             nnz < cap ? (nnz > 0 ? nnz : 1) : cap, &over, true, perm_out);
         if (rc) return rc;

@@ -468,7 +468,7 @@ mfx_sgd_plan *mfx_sgd_plan_create2(const int32_t *idx, const double *r, int64_t 
         // where the host's 3 ns per rating is cheaper).
         bool on_device = false;
         if (sched == MFX_SCHED_DEVICE || (sched == MFX_SCHED_AUTO && nnz >= (1 << 20) && nnz < ((int64_t)1 << 31) - 1)) {
-            const int64_t budget = sched == MFX_SCHED_DEVICE ? ((int64_t)1 << 22) : nnz / 1000;
+            const int64_t budget = sched == MFX_SCHED_DEVICE ? ((int64_t)1 << 20) : nnz / 1000;
             bool over = false;
             if (schedule_device(idx, r, nnz, nu, ni, p->d_recs, nullptr, p->level_off, &p->n_levels, budget, &over, false, nullptr)) {
                 if (sched == MFX_SCHED_DEVICE || last_code() == MFX_E_RANGE) return bail();

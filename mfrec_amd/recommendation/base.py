@@ -78,7 +78,7 @@ class BaseRecommender(object):
                 try:                               # GPU builder: milliseconds (recolours the shuffled order)
                     perm, _ = balanced_order_gpu(ratings_index[order], self.nbr_users, self.nbr_items)
                     order = order[perm]
-                except MfxError:                   # > 2^22 levels etc.: the host builder
+                except MfxError:                   # > 2^20 levels etc.: the host builder
                     order, _ = balanced_order(ratings_index, self.nbr_users, self.nbr_items,
                                               seed=int(np.random.randint(0, 2 ** 31 - 1)))
             except MfxError:

@@ -100,8 +100,8 @@ def test_auto_falls_back_to_host_when_levels_explode():
 def test_device_builder_refuses_more_levels_than_its_budget_and_bad_flags():
     from mfrec_amd import _shim as S
     from mfrec_amd.plan import SgdPlan
-    # a single user with 2^22 + 1 ratings needs that many levels: explicit "device" must fail loudly
-    nnz = (1 << 22) + 1
+    # a single user with 2^20 + 1 ratings needs that many levels: explicit "device" must fail loudly
+    nnz = (1 << 20) + 1
     idx = np.zeros((nnz, 2), dtype=np.int32)
     idx[:, 1] = np.arange(nnz) % 1000
     with pytest.raises(S.MfxError, match="levels"):

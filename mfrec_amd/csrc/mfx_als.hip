@@ -372,19 +372,26 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 ? 2 : (NT >= 5 ? 2 : 3))) void k_
         for (int c = 0; c < 16; ++c) d[c] = A[drow + c];
         double myinv = 1.0;
         bool ok = true;
-#pragma unroll
-        for (int jj = 0; jj < 16; ++jj) {
-            const double pj = readlane_f64(d[jj], jj);
+        // DPP row broadcasts instead of v_readlane (all 64 lanes active: four copies of the block); the
+        // next pivot's rsqrt chain runs under the remaining updates of the current step.  Only the
+        // factorisation: the panel solve keeps reading L11 from LDS (its DPP form costs 64 VGPRs).
+        double pj = dpp_bcast<0>(d[0]);
+        double inv = rsqrt_fma(pj);
+        static_for<0, 16>([&](auto JJ) {
+            constexpr int jj = JJ;
             ok = ok && (pj > 0.0);
-            const double inv = rsqrt_nr(pj);
             if (r == jj) myinv = inv;
-            d[jj] = (r == jj) ? pj * inv : d[jj] * inv;
-#pragma unroll
-            for (int c = jj + 1; c < 16; ++c) {
-                const double lcj = readlane_f64(d[jj], c);
-                d[c] -= d[jj] * lcj;
+            d[jj] *= inv;
+            if constexpr (jj < 15) {
+                dpp_fnma<jj + 1>(d[jj + 1], d[jj], d[jj]);
+                pj = dpp_bcast<jj + 1>(d[jj + 1]);
+                inv = rsqrt_fma(pj);
+                static_for<jj + 2, 16>([&](auto C) {
+                    constexpr int c = C;
+                    dpp_fnma<c, false>(d[c], d[jj], d[jj]);
+                });
             }
-        }
+        });
         if (lane < 16) {
 #pragma unroll
             for (int c = 0; c < 16; ++c)

@@ -220,7 +220,7 @@ def main():
     try:
         import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-        if cands and a.order == "shuffled" and (nu, ni, nnz, k) == (100000, 50000, 10000000, 64):
+        if cands and a.order == "shuffled" and a.storage == "f64" and (nu, ni, nnz, k) == (100000, 50000, 10000000, 64):
             tj = json.load(open(cands[-1]))
             traffic = (tj["read_bytes_per_rating"] + tj["write_bytes_per_rating"]) * nnz / launches
             traffic_src = os.path.basename(cands[-1])

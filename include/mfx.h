@@ -188,6 +188,9 @@ void mfx_sgd_plan_destroy(mfx_sgd_plan *p);
  * [4]=ratings per wave batch, [5]=device bytes held, [6]=schedule build microseconds,
  * [7]=launches per epoch (Funk) */
 int mfx_sgd_plan_info(const mfx_sgd_plan *p, int64_t info[8]);
+/* Name of the k1_level instantiation this plan launches for `mode` (0 linear, 1 logistic, 2 learned
+ * bias): "k1_level<lanes per rating,features per lane,ratings per wave,access form,mode>". */
+int mfx_sgd_plan_kernel_name(const mfx_sgd_plan *p, int mode, char *buf, int buflen);
 /* Storage type of the factor rows inside the plan: 64 (default; exact) or 32 -- "f32 storage,
  * f64 arithmetic" fast mode of the full-k kernels: rows are widened on load and rounded once on
  * store.  NOT bit-exact (measured RMSE delta: DESIGN.md); single-GPU; call before set_factors. */
@@ -238,6 +241,15 @@ int mfx_sgd_run_kmf_sharded(mfx_sgd_plan *p, int mode, int nbr_epochs, double le
                             double *rmse_out /* local shard's online RMSE */,
                             double *se_out /* nullable: f64[nbr_epochs] local sum of squared errors */);
 
+/* Test / rehearsal hook: the arithmetic of mfx_sgd_run_kmf_sharded for `world` shards that all live on
+ * THIS GPU, no communicator.  plans[g] = shard g's plan (same item replica set in each); per epoch every
+ * shard runs its local epoch, the item deltas are summed in rank order on the device (the stand-in for
+ * the all-reduce, whose summation order RCCL does not fix) and every shard receives
+ * U_start + scale * sum.  se_out: nullable f64[world * nbr_epochs], shard-major. */
+int mfx_sgd_run_kmf_fake_world(mfx_sgd_plan **plans, int world, int mode, int nbr_epochs,
+                               double learning_rate, double K_users, double K_items, double K_bias,
+                               double scale, double *se_out);
+
 /* Funk passes (estimator_loop_without_bias / _with_bias) on a user shard: after every
  * feature-epoch the item-side vector U[f,:] is combined as for the full-k kernels
  * (all-reduce of [ni] doubles) and the squared error is made global, so every rank takes the
@@ -256,6 +268,36 @@ int mfx_als_wrmf_sharded(int nbr_epochs, int dim, double *u, double *v,
                          const int32_t *ratings_users_col, const int32_t *ratings_items_row,
                          int64_t n_irow, const int32_t *ratings_items_col, int nu, int ni, int c_pos,
                          double lambda);
+
+/* ------------------------------------------------ exact multi-GPU mode (DSGD block rotation)
+ * Users are cut into `world` blocks (one per GPU), items into `world` blocks.  In sub-epoch s GPU g
+ * trains the ratings of block (g, (g+s) mod world) and then passes that item block (rows + biases) to
+ * GPU g-1 over xGMI (ncclSend/ncclRecv ring) while it receives the next one from GPU g+1.  The blocks of
+ * a sub-epoch share no user and no item, so the epoch IS the reference's sequential loop
+ * (kmf_train.pyx:243-270) on the rating order
+ *     for s: for g: ratings of block (g, (g+s) mod world), in the order given
+ * and the result is bit-identical to it -- the multi-GPU mode that keeps "RMSE within 1e-5 of the
+ * reference" (parameter averaging, above, does not).  The reference's only multi-machine precedent is
+ * the averaging prototype gradient_descent.py:124-211.
+ * ratings_index holds GLOBAL ids; a rank keeps the ratings of its own user block (so passing all ratings
+ * or only the rank's own is the same).  rank = -1: all `world` ranks live in this process on this GPU
+ * (rotation = device copy), for tests and rehearsals.  mfx_comm_init first when world > 1 and rank >= 0.
+ * v / users_bias are this rank's users ([k, nu_local] / [nu_local]; fake world: all users); u /
+ * items_bias are always the full item side.  mfx_dsgd_get_factors is collective. */
+typedef struct mfx_dsgd mfx_dsgd;
+mfx_dsgd *mfx_dsgd_create(const int32_t *ratings_index, const double *ratings, int64_t nnz, int nu,
+                          int ni, int dim, const int64_t *user_bounds /* world+1 */,
+                          const int64_t *item_bounds /* world+1 */, int rank, int world);
+void mfx_dsgd_destroy(mfx_dsgd *d);
+/* info[0] = ratings held by this process, [1] = dependency levels summed over its blocks,
+ * [2] / [3] = largest / smallest block (ratings), [4] = kernel launches per epoch */
+int mfx_dsgd_info(const mfx_dsgd *d, int64_t info[8]);
+int mfx_dsgd_set_factors(mfx_dsgd *d, const double *u, const double *v, const double *items_bias,
+                         const double *users_bias);
+/* se_out: nullable f64[nbr_epochs], squared-error sum of every epoch over all ratings of the job */
+int mfx_dsgd_run_kmf(mfx_dsgd *d, int mode, int nbr_epochs, double learning_rate, double K_users,
+                     double K_items, double K_bias, double *se_out);
+int mfx_dsgd_get_factors(mfx_dsgd *d, double *u, double *v, double *items_bias, double *users_bias);
 
 #ifdef __cplusplus
 }

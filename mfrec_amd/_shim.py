@@ -67,6 +67,7 @@ SIGNATURES = {
     "mfx_sgd_plan_destroy": (None, [C.c_void_p]),
     "mfx_sgd_plan_info": (C.c_int, [C.c_void_p, _lp]),
     "mfx_sgd_plan_set_storage": (C.c_int, [C.c_void_p, C.c_int]),
+    "mfx_sgd_plan_kernel_name": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int]),
     "mfx_sgd_set_factors": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp]),
     "mfx_sgd_get_factors": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp]),
     "mfx_sgd_run_kmf": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double,
@@ -89,6 +90,16 @@ SIGNATURES = {
                                            C.c_int64, _lp]),
     "mfx_sgd_run_kmf_sharded": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double,
                                           C.c_double, C.c_double, C.c_double, _dp, _dp]),
+    "mfx_sgd_run_kmf_fake_world": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_double,
+                                             C.c_double, C.c_double, C.c_double, C.c_double, _dp]),
+    "mfx_dsgd_create": (C.c_void_p, [_ip, _dp, C.c_int64, C.c_int, C.c_int, C.c_int, _lp, _lp, C.c_int,
+                                     C.c_int]),
+    "mfx_dsgd_destroy": (None, [C.c_void_p]),
+    "mfx_dsgd_info": (C.c_int, [C.c_void_p, _lp]),
+    "mfx_dsgd_set_factors": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp]),
+    "mfx_dsgd_run_kmf": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                   C.c_double, _dp]),
+    "mfx_dsgd_get_factors": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp]),
 }
 
 _lib = None

@@ -901,7 +901,9 @@ extern "C" int mfx_debug_als_stamps(unsigned long long *out)
 __global__ __launch_bounds__(256) void k_transpose_als(const double *in, double *out, int rows, int cols)
 {
     __shared__ double tile[32][33];
-    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    // 1-D grid of tiles (a 2-D grid would cap rows at 65535 * 32)
+    const unsigned nbx = (unsigned)(cols + 31) / 32;
+    const int bx = (int)(blockIdx.x % nbx) * 32, by = (int)(blockIdx.x / nbx) * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int i = ty; i < 32; i += 8) {
         const int r = by + i, c = bx + tx;
@@ -1060,8 +1062,9 @@ int als_half(int k, int NT, const AlsKernels &K, const double *dY, int ny, doubl
 int transpose_to(const double *in, double *out, int rows, int cols)
 {
     if (!rows || !cols) return MFX_OK;
-    hipLaunchKernelGGL(k_transpose_als, dim3(ceil_div(cols, 32), ceil_div(rows, 32)), dim3(256), 0,
-                       mfx::stream(), in, out, rows, cols);
+    const int64_t tiles = (int64_t)ceil_div(cols, 32) * ceil_div(rows, 32);
+    if (tiles > 0x7fffffff) return mfx::fail(MFX_E_ARG, "transpose: %d x %d is too large", rows, cols);
+    hipLaunchKernelGGL(k_transpose_als, dim3((unsigned)tiles), dim3(256), 0, mfx::stream(), in, out, rows, cols);
     MFX_HIP(hipGetLastError());
     return MFX_OK;
 }
@@ -1143,9 +1146,13 @@ static int als_wrmf_impl(int nbr_epochs, int dim, double *u, double *v, const in
     MFX_HIP(hipMemset(dStatus.p, 0, 4));
     rc = transpose_to(dUkm.as<double>(), dU.as<double>(), dim, ni);      // [k][ni] -> [ni][k]
     if (!rc) rc = transpose_to(dVkm.as<double>(), dV.as<double>(), dim, nu);
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    MFX_HIP(hipEventCreate(&ev0));
-    MFX_HIP(hipEventCreate(&ev1));
+    struct EvPair {                                 // destroyed on every return path
+        hipEvent_t a = nullptr, b = nullptr;
+        ~EvPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } evp;
+    MFX_HIP(hipEventCreate(&evp.a));
+    MFX_HIP(hipEventCreate(&evp.b));
+    hipEvent_t ev0 = evp.a, ev1 = evp.b;
     MFX_HIP(hipEventRecord(ev0, s));
     for (int e = 0; e < nbr_epochs && !rc; ++e) {
         // user pass (als_implicit.pyx:257-302), then item pass (:307-352)
@@ -1164,8 +1171,6 @@ static int als_wrmf_impl(int nbr_epochs, int dim, double *u, double *v, const in
         MFX_HIP(hipEventElapsedTime(&ms, ev0, ev1));
         mfx::set_last_compute_ms((double)ms);
     }
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
     if (rc) return rc;
     rc = transpose_to(dU.as<double>(), dUkm.as<double>(), ni, dim);
     if (!rc) rc = transpose_to(dV.as<double>(), dVkm.as<double>(), nu, dim);

@@ -9,29 +9,7 @@
 #include <dlfcn.h>
 #include <stdlib.h>
 #include <string.h>
-#include "mfx_common.h"
-
-struct mfx_sgd_plan;
-namespace mfx {
-int sgd_run_k1_hooked(mfx_sgd_plan *p, int mode, int epochs, double lr, double Ku, double Ki,
-                      double Kb, int (*hook)(mfx_sgd_plan *, int, void *), void *ctx,
-                      double *rmse_out, double *se_out);
-double *plan_U(mfx_sgd_plan *p);
-double *plan_ib(mfx_sgd_plan *p);
-int plan_ni(mfx_sgd_plan *p);
-int plan_k(mfx_sgd_plan *p);
-int plan_start_buffers(mfx_sgd_plan *p, double **U_start, double **ib_start);
-int plan_prepare_nk(mfx_sgd_plan *p);
-struct FunkHooks {
-    int (*pre)(void *ctx, double *uf, int ni);
-    int (*post)(void *ctx, double *uf, int ni);
-    int (*global_se)(void *ctx, double *se, double *nnz);
-    void *ctx;
-};
-int funk_core(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_init, double lr,
-              double K, double mu, int use_bias, int upd_u, int upd_i, int epoch_cap,
-              double *rmse_hist, int64_t hist_cap, int64_t *n_hist, const FunkHooks *hk);
-}  // namespace mfx
+#include "mfx_sgd_internal.h"
 
 namespace {
 
@@ -49,7 +27,13 @@ struct Rccl {
     int (*CommDestroy)(ncclComm_t) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Broadcast)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    const char *(*GetLastError)(ncclComm_t) = nullptr;
 } R;
 
 ncclComm_t g_comm = nullptr;
@@ -70,8 +54,15 @@ int load_rccl()
     R.CommDestroy = (decltype(R.CommDestroy))dlsym(R.h, "ncclCommDestroy");
     R.AllReduce = (decltype(R.AllReduce))dlsym(R.h, "ncclAllReduce");
     R.AllGather = (decltype(R.AllGather))dlsym(R.h, "ncclAllGather");
+    R.Broadcast = (decltype(R.Broadcast))dlsym(R.h, "ncclBroadcast");
+    R.Send = (decltype(R.Send))dlsym(R.h, "ncclSend");
+    R.Recv = (decltype(R.Recv))dlsym(R.h, "ncclRecv");
+    R.GroupStart = (decltype(R.GroupStart))dlsym(R.h, "ncclGroupStart");
+    R.GroupEnd = (decltype(R.GroupEnd))dlsym(R.h, "ncclGroupEnd");
     R.GetErrorString = (decltype(R.GetErrorString))dlsym(R.h, "ncclGetErrorString");
-    if (!R.GetUniqueId || !R.CommInitRank || !R.CommDestroy || !R.AllReduce || !R.AllGather) {
+    R.GetLastError = (decltype(R.GetLastError))dlsym(R.h, "ncclGetLastError");
+    if (!R.GetUniqueId || !R.CommInitRank || !R.CommDestroy || !R.AllReduce || !R.AllGather ||
+        !R.Broadcast || !R.Send || !R.Recv || !R.GroupStart || !R.GroupEnd) {
         dlclose(R.h);
         R.h = nullptr;
         return mfx::fail(MFX_E_RCCL, "librccl lacks a required symbol");
@@ -79,12 +70,17 @@ int load_rccl()
     return MFX_OK;
 }
 
+// the failure line carries RCCL's own last-error text (what NCCL_DEBUG=WARN would print) and the rank
 #define MFX_NCCL(call)                                                                    \
     do {                                                                                  \
         int r_ = (call);                                                                  \
-        if (r_ != ncclSuccess)                                                            \
-            return mfx::fail(MFX_E_RCCL, "%s:%d: %s -> %s", __FILE__, __LINE__, #call,    \
-                             R.GetErrorString ? R.GetErrorString(r_) : "rccl error");     \
+        if (r_ != ncclSuccess) {                                                          \
+            const char *le_ = R.GetLastError ? R.GetLastError(g_comm) : nullptr;          \
+            return mfx::fail(MFX_E_RCCL, "rank %d/%d: %s:%d: %s -> %s [%s]", g_rank,      \
+                             g_world, __FILE__, __LINE__, #call,                          \
+                             R.GetErrorString ? R.GetErrorString(r_) : "rccl error",      \
+                             (le_ && *le_) ? le_ : "no further detail");                  \
+        }                                                                                 \
     } while (0)
 
 // a <- a - b
@@ -101,6 +97,13 @@ __global__ __launch_bounds__(256) void k_combine(double *a, double *b, double sc
         a[i] = x;
         b[i] = x;
     }
+}
+
+// a <- a + b   (fake world: the rank-ordered sum that stands in for the all-reduce)
+__global__ __launch_bounds__(256) void k_add(double *a, const double *b, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        a[i] = a[i] + b[i];
 }
 
 int grid_for(size_t n) { return (int)(n / 256 + 1 < 4096 ? n / 256 + 1 : 4096); }
@@ -140,6 +143,29 @@ int comm_allgather_f64(double *buf, size_t count)
     MFX_NCCL(R.AllGather(buf + (size_t)g_rank * count, buf, count, ncclFloat64, g_comm, mfx::stream()));
     return MFX_OK;
 }
+int comm_allreduce_sum_f64(double *buf, size_t count)
+{
+    if (!g_comm || !count) return MFX_OK;
+    MFX_NCCL(R.AllReduce(buf, buf, count, ncclFloat64, ncclSum, g_comm, mfx::stream()));
+    return MFX_OK;
+}
+int comm_broadcast_f64(double *buf, size_t count, int root)
+{
+    if (!g_comm || !count) return MFX_OK;
+    MFX_NCCL(R.Broadcast(buf, buf, count, ncclFloat64, root, g_comm, mfx::stream()));
+    return MFX_OK;
+}
+int comm_sendrecv_f64(const CommSeg *out, int n_out, int to, const CommSeg *in, int n_in, int from)
+{
+    if (!g_comm) return fail(MFX_E_STATE, "comm_sendrecv_f64: no communicator");
+    MFX_NCCL(R.GroupStart());
+    for (int i = 0; i < n_out; ++i)
+        if (out[i].count) MFX_NCCL(R.Send(out[i].ptr, out[i].count, ncclFloat64, to, g_comm, mfx::stream()));
+    for (int i = 0; i < n_in; ++i)
+        if (in[i].count) MFX_NCCL(R.Recv(in[i].ptr, in[i].count, ncclFloat64, from, g_comm, mfx::stream()));
+    MFX_NCCL(R.GroupEnd());
+    return MFX_OK;
+}
 }  // namespace mfx
 
 extern "C" {
@@ -162,6 +188,7 @@ int mfx_comm_init(int rank, int world, const void *id)
         return mfx::fail(MFX_E_ARG, "mfx_comm_init: rank %d / world %d", rank, world);
     int rc = mfx::ensure_init();
     if (rc) return rc;
+    if (g_comm) return mfx::fail(MFX_E_STATE, "mfx_comm_init: a communicator exists already (mfx_comm_destroy first)");
     g_rank = rank;
     g_world = world;
     // world == 1 needs no communicator; MFX_FORCE_COMM=1 builds a 1-rank one anyway so that
@@ -295,6 +322,58 @@ int mfx_sgd_run_kmf_sharded(mfx_sgd_plan *p, int mode, int nbr_epochs, double lr
     }
     return mfx::sgd_run_k1_hooked(p, mode, nbr_epochs, lr, Ku, Ki, Kb, shard_hook, &c, rmse_out,
                                   se_out);
+}
+
+// The arithmetic of mfx_sgd_run_kmf_sharded for `world` shards that all live on THIS GPU (test and
+// rehearsal hook; no communicator): per epoch every shard runs its local epoch from the same item
+// state, the deltas are summed in rank order on the device -- the stand-in for the all-reduce -- and
+// every shard receives U_start + scale * sum.  Same k_sub / k_combine kernels as the RCCL path.
+int mfx_sgd_run_kmf_fake_world(mfx_sgd_plan **plans, int world, int mode, int nbr_epochs, double lr,
+                               double Ku, double Ki, double Kb, double scale, double *se_out)
+{
+    mfx::TraceRange trace_("mfx:run_kmf_fake_world");
+    if (!plans || world < 1 || nbr_epochs < 0) return mfx::fail(MFX_E_ARG, "mfx_sgd_run_kmf_fake_world: bad argument");
+    for (int g = 0; g < world; ++g)
+        if (!plans[g] || mfx::plan_ni(plans[g]) != mfx::plan_ni(plans[0]) || mfx::plan_k(plans[g]) != mfx::plan_k(plans[0]))
+            return mfx::fail(MFX_E_ARG, "mfx_sgd_run_kmf_fake_world: shard %d disagrees on the item side", g);
+    const size_t nb = (size_t)mfx::plan_ni(plans[0]), nU = nb * mfx::plan_k(plans[0]);
+    hipStream_t s = mfx::stream();
+    double *U_start = nullptr, *ib_start = nullptr, *accU = nullptr, *accib = nullptr;
+    int rc = MFX_OK;
+    for (int g = 0; g < world && !rc; ++g) rc = mfx::plan_prepare_nk(plans[g]);
+    if (!rc) rc = mfx::plan_start_buffers(plans[0], &U_start, &ib_start);
+    if (rc) return rc;
+    struct Free {
+        double *&a, *&b;
+        ~Free() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); }
+    } guard{accU, accib};
+    MFX_HIP(hipMalloc((void **)&accU, nU * sizeof(double)));
+    MFX_HIP(hipMalloc((void **)&accib, nb * sizeof(double)));
+    MFX_HIP(hipMemcpyAsync(U_start, mfx::plan_U(plans[0]), nU * sizeof(double), hipMemcpyDeviceToDevice, s));
+    MFX_HIP(hipMemcpyAsync(ib_start, mfx::plan_ib(plans[0]), nb * sizeof(double), hipMemcpyDeviceToDevice, s));
+    for (int ep = 0; ep < nbr_epochs; ++ep) {
+        MFX_HIP(hipMemsetAsync(accU, 0, nU * sizeof(double), s));          // +0.0
+        MFX_HIP(hipMemsetAsync(accib, 0, nb * sizeof(double), s));
+        for (int g = 0; g < world; ++g) {
+            double *U = mfx::plan_U(plans[g]), *ib = mfx::plan_ib(plans[g]);
+            rc = mfx::sgd_run_k1_hooked(plans[g], mode, 1, lr, Ku, Ki, Kb, nullptr, nullptr, nullptr,
+                                        se_out ? se_out + (size_t)g * nbr_epochs + ep : nullptr);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_sub, dim3(grid_for(nU)), dim3(256), 0, s, U, U_start, nU);
+            hipLaunchKernelGGL(k_sub, dim3(grid_for(nb)), dim3(256), 0, s, ib, ib_start, nb);
+            hipLaunchKernelGGL(k_add, dim3(grid_for(nU)), dim3(256), 0, s, accU, (const double *)U, nU);
+            hipLaunchKernelGGL(k_add, dim3(grid_for(nb)), dim3(256), 0, s, accib, (const double *)ib, nb);
+        }
+        hipLaunchKernelGGL(k_combine, dim3(grid_for(nU)), dim3(256), 0, s, accU, U_start, scale, nU);
+        hipLaunchKernelGGL(k_combine, dim3(grid_for(nb)), dim3(256), 0, s, accib, ib_start, scale, nb);
+        MFX_HIP(hipGetLastError());
+        for (int g = 0; g < world; ++g) {
+            MFX_HIP(hipMemcpyAsync(mfx::plan_U(plans[g]), U_start, nU * sizeof(double), hipMemcpyDeviceToDevice, s));
+            MFX_HIP(hipMemcpyAsync(mfx::plan_ib(plans[g]), ib_start, nb * sizeof(double), hipMemcpyDeviceToDevice, s));
+        }
+    }
+    MFX_HIP(hipStreamSynchronize(s));
+    return MFX_OK;
 }
 
 }  // extern "C"

@@ -1,0 +1,368 @@
+// Exact multi-GPU SGD: stratified (DSGD) block rotation (include/mfx.h "exact multi-GPU mode").
+//
+// Sequential SGD is order dependent, and the user-sharded averaging scheme of mfx_comm.hip (the
+// reference's own two-"machine" prototype, gradient_descent.py:124-211) changes the trajectory.  This
+// mode does not: users are cut into G blocks (one per GPU) and items into G blocks; in sub-epoch s
+// GPU g trains the ratings of block (g, (g+s) mod G) -- the G blocks of a sub-epoch share neither a
+// user nor an item, so running them at the same time IS running them one after the other -- and then
+// hands its item block (rows + biases) to GPU g-1 while it receives the next one from GPU g+1
+// (ncclSend/ncclRecv ring over xGMI).  After G sub-epochs every rating has been applied once and every
+// item block is home again.  The result is bit-identical to the reference's sequential loop
+// (kmf_train.pyx:243-270) run on the rating order
+//     for s in 0..G-1: for g in 0..G-1: ratings of block (g, (g+s) mod G) in their given order
+// which is as legitimate an order as the reference's unseeded shuffle (base.py:1127-1129).
+//
+// One DSGD rank = G sub-plans (one per item block) that share the rank's user rows.  rank = -1 keeps
+// all G ranks in this process on this GPU ("fake world": the rotation is a device copy); it runs the
+// same code path except for the transport and is what the single-GPU tests drive.
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "mfx_sgd_internal.h"
+
+using namespace mfx;
+
+namespace {
+
+struct DsgdRank {
+    int g = 0;                              // this rank's user block
+    int user_lo = 0, nu_local = 0;
+    std::vector<mfx_sgd_plan *> plans;      // [G]: block (g, j); plans[0] owns the user-side buffers
+};
+
+int block_of(const std::vector<int64_t> &bounds, int64_t x)
+{
+    // bounds is ascending, bounds[0] = 0, bounds.back() = n; blocks may be empty
+    int lo = 0, hi = (int)bounds.size() - 1;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) / 2;
+        if (x >= bounds[mid]) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+}  // namespace
+
+struct mfx_dsgd {
+    int world = 1, rank = 0;                // rank < 0: fake world
+    int nu = 0, ni = 0, k = 0;
+    std::vector<int64_t> ub, ib;            // user / item block bounds [world + 1]
+    std::vector<DsgdRank> ranks;            // 1 (a real rank) or world (fake world)
+    bool have_factors = false;
+    int64_t nnz_local = 0;
+};
+
+extern "C" {
+
+void mfx_dsgd_destroy(mfx_dsgd *d)
+{
+    if (!d) return;
+    for (DsgdRank &r : d->ranks) {
+        // sub-plans that alias the user side first, their owner (plans[0]) last
+        for (size_t j = r.plans.size(); j-- > 0;)
+            if (r.plans[j]) mfx_sgd_plan_destroy(r.plans[j]);
+    }
+    delete d;
+}
+
+mfx_dsgd *mfx_dsgd_create(const int32_t *idx, const double *r, int64_t nnz, int nu, int ni, int dim,
+                          const int64_t *user_bounds, const int64_t *item_bounds, int rank, int world)
+{
+    TraceRange trace_("mfx:dsgd_create (block split + schedules)");
+    if ((nnz > 0 && (!idx || !r)) || nnz < 0 || nu <= 0 || ni <= 0 || dim < 1 || !user_bounds || !item_bounds ||
+        world < 1 || rank < -1 || rank >= world) {
+        fail(MFX_E_ARG, "mfx_dsgd_create: bad argument");
+        return nullptr;
+    }
+    if (user_bounds[0] != 0 || user_bounds[world] != nu || item_bounds[0] != 0 || item_bounds[world] != ni) {
+        fail(MFX_E_ARG, "mfx_dsgd_create: bounds must run from 0 to nu / ni");
+        return nullptr;
+    }
+    for (int g = 0; g < world; ++g)
+        if (user_bounds[g + 1] < user_bounds[g] || item_bounds[g + 1] < item_bounds[g]) {
+            fail(MFX_E_ARG, "mfx_dsgd_create: bounds must be ascending");
+            return nullptr;
+        }
+    if (rank >= 0 && world > 1 && (!comm_active() || comm_world() != world || comm_rank() != rank)) {
+        fail(MFX_E_STATE, "mfx_dsgd_create: mfx_comm_init(rank=%d, world=%d) has not been called", rank, world);
+        return nullptr;
+    }
+    if (ensure_init()) return nullptr;
+    mfx_dsgd *d = new (std::nothrow) mfx_dsgd();
+    if (!d) {
+        fail(MFX_E_NOMEM, "mfx_dsgd_create: out of host memory");
+        return nullptr;
+    }
+    try {
+        d->world = world;
+        d->rank = rank;
+        d->nu = nu;
+        d->ni = ni;
+        d->k = dim;
+        d->ub.assign(user_bounds, user_bounds + world + 1);
+        d->ib.assign(item_bounds, item_bounds + world + 1);
+        const int g0 = rank < 0 ? 0 : rank, g1 = rank < 0 ? world : rank + 1;
+        const int nr = g1 - g0;
+        // split the ratings (order preserved) into this process's blocks, ids made block-local
+        std::vector<int64_t> cnt((size_t)nr * world, 0);
+        std::vector<int32_t> blk((size_t)(nnz ? nnz : 1));       // block slot per rating, -1 = not ours
+        for (int64_t t = 0; t < nnz; ++t) {
+            const int32_t u = idx[2 * t], i = idx[2 * t + 1];
+            if (u < 0 || u >= nu || i < 0 || i >= ni) {
+                fail(MFX_E_RANGE, "mfx_dsgd_create: rating %lld: (user %d, item %d) outside [0,%d) x [0,%d)",
+                     (long long)t, u, i, nu, ni);
+                mfx_dsgd_destroy(d);
+                return nullptr;
+            }
+            const int g = block_of(d->ub, u);
+            if (g < g0 || g >= g1) { blk[t] = -1; continue; }
+            const int b = (g - g0) * world + block_of(d->ib, i);
+            blk[t] = b;
+            ++cnt[b];
+        }
+        std::vector<std::vector<int32_t>> bidx((size_t)nr * world);
+        std::vector<std::vector<double>> br((size_t)nr * world);
+        for (size_t b = 0; b < cnt.size(); ++b) {
+            bidx[b].resize((size_t)cnt[b] * 2 + 2);
+            br[b].resize((size_t)cnt[b] + 1);
+            cnt[b] = 0;
+        }
+        for (int64_t t = 0; t < nnz; ++t) {
+            const int b = blk[t];
+            if (b < 0) continue;
+            const int g = g0 + b / world, j = b % world;
+            const int64_t c = cnt[b]++;
+            bidx[b][2 * c] = idx[2 * t] - (int32_t)d->ub[g];
+            bidx[b][2 * c + 1] = idx[2 * t + 1] - (int32_t)d->ib[j];
+            br[b][c] = r[t];
+            ++d->nnz_local;
+        }
+        std::vector<int32_t>().swap(blk);
+        d->ranks.resize((size_t)nr);
+        for (int gi = 0; gi < nr; ++gi) {
+            DsgdRank &R = d->ranks[gi];
+            R.g = g0 + gi;
+            R.user_lo = (int)d->ub[R.g];
+            R.nu_local = (int)(d->ub[R.g + 1] - d->ub[R.g]);
+            R.plans.assign((size_t)world, nullptr);
+            for (int j = 0; j < world; ++j) {
+                const size_t b = (size_t)gi * world + j;
+                const int nij = (int)(d->ib[j + 1] - d->ib[j]);
+                R.plans[j] = mfx_sgd_plan_create(bidx[b].data(), br[b].data(), cnt[b], R.nu_local > 0 ? R.nu_local : 1,
+                                                 nij > 0 ? nij : 1, dim);
+                if (!R.plans[j]) {
+                    mfx_dsgd_destroy(d);
+                    return nullptr;
+                }
+                if (j > 0 && plan_alias_users(R.plans[j], R.plans[0])) {
+                    mfx_dsgd_destroy(d);
+                    return nullptr;
+                }
+                std::vector<int32_t>().swap(bidx[b]);
+                std::vector<double>().swap(br[b]);
+            }
+        }
+    } catch (const std::bad_alloc &) {
+        fail(MFX_E_NOMEM, "mfx_dsgd_create: out of host memory");
+        mfx_dsgd_destroy(d);
+        return nullptr;
+    }
+    return d;
+}
+
+/* info[0] = ratings held by this process, [1] = sum of dependency levels over its blocks,
+ * [2] = largest block (ratings), [3] = smallest block, [4] = launches per epoch (all blocks) */
+int mfx_dsgd_info(const mfx_dsgd *d, int64_t info[8])
+{
+    if (!d || !info) return fail(MFX_E_ARG, "mfx_dsgd_info: NULL");
+    memset(info, 0, 8 * sizeof(int64_t));
+    info[0] = d->nnz_local;
+    info[3] = INT64_MAX;
+    for (const DsgdRank &R : d->ranks)
+        for (mfx_sgd_plan *p : R.plans) {
+            int64_t pi[8];
+            mfx_sgd_plan_info(p, pi);
+            info[1] += pi[0];
+            info[4] += pi[2];
+            const int64_t n = plan_nnz(p);
+            if (n > info[2]) info[2] = n;
+            if (n < info[3]) info[3] = n;
+        }
+    return MFX_OK;
+}
+
+// u [k, ni] / items_bias [ni]: the FULL item side (every rank passes the same arrays; a rank keeps the
+// block it starts with).  v [k, nu_local] / users_bias [nu_local]: this rank's users -- in the fake
+// world (rank -1) the full [k, nu] / [nu].
+int mfx_dsgd_set_factors(mfx_dsgd *d, const double *u, const double *v, const double *items_bias,
+                         const double *users_bias)
+{
+    TraceRange trace_("mfx:dsgd_set_factors");
+    if (!d || !u || !v) return fail(MFX_E_ARG, "mfx_dsgd_set_factors: NULL argument");
+    const int k = d->k;
+    const int64_t v_ld = d->rank < 0 ? d->nu : d->ranks[0].nu_local;      // row length of the v passed in
+    std::vector<double> tmp;
+    for (DsgdRank &R : d->ranks) {
+        // users: the rank's column range of v
+        const int64_t off = d->rank < 0 ? R.user_lo : 0;
+        const int n = R.nu_local > 0 ? R.nu_local : 1;
+        tmp.assign((size_t)k * n, 0.0);
+        for (int f = 0; f < k; ++f)
+            if (R.nu_local > 0) memcpy(&tmp[(size_t)f * n], v + (size_t)f * v_ld + off, (size_t)R.nu_local * sizeof(double));
+        std::vector<double> ubt((size_t)n, 0.0);
+        if (users_bias && R.nu_local > 0) memcpy(ubt.data(), users_bias + off, (size_t)R.nu_local * sizeof(double));
+        int rc = plan_upload_users(R.plans[0], tmp.data(), ubt.data());
+        if (rc) return rc;
+        // items: block j = g is the one this rank starts with; the other blocks arrive by rotation, but
+        // every sub-plan gets its block here so that a plan is never run on uninitialised rows
+        for (int j = 0; j < d->world; ++j) {
+            const int nij = (int)(d->ib[j + 1] - d->ib[j]);
+            const int m = nij > 0 ? nij : 1;
+            tmp.assign((size_t)k * m, 0.0);
+            for (int f = 0; f < k; ++f)
+                if (nij > 0) memcpy(&tmp[(size_t)f * m], u + (size_t)f * d->ni + d->ib[j], (size_t)nij * sizeof(double));
+            std::vector<double> ibt((size_t)m, 0.0);
+            if (items_bias && nij > 0) memcpy(ibt.data(), items_bias + d->ib[j], (size_t)nij * sizeof(double));
+            rc = plan_upload_items(R.plans[j], tmp.data(), ibt.data());
+            if (rc) return rc;
+            plan_mark_ready(R.plans[j]);
+        }
+    }
+    d->have_factors = true;
+    return MFX_OK;
+}
+
+// se_out (nullable): f64[nbr_epochs], the squared-error sum of each epoch over ALL ratings of the job
+// (online, as the reference accumulates it, kmf_train.pyx:257); blocks are added in sub-epoch order,
+// ranks in rank order.
+int mfx_dsgd_run_kmf(mfx_dsgd *d, int mode, int nbr_epochs, double lr, double Ku, double Ki, double Kb,
+                     double *se_out)
+{
+    TraceRange trace_("mfx:dsgd_run_kmf (block rotation)");
+    if (!d) return fail(MFX_E_ARG, "mfx_dsgd_run_kmf: NULL");
+    if (!d->have_factors) return fail(MFX_E_STATE, "mfx_dsgd_run_kmf: mfx_dsgd_set_factors has not been called");
+    if (mode != MFX_MODE_LINEAR && mode != MFX_MODE_LOGISTIC) return fail(MFX_E_ARG, "mfx_dsgd_run_kmf: mode %d", mode);
+    if (nbr_epochs <= 0) return MFX_OK;
+    const int G = d->world;
+    hipStream_t s = stream();
+    int rc;
+    for (DsgdRank &R : d->ranks)
+        for (mfx_sgd_plan *p : R.plans)
+            if ((rc = sgd_reset_se(p, nbr_epochs))) return rc;
+    for (int ep = 0; ep < nbr_epochs; ++ep) {
+        for (int sub = 0; sub < G; ++sub) {
+            for (DsgdRank &R : d->ranks) {
+                mfx_sgd_plan *p = R.plans[(R.g + sub) % G];
+                if ((rc = sgd_enqueue_k1(p, mode, lr, Ku, Ki, Kb))) return rc;
+            }
+            if (G == 1) continue;
+            // rotate: block j = (g + sub) % G leaves rank g for rank g - 1
+            if (d->rank < 0) {
+                for (DsgdRank &R : d->ranks) {
+                    const int j = (R.g + sub) % G;
+                    DsgdRank &dst = d->ranks[(R.g + G - 1) % G];
+                    mfx_sgd_plan *from = R.plans[j], *to = dst.plans[j];
+                    MFX_HIP(hipMemcpyAsync(plan_U(to), plan_U(from), (size_t)plan_ni(from) * d->k * sizeof(double),
+                                           hipMemcpyDeviceToDevice, s));
+                    MFX_HIP(hipMemcpyAsync(plan_ib(to), plan_ib(from), (size_t)plan_ni(from) * sizeof(double),
+                                           hipMemcpyDeviceToDevice, s));
+                }
+            } else {
+                DsgdRank &R = d->ranks[0];
+                const int j_out = (R.g + sub) % G, j_in = (R.g + sub + 1) % G;
+                mfx_sgd_plan *po = R.plans[j_out], *pi = R.plans[j_in];
+                // empty item blocks are stored as one padding row: nothing travels for them
+                const size_t n_out = (size_t)(d->ib[j_out + 1] - d->ib[j_out]), n_in = (size_t)(d->ib[j_in + 1] - d->ib[j_in]);
+                const CommSeg out[2] = {{plan_U(po), n_out * d->k}, {plan_ib(po), n_out}};
+                const CommSeg in[2] = {{plan_U(pi), n_in * d->k}, {plan_ib(pi), n_in}};
+                if ((rc = comm_sendrecv_f64(out, 2, (R.g + G - 1) % G, in, 2, (R.g + 1) % G))) return rc;
+            }
+        }
+    }
+    MFX_HIP(hipStreamSynchronize(s));
+    if (se_out) {
+        std::vector<double> se((size_t)nbr_epochs, 0.0), tmp((size_t)nbr_epochs);
+        // per epoch: blocks in sub-epoch order, ranks in rank order (fake world: exactly the order of the
+        // equivalent sequential run; real ranks: each rank's partial, then a rank-ordered sum)
+        std::vector<std::vector<double>> per((size_t)d->ranks.size() * G);
+        for (size_t gi = 0; gi < d->ranks.size(); ++gi)
+            for (int j = 0; j < G; ++j) {
+                per[gi * G + j].resize((size_t)nbr_epochs);
+                if ((rc = sgd_fetch_se(d->ranks[gi].plans[j], nbr_epochs, per[gi * G + j].data()))) return rc;
+            }
+        for (int ep = 0; ep < nbr_epochs; ++ep)
+            for (int sub = 0; sub < G; ++sub)
+                for (size_t gi = 0; gi < d->ranks.size(); ++gi)
+                    se[ep] += per[gi * G + (d->ranks[gi].g + sub) % G][ep];
+        if (d->rank >= 0 && G > 1) {
+            // all-gather the per-rank partials and add them in rank order (deterministic)
+            double *dbuf = nullptr;
+            MFX_HIP(hipMalloc((void **)&dbuf, (size_t)G * nbr_epochs * sizeof(double)));
+            hipError_t e = hipMemcpyAsync(dbuf + (size_t)d->rank * nbr_epochs, se.data(), (size_t)nbr_epochs * sizeof(double),
+                                          hipMemcpyHostToDevice, s);
+            rc = e == hipSuccess ? comm_allgather_f64(dbuf, (size_t)nbr_epochs) : fail(MFX_E_HIP, "mfx_dsgd_run_kmf: copy failed");
+            std::vector<double> all((size_t)G * nbr_epochs);
+            if (!rc && hipMemcpyAsync(all.data(), dbuf, all.size() * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess)
+                rc = fail(MFX_E_HIP, "mfx_dsgd_run_kmf: copy failed");
+            if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = fail(MFX_E_HIP, "mfx_dsgd_run_kmf: sync failed");
+            (void)hipFree(dbuf);
+            if (rc) return rc;
+            for (int ep = 0; ep < nbr_epochs; ++ep) {
+                double t = 0.0;
+                for (int g = 0; g < G; ++g) t += all[(size_t)g * nbr_epochs + ep];
+                se[ep] = t;
+            }
+        }
+        memcpy(se_out, se.data(), (size_t)nbr_epochs * sizeof(double));
+    }
+    return MFX_OK;
+}
+
+// u [k, ni] / items_bias [ni] (nullable): the full item side, gathered from the ranks that hold the
+// blocks (collective: every rank must call).  v / users_bias: as in mfx_dsgd_set_factors.
+int mfx_dsgd_get_factors(mfx_dsgd *d, double *u, double *v, double *items_bias, double *users_bias)
+{
+    TraceRange trace_("mfx:dsgd_get_factors");
+    if (!d) return fail(MFX_E_ARG, "mfx_dsgd_get_factors: NULL");
+    if (!d->have_factors) return fail(MFX_E_STATE, "mfx_dsgd_get_factors: no factors");
+    const int k = d->k, G = d->world;
+    const int64_t v_ld = d->rank < 0 ? d->nu : d->ranks[0].nu_local;
+    std::vector<double> tmp, bt;
+    int rc;
+    for (DsgdRank &R : d->ranks) {
+        if (v || users_bias) {
+            const int n = R.nu_local > 0 ? R.nu_local : 1;
+            tmp.resize((size_t)k * n);
+            bt.resize((size_t)n);
+            if ((rc = plan_download_users(R.plans[0], tmp.data(), bt.data()))) return rc;
+            const int64_t off = d->rank < 0 ? R.user_lo : 0;
+            if (v && R.nu_local > 0)
+                for (int f = 0; f < k; ++f) memcpy(v + (size_t)f * v_ld + off, &tmp[(size_t)f * n], (size_t)R.nu_local * sizeof(double));
+            if (users_bias && R.nu_local > 0) memcpy(users_bias + off, bt.data(), (size_t)R.nu_local * sizeof(double));
+        }
+    }
+    if (!u && !items_bias) return MFX_OK;
+    // between epochs block j is at rank j (plan (j, j)); a real rank broadcasts its block to the others
+    for (int j = 0; j < G; ++j) {
+        const int nij = (int)(d->ib[j + 1] - d->ib[j]);
+        if (nij <= 0) continue;
+        mfx_sgd_plan *p = nullptr;
+        if (d->rank < 0) p = d->ranks[j].plans[j];
+        else {
+            p = d->ranks[0].plans[j];
+            if (G > 1) {
+                if ((rc = comm_broadcast_f64(plan_U(p), (size_t)nij * k, j))) return rc;
+                if ((rc = comm_broadcast_f64(plan_ib(p), (size_t)nij, j))) return rc;
+            }
+        }
+        tmp.resize((size_t)k * nij);
+        bt.resize((size_t)nij);
+        if ((rc = plan_download_items(p, tmp.data(), bt.data()))) return rc;
+        if (u)
+            for (int f = 0; f < k; ++f) memcpy(u + (size_t)f * d->ni + d->ib[j], &tmp[(size_t)f * nij], (size_t)nij * sizeof(double));
+        if (items_bias) memcpy(items_bias + d->ib[j], bt.data(), (size_t)nij * sizeof(double));
+    }
+    return MFX_OK;
+}
+
+}  // extern "C"

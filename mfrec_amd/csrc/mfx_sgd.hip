@@ -7,6 +7,7 @@
 #include <unordered_map>
 #include <vector>
 #include "mfx_sgd_kernels.h"
+#include "mfx_sgd_internal.h"
 
 using namespace mfx;
 
@@ -53,6 +54,7 @@ struct mfx_sgd_plan {
     double *d_U_start = nullptr, *d_ib_start = nullptr;   // sharded mode (lazy)
     bool have_factors = false;
     bool nk_current = false, km_current = false;
+    bool owns_users = true;              // false: d_V_*, d_ub belong to another plan (plan_alias_users)
 
     K2Dyn *d_k2dyn = nullptr;            // Funk per-feature record (lazy)
     hipGraphExec_t graph2 = nullptr;     // cached hipGraph of one Funk epoch
@@ -78,9 +80,12 @@ int dev_alloc(mfx_sgd_plan *p, T **ptr, size_t n)
     return MFX_OK;
 }
 
+void drop_graph(mfx_sgd_plan *p);
+
 int ensure_se_cap(mfx_sgd_plan *p, int64_t epochs)
 {
     if (epochs <= p->se_cap) return MFX_OK;
+    drop_graph(p);                     // the captured epochs hold the old array's address
     if (p->d_se_epoch) (void)hipFree(p->d_se_epoch);
     p->d_se_epoch = nullptr;
     int64_t cap = epochs < 64 ? 64 : epochs;
@@ -103,8 +108,9 @@ template <typename TI, typename TO>
 int transpose(const TI *in, TO *out, int rows, int cols)
 {
     if (rows == 0 || cols == 0) return MFX_OK;
-    dim3 grid(ceil_div(cols, 32), ceil_div(rows, 32));
-    hipLaunchKernelGGL((k_transpose<TI, TO>), grid, dim3(256), 0, stream(), in, out, rows, cols);
+    const int64_t tiles = (int64_t)ceil_div(cols, 32) * ceil_div(rows, 32);
+    if (tiles > 0x7fffffff) return fail(MFX_E_ARG, "transpose: %d x %d is too large", rows, cols);
+    hipLaunchKernelGGL((k_transpose<TI, TO>), dim3((unsigned)tiles), dim3(256), 0, stream(), in, out, rows, cols);
     MFX_HIP(hipGetLastError());
     return MFX_OK;
 }
@@ -151,18 +157,24 @@ int k1_vec_mode()
     return (e && *e) ? atoi(e) : 2;
 }
 
-// pick the kernel instantiation for (k, mode, batch, storage type)
+// pick the kernel instantiation for (k, mode, batch, storage type); `tag` names the template
+// arguments that were chosen (mfx_sgd_plan_kernel_name: bench.py labels its roofline with it)
+struct K1Sel {
+    void *fn;
+    const char *tag;
+};
+
 template <int MODE, typename TS, bool TAIL>
-void *k1_pick(int k, int batch)
+K1Sel k1_pick(int k, int batch)
 {
-#define MFX_K1(KP, FPL, B) (TAIL ? (void *)k1_tail<KP, FPL, B, MODE, 0, TS> : (void *)k1_level<KP, FPL, B, MODE, 0, TS>)
+#define MFX_K1(KP, FPL, B) K1Sel{TAIL ? (void *)k1_tail<KP, FPL, B, MODE, 0, TS> : (void *)k1_level<KP, FPL, B, MODE, 0, TS>, #KP "," #FPL "," #B ",8B/lane"}
     // (the tail kernel runs several levels in one launch: it keeps plain stores, which the compiler
     // drains before the workgroup barrier between levels -- an asm store would slip past it)
     // 16 bytes per lane (contiguous feature pairs), f64 rows, even k > 4: vec = 1 plain
     // stores, vec = 2 (default) write-through stores -- no dirty lines left for the end-of-kernel
     // write-back.  cfg 2: 1.68 (8 B per lane) / 1.75 / 1.88 G updates/s; 16 or 4 ratings per wave,
     // and write-through bias stores, measured slower.
-#define MFX_K1VF(KP, FPL, B, NTF) (TAIL ? (void *)k1_tail<KP, FPL, B, MODE, 0, TS, true> : (void *)k1_level<KP, FPL, B, MODE, NTF, TS, true>)
+#define MFX_K1VF(KP, FPL, B, NTF) K1Sel{TAIL ? (void *)k1_tail<KP, FPL, B, MODE, 0, TS, true> : (void *)k1_level<KP, FPL, B, MODE, NTF, TS, true>, (NTF == 2 && !TAIL) ? #KP "," #FPL "," #B ",vec16+wt" : #KP "," #FPL "," #B ",vec16"}
     {
         // the learned-bias family stores ONE feature per row: 16-byte loads only, plain stores
         const int vec = (MODE == K1_LEARNED && k1_vec_mode()) ? 1 : k1_vec_mode();   // (write-through scalars: no gain)
@@ -204,7 +216,7 @@ void *k1_pick(int k, int batch)
 }
 
 template <bool TAIL>
-void *k1_select(int k, int mode, int batch, int f32)
+K1Sel k1_select(int k, int mode, int batch, int f32)
 {
     switch (mode * 2 + (f32 ? 1 : 0)) {
     case 0: return k1_pick<K1_LINEAR, double, TAIL>(k, batch);
@@ -216,8 +228,8 @@ void *k1_select(int k, int mode, int batch, int f32)
     }
 }
 
-void *k1_kernel(int k, int mode, int batch, int f32) { return k1_select<false>(k, mode, batch, f32); }
-void *k1_tail_kernel(int k, int mode, int batch, int f32) { return k1_select<true>(k, mode, batch, f32); }
+void *k1_kernel(int k, int mode, int batch, int f32) { return k1_select<false>(k, mode, batch, f32).fn; }
+void *k1_tail_kernel(int k, int mode, int batch, int f32) { return k1_select<true>(k, mode, batch, f32).fn; }
 
 int env_int(const char *name, int dflt)
 {
@@ -331,14 +343,14 @@ K1Params k1_params(mfx_sgd_plan *p, double lr, double Ku, double Ki, double Kb, 
 // run `epochs` full-k epochs; hook (nullable) is called after each epoch's launches have
 // been enqueued (sharded mode enqueues its all-reduce there).
 template <typename Hook>
-int run_k1_epochs(mfx_sgd_plan *p, int mode, int epochs, const K1Params &P, Hook &&hook)
+int run_k1_epochs(mfx_sgd_plan *p, int mode, int epochs, const K1Params &P, Hook &&hook, bool reset_se = true)
 {
-    int rc = ensure_se_cap(p, epochs);
+    int rc = reset_se ? ensure_se_cap(p, epochs) : MFX_OK;
     if (rc) return rc;
     rc = to_nk(p);
     if (rc) return rc;
     p->km_current = false;
-    MFX_HIP(hipMemsetAsync(p->d_counter, 0, sizeof(int), stream()));
+    if (reset_se) MFX_HIP(hipMemsetAsync(p->d_counter, 0, sizeof(int), stream()));
     // very long launch sequences (power-law data without the tail kernel) are not worth a graph
     const bool graph = use_graph() && p->segs.size() <= kMaxGraphNodes;
     if (graph && !(p->graph && p->graph_mode == mode && same_params(p->graph_params, P))) {
@@ -390,7 +402,7 @@ int fetch_rmse(mfx_sgd_plan *p, int64_t n, double *rmse_out, double *se_out)
 
 }  // namespace
 
-// exposed to mfx_comm.hip (sharded mode)
+// exposed to mfx_comm.hip / mfx_dsgd.hip (mfx_sgd_internal.h)
 namespace mfx {
 int sgd_run_k1_hooked(mfx_sgd_plan *p, int mode, int epochs, double lr, double Ku, double Ki,
                       double Kb, int (*hook)(mfx_sgd_plan *, int, void *), void *ctx,
@@ -404,10 +416,29 @@ int sgd_run_k1_hooked(mfx_sgd_plan *p, int mode, int epochs, double lr, double K
     if (rc) return rc;
     return fetch_rmse(p, epochs, rmse_out, se_out);
 }
+int sgd_reset_se(mfx_sgd_plan *p, int64_t epochs)
+{
+    int rc = ensure_se_cap(p, epochs);
+    if (rc) return rc;
+    MFX_HIP(hipMemsetAsync(p->d_counter, 0, sizeof(int), stream()));
+    return MFX_OK;
+}
+int sgd_enqueue_k1(mfx_sgd_plan *p, int mode, double lr, double Ku, double Ki, double Kb)
+{
+    int rc = check_plan(p, "sgd_enqueue_k1");
+    if (rc) return rc;
+    K1Params P = k1_params(p, lr, Ku, Ki, Kb, 1, 1);
+    return run_k1_epochs(p, mode, 1, P, [](int) { return MFX_OK; }, false);
+}
+int sgd_fetch_se(mfx_sgd_plan *p, int64_t n, double *se_out) { return fetch_rmse(p, n, nullptr, se_out); }
 double *plan_U(mfx_sgd_plan *p) { return p->d_U_nk; }
+double *plan_V(mfx_sgd_plan *p) { return p->d_V_nk; }
 double *plan_ib(mfx_sgd_plan *p) { return p->d_ib; }
+double *plan_ub(mfx_sgd_plan *p) { return p->d_ub; }
 int plan_ni(mfx_sgd_plan *p) { return p->ni; }
+int plan_nu(mfx_sgd_plan *p) { return p->nu; }
 int plan_k(mfx_sgd_plan *p) { return p->k; }
+int64_t plan_nnz(mfx_sgd_plan *p) { return p->nnz; }
 int plan_start_buffers(mfx_sgd_plan *p, double **U_start, double **ib_start)
 {
     if (!p->d_U_start) {
@@ -420,6 +451,65 @@ int plan_start_buffers(mfx_sgd_plan *p, double **U_start, double **ib_start)
     return MFX_OK;
 }
 int plan_prepare_nk(mfx_sgd_plan *p) { return to_nk(p); }
+int plan_alias_users(mfx_sgd_plan *p, mfx_sgd_plan *master)
+{
+    if (!p || !master || p == master || p->nu != master->nu || p->k != master->k || p->f32 || master->f32)
+        return fail(MFX_E_ARG, "plan_alias_users: plans disagree on the user side");
+    if (p->have_factors) return fail(MFX_E_STATE, "plan_alias_users: call before factors are set");
+    drop_graph(p);
+    if (p->owns_users) {
+        if (p->d_V_km) (void)hipFree(p->d_V_km);
+        if (p->d_V_nk) (void)hipFree(p->d_V_nk);
+        if (p->d_ub) (void)hipFree(p->d_ub);
+    }
+    p->owns_users = false;
+    p->d_V_km = master->d_V_km;
+    p->d_V_nk = master->d_V_nk;
+    p->d_ub = master->d_ub;
+    return MFX_OK;
+}
+int plan_upload_items(mfx_sgd_plan *p, const double *u_km, const double *ib)
+{
+    if (p->f32) return fail(MFX_E_STATE, "plan_upload_items: f64 rows only");
+    MFX_HIP(hipStreamSynchronize(stream()));
+    MFX_HIP(hipMemcpy(p->d_U_km, u_km, (size_t)p->k * p->ni * sizeof(double), hipMemcpyHostToDevice));
+    if (ib) MFX_HIP(hipMemcpy(p->d_ib, ib, (size_t)p->ni * sizeof(double), hipMemcpyHostToDevice));
+    else MFX_HIP(hipMemset(p->d_ib, 0, (size_t)p->ni * sizeof(double)));
+    return transpose(p->d_U_km, p->d_U_nk, p->k, p->ni);
+}
+int plan_upload_users(mfx_sgd_plan *p, const double *v_km, const double *ub)
+{
+    if (p->f32) return fail(MFX_E_STATE, "plan_upload_users: f64 rows only");
+    MFX_HIP(hipStreamSynchronize(stream()));
+    MFX_HIP(hipMemcpy(p->d_V_km, v_km, (size_t)p->k * p->nu * sizeof(double), hipMemcpyHostToDevice));
+    if (ub) MFX_HIP(hipMemcpy(p->d_ub, ub, (size_t)p->nu * sizeof(double), hipMemcpyHostToDevice));
+    else MFX_HIP(hipMemset(p->d_ub, 0, (size_t)p->nu * sizeof(double)));
+    return transpose(p->d_V_km, p->d_V_nk, p->k, p->nu);
+}
+int plan_download_items(mfx_sgd_plan *p, double *u_km, double *ib)
+{
+    int rc = transpose((const double *)p->d_U_nk, p->d_U_km, p->ni, p->k);
+    if (rc) return rc;
+    MFX_HIP(hipStreamSynchronize(stream()));
+    if (u_km) MFX_HIP(hipMemcpy(u_km, p->d_U_km, (size_t)p->k * p->ni * sizeof(double), hipMemcpyDeviceToHost));
+    if (ib) MFX_HIP(hipMemcpy(ib, p->d_ib, (size_t)p->ni * sizeof(double), hipMemcpyDeviceToHost));
+    return MFX_OK;
+}
+int plan_download_users(mfx_sgd_plan *p, double *v_km, double *ub)
+{
+    int rc = transpose((const double *)p->d_V_nk, p->d_V_km, p->nu, p->k);
+    if (rc) return rc;
+    MFX_HIP(hipStreamSynchronize(stream()));
+    if (v_km) MFX_HIP(hipMemcpy(v_km, p->d_V_km, (size_t)p->k * p->nu * sizeof(double), hipMemcpyDeviceToHost));
+    if (ub) MFX_HIP(hipMemcpy(ub, p->d_ub, (size_t)p->nu * sizeof(double), hipMemcpyDeviceToHost));
+    return MFX_OK;
+}
+void plan_mark_ready(mfx_sgd_plan *p)
+{
+    p->have_factors = true;
+    p->nk_current = true;        // the row-major copies are the live ones from here on
+    p->km_current = false;
+}
 }  // namespace mfx
 
 extern "C" {
@@ -578,6 +668,7 @@ void mfx_sgd_plan_destroy(mfx_sgd_plan *p)
     if (!p) return;
     if (ready()) (void)hipStreamSynchronize(stream());
     drop_graph(p);
+    if (!p->owns_users) p->d_V_km = p->d_V_nk = p->d_ub = nullptr;
     void *ptrs[] = {p->d_recs, p->d_U_km, p->d_V_km, p->d_U_nk, p->d_V_nk, p->d_ib, p->d_ub,
                     p->d_cache, p->d_k2dyn, p->d_level_off, p->d_k1_wave_off, p->d_k2_wave_off, p->d_se_partial, p->d_se_tmp, p->d_se_epoch, p->d_counter, p->d_U_start,
                     p->d_ib_start};
@@ -608,6 +699,15 @@ int mfx_sgd_plan_info(const mfx_sgd_plan *p, int64_t info[8])
     info[6] = p->sched_us;
     info[7] = (int64_t)p->segs2.size();
     (void)flaunches;
+    return MFX_OK;
+}
+
+int mfx_sgd_plan_kernel_name(const mfx_sgd_plan *p, int mode, char *buf, int buflen)
+{
+    if (!p || !buf || buflen < 1 || mode < 0 || mode > 2) return fail(MFX_E_ARG, "mfx_sgd_plan_kernel_name: bad argument");
+    static const char *const mode_name[] = {"linear", "logistic", "learned"};
+    snprintf(buf, (size_t)buflen, "k1_level<%s,%s%s>", k1_select<false>(p->k, mode, p->batch, p->f32).tag,
+             mode_name[mode], p->f32 ? ",f32" : "");
     return MFX_OK;
 }
 
@@ -730,15 +830,9 @@ static int enqueue_k2_epoch(mfx_sgd_plan *p, const K2Params &P)
 }  // extern "C"
 
 namespace mfx {
-// hooks of the user-sharded Funk pass (mfx_comm.hip): snapshot / combine the item-side feature
-// vector around every epoch and make the squared error global, so that every rank takes the
-// same decision in the data-dependent stopping rule
-struct FunkHooks {
-    int (*pre)(void *ctx, double *uf, int ni);
-    int (*post)(void *ctx, double *uf, int ni);
-    int (*global_se)(void *ctx, double *se, double *nnz);
-    void *ctx;
-};
+// (FunkHooks: mfx_sgd_internal.h -- snapshot / combine the item-side feature vector around every
+// epoch and make the squared error global, so that every rank takes the same decision in the
+// data-dependent stopping rule)
 
 int funk_core(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_init, double lr,
               double K, double mu, int use_bias, int upd_u, int upd_i, int epoch_cap,
@@ -907,6 +1001,21 @@ int mfx_kmf_train(int mode, int nbr_epochs, int dim, double lr, double Ku, doubl
     return rc;
 }
 
+// No ratings: the reference's loops run min_epochs empty epochs per feature (rmse = sqrt(0/0) is NaN and
+// `NaN <= x` is false, gd_estimator.pyx:742) and leave every array as it was -- e.g. retrain_user for
+// a user without ratings (gradient_descent.py:879-905) is a no-op, not an error.
+static int empty_history(int min_epochs, int dim, int epoch_cap, double *rmse_hist, int64_t hist_cap,
+                         int64_t *n_hist)
+{
+    int per_feature = min_epochs > 0 ? min_epochs : 0;
+    if (epoch_cap > 0 && per_feature > epoch_cap) per_feature = epoch_cap;
+    const int64_t n = (int64_t)per_feature * (dim > 0 ? dim : 0);
+    if (rmse_hist)
+        for (int64_t i = 0; i < n && i < hist_cap; ++i) rmse_hist[i] = NAN;
+    if (n_hist) *n_hist = n;
+    return MFX_OK;
+}
+
 int mfx_funk(int min_epochs, double min_improvement, int dim, double f_init, double lr, double K,
              double mu, double *u, double *v, const int32_t *idx, const double *r, const double *ib,
              const double *ub, int64_t nnz, int nu, int ni, int upd_u, int upd_i, int epoch_cap,
@@ -916,9 +1025,7 @@ int mfx_funk(int min_epochs, double min_improvement, int dim, double f_init, dou
         return fail(MFX_E_ARG, "mfx_funk: NULL argument");
     }
     if (n_hist) *n_hist = 0;
-    if (nnz == 0) {
-        return fail(MFX_E_ARG, "mfx_funk: no ratings (the reference's stopping rule would divide 0/0)");
-    }
+    if (nnz == 0) return empty_history(min_epochs, dim, epoch_cap, rmse_hist, hist_cap, n_hist);
     mfx_sgd_plan *p = mfx_sgd_plan_create(idx, r, nnz, nu, ni, dim);
     if (!p) return last_code();
     int rc = mfx_sgd_set_factors(p, u, v, ib, ub);
@@ -939,9 +1046,7 @@ int mfx_learned_bias(int min_epochs, double min_improvement, int dim, double f_i
         return fail(MFX_E_ARG, "mfx_learned_bias: NULL argument");
     }
     if (n_hist) *n_hist = 0;
-    if (nnz == 0) {
-        return fail(MFX_E_ARG, "mfx_learned_bias: no ratings");
-    }
+    if (nnz == 0) return empty_history(min_epochs, dim, epoch_cap, rmse_hist, hist_cap, n_hist);
     mfx_sgd_plan *p = mfx_sgd_plan_create(idx, r, nnz, nu, ni, dim);
     if (!p) return last_code();
     int rc = mfx_sgd_set_factors(p, u, v, ib, ub);

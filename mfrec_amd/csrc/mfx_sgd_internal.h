@@ -1,0 +1,68 @@
+// Internals of the SGD plan shared between mfx_sgd.hip (owner), mfx_comm.hip (user-sharded
+// averaging mode) and mfx_dsgd.hip (exact block-rotation mode).  Not part of the ABI.
+#pragma once
+#include "mfx_common.h"
+
+struct mfx_sgd_plan;
+
+namespace mfx {
+
+// ---- full-k epochs -------------------------------------------------------------------------
+// `epochs` full-k epochs with `hook` (nullable) called after each epoch's launches have been enqueued;
+// ends with a stream sync and fills rmse_out / se_out (nullable, f64[epochs]).
+int sgd_run_k1_hooked(mfx_sgd_plan *p, int mode, int epochs, double lr, double Ku, double Ki,
+                      double Kb, int (*hook)(mfx_sgd_plan *, int, void *), void *ctx,
+                      double *rmse_out, double *se_out);
+// Asynchronous building block: enqueue ONE full-k epoch (hipGraph replay) on the library stream.
+// The epoch's squared-error sum lands in the plan's per-epoch array at the plan's running counter;
+// sgd_reset_se() rewinds that counter (and sizes the array), sgd_fetch_se() syncs and reads it.
+int sgd_reset_se(mfx_sgd_plan *p, int64_t epochs);
+int sgd_enqueue_k1(mfx_sgd_plan *p, int mode, double lr, double Ku, double Ki, double Kb);
+int sgd_fetch_se(mfx_sgd_plan *p, int64_t n, double *se_out);
+
+// ---- plan state ----------------------------------------------------------------------------
+double *plan_U(mfx_sgd_plan *p);          // [ni][k] row-major item rows
+double *plan_V(mfx_sgd_plan *p);          // [nu][k]
+double *plan_ib(mfx_sgd_plan *p);
+double *plan_ub(mfx_sgd_plan *p);
+int plan_ni(mfx_sgd_plan *p);
+int plan_nu(mfx_sgd_plan *p);
+int plan_k(mfx_sgd_plan *p);
+int64_t plan_nnz(mfx_sgd_plan *p);
+int plan_start_buffers(mfx_sgd_plan *p, double **U_start, double **ib_start);
+int plan_prepare_nk(mfx_sgd_plan *p);
+// Several plans over the SAME users (the item blocks of one DSGD rank): p gives up its own user-side
+// buffers and uses master's.  Call before any factor is set.
+int plan_alias_users(mfx_sgd_plan *p, mfx_sgd_plan *master);
+// Side-by-side factor transfers in the host layout ([k][n] feature-major f64), one side at a time;
+// after the first upload of BOTH sides plan_mark_ready() declares the row-major copies current.
+int plan_upload_items(mfx_sgd_plan *p, const double *u_km, const double *ib);
+int plan_upload_users(mfx_sgd_plan *p, const double *v_km, const double *ub);
+int plan_download_items(mfx_sgd_plan *p, double *u_km, double *ib);
+int plan_download_users(mfx_sgd_plan *p, double *v_km, double *ub);
+void plan_mark_ready(mfx_sgd_plan *p);
+
+// ---- Funk hooks (user-sharded Funk pass) ---------------------------------------------------
+struct FunkHooks {
+    int (*pre)(void *ctx, double *uf, int ni);
+    int (*post)(void *ctx, double *uf, int ni);
+    int (*global_se)(void *ctx, double *se, double *nnz);
+    void *ctx;
+};
+int funk_core(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_init, double lr,
+              double K, double mu, int use_bias, int upd_u, int upd_i, int epoch_cap,
+              double *rmse_hist, int64_t hist_cap, int64_t *n_hist, const FunkHooks *hk);
+
+// ---- communicator (mfx_comm.hip) -----------------------------------------------------------
+bool comm_active();
+int comm_rank();
+int comm_world();
+int comm_allgather_f64(double *buf, size_t count);          // in place: rank g's part at buf + g*count
+int comm_allreduce_sum_f64(double *buf, size_t count);      // in place, library stream
+int comm_broadcast_f64(double *buf, size_t count, int root);
+// one fused group on the library stream: send every (ptr, count) of `out` to `to`, receive every
+// (ptr, count) of `in` from `from`
+struct CommSeg { double *ptr; size_t count; };
+int comm_sendrecv_f64(const CommSeg *out, int n_out, int to, const CommSeg *in, int n_in, int from);
+
+}  // namespace mfx

@@ -628,12 +628,14 @@ __global__ void k_reduce_se2(const double *tmp, double *out, int *counter)
     }
 }
 
-// out[c][r] = in[r][c]; in is rows x cols row-major; element types converted on the way
+// out[c][r] = in[r][c]; in is rows x cols row-major; element types converted on the way.
+// 1-D grid of ceil(cols/32) * ceil(rows/32) tiles (a 2-D grid would cap rows at 65535 * 32).
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void k_transpose(const TI *in, TO *out, int rows, int cols)
 {
     __shared__ double tile[32][33];
-    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const unsigned nbx = (unsigned)(cols + 31) / 32;
+    const int bx = (int)(blockIdx.x % nbx) * 32, by = (int)(blockIdx.x / nbx) * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     for (int i = ty; i < 32; i += 8) {
         const int r = by + i, c = bx + tx;

@@ -58,6 +58,12 @@ class SgdPlan(object):
         d["schedule_builder"] = {1: "host", 2: "device"}.get(S.lib().mfx_sgd_plan_schedule_builder(self._h), "?")
         return d
 
+    def kernel_name(self, mode=LINEAR):
+        """The k1_level instantiation the library launches for this plan (from the library itself)."""
+        buf = C.create_string_buffer(128)
+        S.check(S.lib().mfx_sgd_plan_kernel_name(self._h, int(mode), buf, 128))
+        return buf.value.decode()
+
     def set_factors(self, u, v, items_bias=None, users_bias=None):
         pu, pv, nu, ni = S.factor_args(u, v, self.k)
         if (nu, ni) != (self.nu, self.ni):
@@ -131,6 +137,18 @@ class SgdPlan(object):
                                                 float(K_items), float(K_bias), float(scale),
                                                 S.f64(rm, "rmse", 1), S.f64(se, "se", 1)))
         return rm[:int(nbr_epochs)], se[:int(nbr_epochs)]
+
+
+def run_kmf_fake_world(plans, mode, nbr_epochs, learning_rate, K_users, K_items, K_bias, scale):
+    """All shards of the user-sharded scheme on ONE GPU, rank-ordered on-device sum in place of the
+    all-reduce (mfx_sgd_run_kmf_fake_world).  -> se f64[world, nbr_epochs]."""
+    world = len(plans)
+    arr = (C.c_void_p * world)(*[p._h for p in plans])
+    se = np.zeros((world, max(int(nbr_epochs), 1)))
+    S.check(S.lib().mfx_sgd_run_kmf_fake_world(arr, world, int(mode), int(nbr_epochs), float(learning_rate),
+                                               float(K_users), float(K_items), float(K_bias), float(scale),
+                                               S.f64(se, "se", 2)))
+    return se[:, :int(nbr_epochs)]
 
 
 class Timer(object):

@@ -61,6 +61,147 @@ def epoch_loop(nbr_epochs, u, items_bias, local_epoch, allreduce_sum, world, sca
         items_bias[...] = combine(ib_start, dib, scale)
 
 
+class FakeWorldKMF(object):
+    """All `world` shards of the averaging scheme on ONE GPU (test / rehearsal hook): the same
+    delta / combine kernels as the RCCL path, with a rank-ordered on-device sum standing in for the
+    all-reduce -- so the result equals oracle/sharded_sim.py bit for bit."""
+
+    def __init__(self, ratings_index, ratings, nbr_users, nbr_items, dim, world):
+        from .plan import SgdPlan
+        self.world, self.k, self.nu, self.ni = int(world), int(dim), int(nbr_users), int(nbr_items)
+        self.bounds = user_blocks(ratings_index, nbr_users, world)
+        self.shards = [shard(ratings_index, ratings, self.bounds, g) for g in range(world)]
+        self.plans = [SgdPlan(idx, r, max(n, 1), nbr_items, dim) for idx, r, lo, n in self.shards]
+
+    def set_factors(self, u, v_full, items_bias, users_bias_full):
+        for p, (_, _, lo, n) in zip(self.plans, self.shards):
+            p.set_factors(u, np.ascontiguousarray(v_full[:, lo:lo + max(n, 1)]), items_bias,
+                          np.ascontiguousarray(users_bias_full[lo:lo + max(n, 1)]))
+
+    def train(self, mode, nbr_epochs, learning_rate, K_users, K_items, K_bias, scale=None):
+        from .plan import run_kmf_fake_world
+        scale = 1.0 / self.world if scale is None else scale
+        return run_kmf_fake_world(self.plans, mode, nbr_epochs, learning_rate, K_users, K_items, K_bias, scale)
+
+    def get_factors(self):
+        u = np.zeros((self.k, self.ni)); ib = np.zeros(self.ni)
+        v = np.zeros((self.k, self.nu)); ub = np.zeros(self.nu)
+        for g, (p, (_, _, lo, n)) in enumerate(zip(self.plans, self.shards)):
+            ug = np.zeros((self.k, self.ni)); vg = np.zeros((self.k, max(n, 1)))
+            ibg = np.zeros(self.ni); ubg = np.zeros(max(n, 1))
+            p.get_factors(ug, vg, ibg, ubg)
+            if g == 0:
+                u, ib = ug, ibg
+            v[:, lo:lo + n] = vg[:, :n]; ub[lo:lo + n] = ubg[:n]
+        return u, v, ib, ub
+
+    def close(self):
+        for p in self.plans:
+            p.close()
+
+
+# ------------------------------------------------------------------------------------------
+# Exact multi-GPU mode: DSGD block rotation (include/mfx.h "exact multi-GPU mode")
+# ------------------------------------------------------------------------------------------
+def item_blocks(ratings_index, nbr_items, world):
+    """-> int64[world+1] item boundaries: contiguous blocks with ~equal rating counts."""
+    sw = np.ascontiguousarray(ratings_index[:, ::-1])
+    return user_blocks(sw, nbr_items, world)
+
+
+def dsgd_block_order(ratings_index, user_bounds, item_bounds):
+    """The sequential rating order a DSGD epoch is bit-identical to: sub-epoch s = 0..G-1, inside it
+    GPU g = 0..G-1 with its block (g, (g+s) mod G), inside a block the given order.  -> int64 perm."""
+    G = len(user_bounds) - 1
+    ub = np.searchsorted(user_bounds, ratings_index[:, 0], side="right") - 1
+    jb = np.searchsorted(item_bounds, ratings_index[:, 1], side="right") - 1
+    # empty blocks repeat a bound: searchsorted(right) lands on the LAST block starting at that id,
+    # which is the non-empty one -- the same choice as the library's binary search
+    sub = (jb - ub) % G
+    return np.lexsort((np.arange(ratings_index.shape[0]), ub, sub)).astype(np.int64)
+
+
+def dsgd_epoch_loop(nbr_epochs, rank, world, train_block, rotate):
+    """Generic DSGD driver (what mfx_dsgd_run_kmf does inside libmfx): train_block(j) runs this rank's
+    ratings of item block j in place; rotate(j_out, j_in) sends block j_out to rank-1 and receives block
+    j_in from rank+1."""
+    for _ in range(nbr_epochs):
+        for s in range(world):
+            j = (rank + s) % world
+            train_block(j)
+            if world > 1:
+                rotate(j, (j + 1) % world)
+
+
+class DsgdKMF(object):
+    """Exact multi-GPU full-k SGD (mfx_dsgd_*).  rank = -1: every rank in this process on this GPU."""
+
+    def __init__(self, ratings_index, ratings, nbr_users, nbr_items, dim, rank, world,
+                 user_bounds=None, item_bounds=None):
+        import ctypes as C
+        from . import _shim as S
+        self.rank, self.world, self.k = int(rank), int(world), int(dim)
+        self.nu, self.ni = int(nbr_users), int(nbr_items)
+        self.user_bounds = np.ascontiguousarray(
+            user_blocks(ratings_index, nbr_users, world) if user_bounds is None else user_bounds, dtype=np.int64)
+        self.item_bounds = np.ascontiguousarray(
+            item_blocks(ratings_index, nbr_items, world) if item_bounds is None else item_bounds, dtype=np.int64)
+        pi, pr, nnz = S.ratings_args(ratings_index, ratings)
+        self._h = S.lib().mfx_dsgd_create(pi, pr, nnz, self.nu, self.ni, self.k,
+                                          self.user_bounds.ctypes.data_as(S._lp),
+                                          self.item_bounds.ctypes.data_as(S._lp), self.rank, self.world)
+        if not self._h:
+            msg = S.last_error()
+            raise (ValueError if ("outside" in msg or "bad argument" in msg or "bounds" in msg) else S.MfxError)(msg)
+        g = max(self.rank, 0)
+        self.user_lo = 0 if self.rank < 0 else int(self.user_bounds[g])
+        self.nu_local = self.nu if self.rank < 0 else int(self.user_bounds[g + 1] - self.user_bounds[g])
+
+    def info(self):
+        import ctypes as C
+        from . import _shim as S
+        a = (C.c_int64 * 8)()
+        S.check(S.lib().mfx_dsgd_info(self._h, a))
+        return dict(zip(("nnz_local", "levels_total", "max_block", "min_block", "launches_per_epoch"),
+                        [int(x) for x in a][:5]))
+
+    def _args(self, u, v, items_bias, users_bias):
+        from . import _shim as S
+        pu = S.f64(u, "u", 2, (self.k, self.ni))
+        pv = S.f64(v, "v", 2, (self.k, self.nu_local))
+        pib = S.f64(items_bias, "items_bias", 1, (self.ni,), allow_none=True)
+        pub = S.f64(users_bias, "users_bias", 1, (self.nu_local,), allow_none=True)
+        return pu, pv, pib, pub
+
+    def set_factors(self, u, v, items_bias=None, users_bias=None):
+        from . import _shim as S
+        S.check(S.lib().mfx_dsgd_set_factors(self._h, *self._args(u, v, items_bias, users_bias)))
+
+    def train(self, mode, nbr_epochs, learning_rate, K_users, K_items, K_bias):
+        """-> f64[nbr_epochs] squared-error sums over all ratings of the job (online)."""
+        from . import _shim as S
+        se = np.zeros(max(int(nbr_epochs), 1))
+        S.check(S.lib().mfx_dsgd_run_kmf(self._h, int(mode), int(nbr_epochs), float(learning_rate),
+                                         float(K_users), float(K_items), float(K_bias), S.f64(se, "se", 1)))
+        return se[:int(nbr_epochs)]
+
+    def get_factors(self, u, v, items_bias=None, users_bias=None):
+        from . import _shim as S
+        S.check(S.lib().mfx_dsgd_get_factors(self._h, *self._args(u, v, items_bias, users_bias)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            from . import _shim as S
+            S.lib().mfx_dsgd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ShardedKMF(object):
     """One rank of a user-sharded full-k SGD run on its own GPU (RCCL inside libmfx)."""
 

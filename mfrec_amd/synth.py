@@ -55,19 +55,24 @@ def planted_factors(n, seed, rank=PLANTED_RANK, std=0.6):
     return (std * _normal(seed, c)).reshape(n, rank)
 
 
-def make_ratings(nu, ni, nnz, seed=SEED_DATA, t0=0, user_base=0, nu_total=None, chunk=1 << 22):
+def make_ratings(nu, ni, nnz, seed=SEED_DATA, t0=0, user_base=0, nu_total=None, chunk=1 << 18,
+                 workers=None):
     """Return (ratings_index int32[nnz,2] (user,item), ratings f64[nnz]).
 
     t0 / user_base let a rank generate only its own shard: rating counters
     t0..t0+nnz-1, users drawn uniformly from [user_base, user_base + nu).
     nu_total (default nu) is the size of the planted user-factor table.
+    Chunks are independent (counter-based), so they are filled by a thread pool (numpy
+    releases the GIL inside its loops); the result does not depend on `workers`.
     """
+    import os
     nu_total = nu if nu_total is None else nu_total
     P = planted_factors(nu_total, seed + 1)
     Q = planted_factors(ni, seed + 2)
     idx = np.empty((nnz, 2), dtype=np.int32)
     r = np.empty(nnz, dtype=np.float64)
-    for a in range(0, nnz, chunk):
+
+    def fill(a):
         b = min(nnz, a + chunk)
         t = np.arange(t0 + a, t0 + b, dtype=np.uint64)
         h0, h1 = splitmix64_pair(seed, t)
@@ -78,6 +83,17 @@ def make_ratings(nu, ni, nnz, seed=SEED_DATA, t0=0, user_base=0, nu_total=None, 
         idx[a:b, 0] = user
         idx[a:b, 1] = item
         r[a:b] = np.clip(np.rint(val), 1.0, 5.0)
+
+    starts = list(range(0, nnz, chunk))
+    if workers is None:
+        workers = min(16, os.cpu_count() or 1)
+    if workers <= 1 or len(starts) <= 1:
+        for a in starts:
+            fill(a)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=workers) as ex:
+            list(ex.map(fill, starts))
     return idx, r
 
 

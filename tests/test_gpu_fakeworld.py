@@ -1,0 +1,118 @@
+"""GPU (one device): the G > 1 arithmetic of both multi-GPU modes on the HIP path.
+
+  * averaging mode (mfx_sgd_run_kmf_sharded's scheme): all G shards on this GPU through the same
+    k_sub / k_combine kernels, rank-ordered on-device sum in place of the all-reduce ->
+    bit-identical to oracle/sharded_sim.py at G = 2, 8 and scale = 1/G, 1.
+    (On real hardware ncclAllReduce does NOT sum in rank order: a G > 1 hardware run is compared
+    with `assert_close_to_simulation`, a tolerance, not with array_equal -- see DESIGN.md section 5.)
+  * exact mode (DSGD block rotation, mfx_dsgd_*): all G ranks on this GPU, rotation = device copy ->
+    bit-identical to the sequential oracle on the block order, at G = 1, 2, 3, 8, with empty blocks,
+    linear and logistic."""
+import numpy as np
+import pytest
+
+from mfrec_amd import synth
+
+pytestmark = pytest.mark.gpu
+HP = (0.01, 0.1, 0.1, 0.007)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _init():
+    from mfrec_amd import _shim as S
+    from mfrec_amd import build as B
+    B.build(verbose=False)
+    S.init(0)
+
+
+def assert_close_to_simulation(got, sim, world):
+    """Tolerance for a HARDWARE G > 1 run of the averaging mode: RCCL's all-reduce adds the G deltas in
+    an order of its own choosing, so each combined element may differ from the rank-ordered sum by a few
+    ulps of the largest delta; after E epochs the difference stays far below 1e-9 relative."""
+    for a, b in zip(got, sim):
+        np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-12 * world)
+
+
+@pytest.mark.parametrize("world,scale", [(2, None), (2, 1.0), (8, None), (8, 1.0), (3, 0.5)])
+def test_averaging_fake_world_equals_simulation(world, scale):
+    from mfrec_amd.sharding import FakeWorldKMF
+    from oracle import sharded_sim as SIM
+    nu, ni, nnz, k, E = 700, 260, 30000, 64, 3
+    idx, r = synth.make_ratings(nu, ni, nnz, seed=31)
+    u0, v0 = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
+    T = FakeWorldKMF(idx, r, nu, ni, k, world)
+    T.set_factors(u0, v0, np.zeros(ni), np.zeros(nu))
+    se = T.train(0, E, *HP, scale=scale)
+    got = T.get_factors()
+    T.close()
+    sim = SIM.simulate(0, world, E, k, *HP, u0, v0, np.zeros(ni), np.zeros(nu), idx, r, scale=scale)
+    for a, b in zip(got, sim):
+        assert np.array_equal(a, b)
+    assert_close_to_simulation(got, sim, world)          # the helper accepts the exact result too
+    assert se.shape == (world, E) and np.all(np.isfinite(se)) and np.all(se > 0)
+
+
+@pytest.mark.parametrize("world,k,mode", [(1, 16, 0), (2, 64, 0), (3, 10, 0), (8, 64, 0), (4, 32, 1)])
+def test_dsgd_fake_world_equals_sequential_oracle_on_block_order(world, k, mode):
+    from mfrec_amd.sharding import DsgdKMF
+    from oracle import dsgd_sim as DS
+    nu, ni, nnz, E = 900, 400, 40000, 3
+    idx, r = synth.make_ratings(nu, ni, nnz, seed=5)
+    u0, v0 = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
+    ib0, ub0 = 0.01 * synth.init_normal(1, ni, 3)[0], 0.01 * synth.init_normal(1, nu, 4)[0]
+    T = DsgdKMF(idx, r, nu, ni, k, -1, world)
+    T.set_factors(u0, v0, ib0, ub0)
+    se = T.train(mode, E, *HP)
+    u, v, ib, ub = np.zeros((k, ni)), np.zeros((k, nu)), np.zeros(ni), np.zeros(nu)
+    T.get_factors(u, v, ib, ub)
+    info = T.info()
+    T.close()
+    su, sv, sib, sub, rm = DS.simulate(mode, E, k, *HP, u0, v0, ib0, ub0, idx, r, T.user_bounds, T.item_bounds)
+    if mode == 0:
+        assert np.array_equal(u, su) and np.array_equal(v, sv)
+        assert np.array_equal(ib, sib) and np.array_equal(ub, sub)
+    else:                                   # logistic: device exp() (1 ulp), as on one GPU
+        np.testing.assert_allclose(u, su, rtol=1e-11, atol=1e-14)
+        np.testing.assert_allclose(v, sv, rtol=1e-11, atol=1e-14)
+    np.testing.assert_allclose(np.sqrt(se / nnz), rm, rtol=1e-12)
+    assert info["nnz_local"] == nnz and info["max_block"] >= info["min_block"] >= 0
+
+
+def test_dsgd_empty_blocks_and_real_single_rank():
+    """Hand-made bounds with an empty user block and an empty item block; and the non-fake path with
+    world = 1 (rank 0): one block, no rotation -- the plain sequential order."""
+    from mfrec_amd.sharding import DsgdKMF
+    from oracle import dsgd_sim as DS
+    from oracle import oracle as O
+    nu, ni, nnz, k, E = 300, 200, 8000, 24, 2
+    idx, r = synth.make_ratings(nu, ni, nnz, seed=9)
+    u0, v0 = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
+    ub = np.array([0, 100, 100, 300], dtype=np.int64)
+    jb = np.array([0, 0, 120, 200], dtype=np.int64)
+    T = DsgdKMF(idx, r, nu, ni, k, -1, 3, user_bounds=ub, item_bounds=jb)
+    T.set_factors(u0, v0, np.zeros(ni), np.zeros(nu))
+    T.train(0, E, *HP)
+    u, v, ib, ubias = np.zeros((k, ni)), np.zeros((k, nu)), np.zeros(ni), np.zeros(nu)
+    T.get_factors(u, v, ib, ubias)
+    T.close()
+    su, sv, sib, sub, _ = DS.simulate(0, E, k, *HP, u0, v0, np.zeros(ni), np.zeros(nu), idx, r, ub, jb)
+    assert np.array_equal(u, su) and np.array_equal(v, sv) and np.array_equal(ib, sib) and np.array_equal(ubias, sub)
+
+    T = DsgdKMF(idx, r, nu, ni, k, 0, 1)
+    T.set_factors(u0, v0, np.zeros(ni), np.zeros(nu))
+    T.train(0, E, *HP)
+    T.get_factors(u, v, ib, ubias)
+    T.close()
+    u2, v2, ib2, ub2 = u0.copy(), v0.copy(), np.zeros(ni), np.zeros(nu)
+    O.train_linear_kernel(E, k, 0.1, HP[0], 0, 0, HP[1], HP[2], HP[3], 0.0, u2, v2, idx, r, ib2, ub2)
+    assert np.array_equal(u, u2) and np.array_equal(v, v2) and np.array_equal(ib, ib2) and np.array_equal(ubias, ub2)
+
+
+def test_dsgd_argument_errors():
+    from mfrec_amd.sharding import DsgdKMF
+    idx, r = synth.make_ratings(50, 40, 500, seed=1)
+    with pytest.raises(ValueError):
+        DsgdKMF(idx, r, 50, 40, 8, -1, 2, user_bounds=np.array([0, 30, 49]), item_bounds=np.array([0, 20, 40]))
+    bad = idx.copy(); bad[3, 1] = 40
+    with pytest.raises(ValueError, match="outside"):
+        DsgdKMF(bad, r, 50, 40, 8, -1, 2)

@@ -1,15 +1,23 @@
 #!/usr/bin/env python3
-"""bench.py -- rating-updates/s of the full-k SGD hot path (train_linear_kernel semantics)
-on BASELINE.json configs[1]: synthetic 100K users x 50K items, 10M ratings, k=64, f64.
+"""bench.py -- rating-updates/s of the full-k SGD hot path (train_linear_kernel semantics).
 
-A "step" is one epoch (one pass of the hot path over all ratings of this rank's shard).
-Inputs (ratings in level-major order, schedule, factors) are resident in HBM when the
-timed region starts.  At N > 1 (one process per GPU, torchrun) every rank holds a cfg-2
-sized user shard (weak scaling) and the item factors are all-reduced over RCCL each epoch.
+N = 1 (default):  BASELINE.json configs[1] -- synthetic 100K users x 50K items, 10M ratings, k=64, f64,
+    shuffled order, exact level schedule.  `value` is that.  The same JSON line carries an `also` block
+    with the other kernels of the path, each with its own roofline and CPU baseline:
+    K1 on the user-major and the balanced order, K2 (Funk per-feature pass) on cfg 2, K3 (ALS) on cfg 4
+    at full size, K1 on cfg 3 whole (the 1-GPU point of the strong-scaling curve below).
+N > 1 (one process per GPU under torch.distributed.run): BASELINE.json configs[2] -- 1M users x 200K
+    items, 100M ratings, k=64 -- STRONG scaling: the same 100M ratings are sharded by user over the N
+    GPUs, item factors replicated, RCCL all-reduce of the item deltas every epoch (north_star's scheme:
+    `value`); the exact block-rotation mode (DSGD, ncclSend/Recv ring) is timed next to it under `also`.
+
+A "step" is one epoch (one pass of the hot path over all ratings of the job).  Inputs (ratings in
+level-major order, schedule, factors) are resident in HBM when the timed region starts.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -21,7 +29,11 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import numpy as np  # noqa: E402
 
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
+F64_MFMA_PEAK = 78.6e12    # FLOP/s, SURVEY 8(d) (datasheet f64 matrix peak)
 LR, KU, KI, KB = 0.01, 0.1, 0.1, 0.007        # kmf.py:51-56 defaults
+FUNK_LR, FUNK_K, FUNK_INIT = 0.001, 0.05, 0.1  # gradient_descent.py:80-84 defaults
+CFG2 = (100000, 50000, 10000000, 64)
+CFG3 = (1000000, 200000, 100000000, 64)
 
 
 def algorithmic_bytes(k, nnz, nu, s=8, rec=16):
@@ -32,28 +44,49 @@ def algorithmic_bytes(k, nnz, nu, s=8, rec=16):
     return b_read, b_total
 
 
-def kernel_label(k, batch, storage):
-    """Name of the k1_level instantiation mfx_sgd.hip's k1_pick selects (KP lanes per rating, features
-    per lane, ratings per wave; 'vec16+wt' = 16-byte accesses per lane with write-through row stores)."""
-    vec = int(os.environ.get("MFX_K1_VEC", "2") or 0)
-    tag = "vec16+wt" if vec == 2 else "vec16"
-    if storage == "f64" and vec and k % 2 == 0 and k > 4 and batch == (16 if k <= 32 else 8 if k <= 128 else 4 if k <= 256 else 2):
-        return "k1_level<%d,%d,%d,linear,%s>" % (8 if k <= 16 else 16 if k <= 32 else 32 if k <= 64 else 64,
-                                                 2 if k <= 128 else 4 if k <= 256 else 8, batch, tag)
-    if storage == "f32" and vec and k % 4 == 0 and k > 8 and batch == (16 if k <= 32 else 8 if k <= 128 else 4 if k <= 256 else 2):
-        return "k1_level<%d,%d,%d,linear,f32,%s>" % (8 if k <= 32 else 16 if k <= 64 else 32 if k <= 128 else 64,
-                                                     4 if k <= 256 else 8, batch, tag)
-    return "k1_level<%d,%d,%d,linear>" % ((8 if k <= 8 else 16 if k <= 16 else 32 if k <= 32 else 64),
-                                          (1 if k <= 64 else 2 if k <= 128 else 4 if k <= 256 else 8), batch)
+def host_info():
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        share = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        share = os.cpu_count()
+    return {"cpu_model": model, "nproc": os.cpu_count(), "cpu_share": share}
 
 
-def cpu_baseline(idx, r, nu, ni, k, budget_s=12.0):
-    """The reference CPU path timed on this host, 1 thread (the reference is single-threaded:
-    GIL held, no OpenMP), on a bounded prefix of the same workload with the full-size factor
-    arrays allocated.  kind = "reference": the reference's own Cython kernel
-    (train_linear_kernel, kmf_train.pyx:195-277) built into oracle/_ref by oracle/build_ref.py,
-    when that binary travelled with the snapshot; otherwise kind = "port": the plain-C
-    restatement oracle/mfx_oracle.c (bit-identical output)."""
+def load_reference():
+    """The reference's own Cython kernels (oracle/_ref, built where /root/reference exists and shipped
+    as binaries) or None."""
+    try:
+        from oracle import build_ref
+        return build_ref.load()
+    except Exception:
+        return None
+
+
+def timed_prefix(fn, n_total, budget_s, n_probe=200000):
+    """fn(n) processes the first n ratings; size n so that the run takes about budget_s."""
+    n = min(n_total, n_probe)
+    t0 = time.perf_counter(); fn(n); rate = n / (time.perf_counter() - t0)
+    n2 = int(min(n_total, max(n, rate * budget_s)))
+    t0 = time.perf_counter(); fn(n2); dt = time.perf_counter() - t0
+    return n2 / dt, n2, dt
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baselines (test infrastructure used as the measured-beside baseline; never in the product path)
+# ------------------------------------------------------------------------------------------------
+def cpu_baseline_k1(idx, r, nu, ni, k, budget_s=10.0, replicas=True):
+    """train_linear_kernel (kmf_train.pyx:195-277), 1 thread (the reference is single-threaded: GIL held,
+    no OpenMP), on a bounded prefix of the same workload with the full-size factor arrays allocated.
+    kind "reference" = the reference's own compiled Cython kernel when oracle/_ref travelled with the
+    snapshot, else "port" = oracle/mfx_oracle.c (bit-identical output)."""
     from oracle import oracle as O
     from mfrec_amd import synth
     u, v = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
@@ -62,42 +95,19 @@ def cpu_baseline(idx, r, nu, ni, k, budget_s=12.0):
     def port(n):
         O.train_linear_kernel(1, k, 0.1, LR, 0, 0, KU, KI, KB, 0.0, u, v, idx[:n], r[:n], ib, ub)
 
+    ref = load_reference()
     ref_fn = None
-    try:
-        from oracle import build_ref
-        ref = build_ref.load()
-        if ref is not None:
-            def ref_fn(n):
-                ref["kmf_train"].train_linear_kernel(1, k, 0.1, LR, 0.0, 0.0, KU, KI, KB, 0.0, u, v,
-                                                     idx[:n], r[:n], ib, ub, 1, 1, 0)
-    except Exception:
-        ref_fn = None
-
-    def timed(fn, budget):
-        n = min(idx.shape[0], 200000)
-        t0 = time.perf_counter(); fn(n); rate = n / (time.perf_counter() - t0)
-        n2 = int(min(idx.shape[0], max(n, rate * budget)))
-        t0 = time.perf_counter(); fn(n2); dt = time.perf_counter() - t0
-        return n2 / dt, n2, dt
-
-    def host_info():
-        model = "unknown"
-        try:
-            for ln in open("/proc/cpuinfo"):
-                if ln.startswith("model name"):
-                    model = ln.split(":", 1)[1].strip()
-                    break
-        except OSError:
-            pass
-        return {"cpu_model": model, "nproc": os.cpu_count()}
-
-    p_rate, p_n, p_dt = timed(port, budget_s if ref_fn is None else 5.0)
+    if ref is not None:
+        def ref_fn(n):
+            ref["kmf_train"].train_linear_kernel(1, k, 0.1, LR, 0.0, 0.0, KU, KI, KB, 0.0, u, v,
+                                                 idx[:n], r[:n], ib, ub, 1, 1, 0)
+    p_rate, p_n, p_dt = timed_prefix(port, idx.shape[0], budget_s if ref_fn is None else 4.0)
     out = {"value": p_rate, "unit": "rating-updates/s", "cores": 1, "kind": "port", "host": host_info(),
-           "sample": "first %d of %d ratings (%s), 1 epoch, full-size factors, "
-                     "oracle/mfx_oracle.c single thread, %.1f s" % (p_n, idx.shape[0], "bench order", p_dt)}
+           "sample": "first %d of %d ratings (bench order), 1 epoch, full-size factors, "
+                     "oracle/mfx_oracle.c single thread, %.1f s" % (p_n, idx.shape[0], p_dt)}
     if ref_fn is not None:
         try:
-            r_rate, r_n, r_dt = timed(ref_fn, budget_s)
+            r_rate, r_n, r_dt = timed_prefix(ref_fn, idx.shape[0], budget_s)
             out = {"value": r_rate, "unit": "rating-updates/s", "cores": 1, "kind": "reference",
                    "host": host_info(),
                    "sample": "first %d of %d ratings (bench order), 1 epoch, full-size factors, the "
@@ -106,7 +116,231 @@ def cpu_baseline(idx, r, nu, ni, k, budget_s=12.0):
                    "port_value": p_rate}
         except Exception as e:      # never let the reference leg break the bench line
             out["reference_error"] = repr(e)
+    if replicas:
+        try:
+            out["replicas"] = cpu_replica_aggregate(nu, ni, k)
+        except Exception as e:
+            out["replicas"] = {"error": repr(e)}
     return out
+
+
+def cpu_replica_aggregate(nu, ni, k, n_ratings=1500000):
+    """SURVEY 8(d) "N-process replica aggregate": N independent single-thread replicas of the same kernel
+    (one per CPU this job may use, at most 16), each on its own copy of the factors and the first
+    n_ratings ratings, started together; aggregate = N * n_ratings / slowest replica.  A generous upper
+    bound for "the reference on all host cores" (the reference itself has no parallel path)."""
+    try:
+        share = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        share = os.cpu_count() or 1
+    n = max(1, min(16, share))
+    start = time.time() + 12.0
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-replica", str(n_ratings),
+                               "--users", str(nu), "--items", str(ni), "--k", str(k), "--start-at", repr(start)],
+                              stdout=subprocess.PIPE, env=dict(os.environ, OMP_NUM_THREADS="1"))
+             for _ in range(n)]
+    res = []
+    for p in procs:
+        o, _ = p.communicate(timeout=180)
+        res.append(json.loads(o.decode().strip().splitlines()[-1]))
+    slowest = max(x["seconds"] for x in res)
+    late = max(x["late_s"] for x in res)
+    return {"value": n * n_ratings / slowest, "unit": "rating-updates/s", "processes": n,
+            "kind": res[0]["kind"], "ratings_per_replica": n_ratings, "slowest_replica_s": slowest,
+            "start_skew_s": late,
+            "note": "N independent single-thread replicas run side by side; not a parallel algorithm"}
+
+
+def cpu_replica_main(a):
+    """Child of cpu_replica_aggregate: one replica."""
+    from mfrec_amd import synth
+    from oracle import oracle as O
+    nu, ni, k, n = a.users, a.items, a.k, a.cpu_replica
+    idx, r = synth.make_ratings(nu, ni, n, workers=1)
+    u, v = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
+    ib, ub = np.zeros(ni), np.zeros(nu)
+    ref = load_reference()
+    late = max(0.0, time.time() - a.start_at)
+    while time.time() < a.start_at:
+        time.sleep(0.001)
+    t0 = time.perf_counter()
+    if ref is not None:
+        ref["kmf_train"].train_linear_kernel(1, k, 0.1, LR, 0.0, 0.0, KU, KI, KB, 0.0, u, v, idx, r, ib, ub, 1, 1, 0)
+    else:
+        O.train_linear_kernel(1, k, 0.1, LR, 0, 0, KU, KI, KB, 0.0, u, v, idx, r, ib, ub)
+    print(json.dumps({"seconds": time.perf_counter() - t0, "late_s": late,
+                      "kind": "reference" if ref is not None else "port"}))
+
+
+def cpu_baseline_funk(idx, r, nu, ni, budget_s=8.0):
+    """estimator_loop_without_bias (gd_estimator.pyx:691-779): k = 2 features x 1 epoch each (+ the
+    cache-commit passes) on a bounded prefix, 1 thread."""
+    from oracle import oracle as O
+    from mfrec_amd import synth
+    kk = 2
+    ref = load_reference()
+
+    def run(n):
+        u, v = synth.init_const(kk, ni, FUNK_INIT), synth.init_const(kk, nu, FUNK_INIT)
+        if ref is not None:
+            ref["gd_estimator"].estimator_loop_without_bias(1, 1, 1e9, kk, FUNK_INIT, FUNK_LR, FUNK_K, u, v,
+                                                            idx[:n], r[:n], nu, ni, 0)
+        else:
+            O.estimator_loop_without_bias(1, 1, 1e9, kk, FUNK_INIT, FUNK_LR, FUNK_K, u, v, idx[:n], r[:n], nu, ni)
+
+    rate, n, dt = timed_prefix(run, idx.shape[0], budget_s / 2.0, n_probe=500000)
+    return {"value": rate * kk, "unit": "scalar-updates/s", "cores": 1,
+            "kind": "reference" if ref is not None else "port",
+            "sample": "first %d of %d ratings, 2 features x 1 epoch (+ commit passes), %s, single thread, %.1f s"
+                      % (n, idx.shape[0], "the reference's Cython estimator_loop_without_bias (oracle/_ref)"
+                         if ref is not None else "oracle/mfx_oracle.c", dt)}
+
+
+def als_flops(k, nz, nu, ni):
+    """SURVEY 8(d) FLOP model of one ALS epoch."""
+    return 2 * (k * (k + 1) * nz) + 2 * k * k * (nu + ni) + (nu + ni) * (k ** 3 / 3 + 2 * k * k) + 4 * k * nz
+
+
+def cpu_baseline_als(k):
+    """als_wrmf (als_implicit.pyx:211-352) on the cfg-4 problem divided by 100 in every dimension (10K x 2K,
+    1M ratings, same k), 1 epoch, 1 thread; scaled to cfg 4 by the FLOP model of SURVEY 8(d)."""
+    import scipy.sparse as sp
+    from oracle import oracle as O
+    from mfrec_amd import synth
+    from mfrec_amd.lib.datasets import create_bool_sparse_col, create_bool_sparse_row
+    nu, ni, nnz = 10000, 2000, 1000000
+    idx, _ = synth.make_ratings(nu, ni, nnz)
+    M = sp.csr_matrix((np.ones(nnz, dtype=np.int8), (idx[:, 0], idx[:, 1])), shape=(nu, ni))
+    M.sum_duplicates()
+    nz = int(M.nnz)
+    views = create_bool_sparse_row(M) + create_bool_sparse_col(M)
+    rs = np.random.RandomState(0)
+    u, v = rs.normal(0, 0.1, (k, ni)), rs.normal(0, 0.1, (k, nu))
+    ref = load_reference()
+    t0 = time.perf_counter()
+    if ref is not None:
+        m, m_inv = np.zeros((k, k)), np.zeros((k, k))
+        ref["als_implicit"].als_wrmf(1, k, u, v, m, m_inv, *views, nu, ni, 1, 0.015, 0)
+    else:
+        O.als_wrmf(1, k, u, v, None, None, *views, nu, ni, 1, 0.015)
+    dt = time.perf_counter() - t0
+    F = als_flops(k, nz, nu, ni)
+    return {"value": (nu + ni) / dt, "unit": "rows/s", "cores": 1, "kind": "reference" if ref is not None else "port",
+            "model_gflops": F / dt / 1e9, "seconds": dt,
+            "sample": "cfg 4 / 100: %d x %d, %d distinct ratings, k=%d, 1 epoch, %s, single thread"
+                      % (nu, ni, nz, k, "the reference's Cython als_wrmf (oracle/_ref)" if ref is not None
+                         else "oracle/mfx_oracle.c")}
+
+
+# ------------------------------------------------------------------------------------------------
+# GPU measurements
+# ------------------------------------------------------------------------------------------------
+def k1_measure(plan, nnz, nu, k, steps, warmup, run, label_plan=None):
+    """Timed region of a full-k SGD plan: HIP events on the library stream + roofline of k1_level."""
+    from mfrec_amd.plan import Timer, LINEAR
+    info = plan.info()
+    run(max(warmup, 0))
+    with Timer() as tm:
+        run(steps)
+    launches = info["launches_per_epoch"]
+    b_read, b_total = algorithmic_bytes(k, nnz, nu)
+    avg_launch_s = tm.ms * 1e-3 / (steps * launches)
+    achieved = (b_read * nnz / launches) / avg_launch_s
+    return {"device_ms_per_step": tm.ms / steps, "value": nnz * steps / (tm.ms * 1e-3),
+            "levels": info["n_levels"], "launches_per_epoch": launches,
+            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK, "traffic": None,
+                         "algorithmic_bytes_per_launch": b_read * nnz / launches,
+                         "kernel": (label_plan or plan).kernel_name(LINEAR),
+                         "bytes_per_update_read": b_read, "bytes_per_update_total": b_total,
+                         "avg_launch_us": avg_launch_s * 1e6, "launches_per_epoch": launches,
+                         "frac_total_bytes": (b_total * nnz / launches) / avg_launch_s / HBM_PEAK},
+            "schedule_build_ms": info["schedule_us"] / 1e3}
+
+
+def also_k1_order(idx, r, nu, ni, k, u0, v0, steps, warmup, order):
+    from mfrec_amd import synth
+    from mfrec_amd.plan import SgdPlan, LINEAR
+    if order == "user-major":
+        i2, r2 = synth.user_major(idx, r)
+    else:
+        from mfrec_amd.lib.datasets import balanced_order_gpu
+        perm, _ = balanced_order_gpu(idx, nu, ni)
+        i2, r2 = np.ascontiguousarray(idx[perm]), np.ascontiguousarray(r[perm])
+    with SgdPlan(i2, r2, nu, ni, k) as p:
+        p.set_factors(u0, v0, np.zeros(ni), np.zeros(nu))
+        m = k1_measure(p, idx.shape[0], nu, k, steps, warmup,
+                       lambda n: p.run_kmf(LINEAR, n, LR, KU, KI, KB, want_rmse=False))
+    m["unit"] = "rating-updates/s"
+    m["workload"] = "cfg2 shape, %s order, exact level schedule, full-k SGD" % order
+    return m
+
+
+def also_funk(idx, r, nu, ni, k, order, epochs_per_feature=2):
+    """K2: estimator_loop_without_bias semantics, k features x epochs_per_feature epochs (the stopping rule
+    is disabled with min_improvement = 1e9) + the cache-commit passes."""
+    from mfrec_amd import synth
+    from mfrec_amd.plan import SgdPlan, Timer
+    if order == "balanced":
+        from mfrec_amd.lib.datasets import balanced_order_gpu
+        perm, _ = balanced_order_gpu(idx, nu, ni)
+        idx, r = np.ascontiguousarray(idx[perm]), np.ascontiguousarray(r[perm])
+    nnz = idx.shape[0]
+    with SgdPlan(idx, r, nu, ni, k) as p:
+        p.set_factors(synth.init_const(k, ni, FUNK_INIT), synth.init_const(k, nu, FUNK_INIT))
+        p.run_funk(1, 1e9, FUNK_INIT, FUNK_LR, FUNK_K, epoch_cap=1)        # warm-up: k passes, graph capture
+        p.set_factors(synth.init_const(k, ni, FUNK_INIT), synth.init_const(k, nu, FUNK_INIT))
+        with Timer() as tm:
+            hist = p.run_funk(epochs_per_feature, 1e9, FUNK_INIT, FUNK_LR, FUNK_K)
+        info = p.info()
+    n = len(hist)
+    rate = nnz * n / (tm.ms * 1e-3)
+    launches = info["funk_launches_per_epoch"]
+    ms_pass = tm.ms / n
+    # algorithmic bytes (SURVEY 8(d)): 24 B per scalar update (16-B record + 8-B cache word)
+    return {"value": rate, "unit": "scalar-updates/s", "row_equivalents_per_s": rate / k,
+            "feature_epochs": n, "ms_per_pass": ms_pass, "levels": info["n_levels"],
+            "launches_per_pass": launches, "rmse_online_last": float(hist[-1]),
+            "workload": "cfg2 shape, %s order, k=%d features x %d epochs each + cache-commit passes "
+                        "(estimator_loop_without_bias), exact level schedule" % (order, k, epochs_per_feature),
+            "roofline": {"bound": "hbm", "achieved": rate * 24 / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": rate * 24 / HBM_PEAK, "bytes_per_scalar_update": 24, "kernel": "k2_level",
+                         "avg_launch_us": ms_pass * 1e3 / max(launches, 1), "traffic": None}}
+
+
+def also_als(idx3, nu, ni, k):
+    """K3: als_wrmf on BASELINE cfg 4 at full size (1M x 200K, 100M ratings -> distinct cells, k=128)."""
+    import scipy.sparse as sp
+    from mfrec_amd import _shim as S
+    from mfrec_amd.lib.als_implicit import als_wrmf
+    from mfrec_amd.lib.datasets import create_bool_sparse_col, create_bool_sparse_row
+    nnz = idx3.shape[0]
+    M = sp.csr_matrix((np.ones(nnz, dtype=np.int8), (idx3[:, 0], idx3[:, 1])), shape=(nu, ni))
+    M.sum_duplicates()
+    nz = int(M.nnz)
+    views = create_bool_sparse_row(M) + create_bool_sparse_col(M)
+    del M
+    rs = np.random.RandomState(0)
+    u, v = rs.normal(0, 0.1, (k, ni)), rs.normal(0, 0.1, (k, nu))
+    epochs = 2
+    als_wrmf(1, k, u, v, None, None, *views, nu, ni)            # warm-up incl. transfers
+    als_wrmf(epochs, k, u, v, None, None, *views, nu, ni)
+    dev_s = S.lib().mfx_last_compute_ms() * 1e-3 / epochs
+    F = als_flops(k, nz, nu, ni)
+    return {"value": (nu + ni) / dev_s, "unit": "rows/s", "seconds_per_epoch": dev_s, "epochs_timed": epochs,
+            "model_tflop_per_epoch": F / 1e12, "finite": bool(np.isfinite(u).all() and np.isfinite(v).all()),
+            "workload": "cfg4: %dM x %dK, %d distinct ratings, k=%d, ALS/WRMF (als_wrmf), device time of the "
+                        "epochs (HIP events), factors and CSR views resident" % (nu // 1000000, ni // 1000, nz, k),
+            "roofline": {"bound": "mfma", "achieved": F / dev_s / 1e12, "peak": F64_MFMA_PEAK / 1e12,
+                         "unit": "TFLOP/s", "frac": F / dev_s / F64_MFMA_PEAK, "kernel": "k_als_rows3",
+                         "traffic": None, "flop_model": "SURVEY 8(d)"}}
+
+
+def fail_line(rank, world, what, err):
+    """One greppable line per failing rank (RCCL's own text is inside the library's error message; with
+    NCCL_DEBUG=WARN, set below for N > 1, RCCL also prints its warnings to stderr)."""
+    sys.stderr.write("[bench rank %d/%d] %s FAILED: %s\n" % (rank, world, what, err))
+    sys.stderr.flush()
 
 
 def main():
@@ -114,18 +348,27 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--users", type=int, default=100000, help="users per GPU")
-    ap.add_argument("--items", type=int, default=50000)
-    ap.add_argument("--nnz", type=int, default=10000000, help="ratings per GPU")
+    ap.add_argument("--workload", choices=["auto", "cfg2", "cfg3"], default="auto",
+                    help="auto = cfg2 at N=1 (the config the metric is quoted on), cfg3 user-sharded at N>1")
+    ap.add_argument("--users", type=int, default=None)
+    ap.add_argument("--items", type=int, default=None)
+    ap.add_argument("--nnz", type=int, default=None, help="ratings of the whole job")
     ap.add_argument("--k", type=int, default=64)
     ap.add_argument("--order", choices=["shuffled", "user-major", "balanced"], default="shuffled")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N>1: strong = the job's ratings are divided among the GPUs (default); weak = every "
+                         "GPU gets a job-sized user shard of its own")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
+    ap.add_argument("--no-also", action="store_true", help="skip the `also` block (secondary kernels)")
     ap.add_argument("--no-extra", action="store_true", help=argparse.SUPPRESS)   # accepted, no-op
-    ap.add_argument("--extra-balanced", action="store_true",
-                    help="also time the same kernel on a balanced input order (reported under 'also')")
     ap.add_argument("--storage", choices=["f64", "f32"], default="f64",
                     help="f32 = NOT the reference's precision: rows stored as f32 (measured option only)")
+    ap.add_argument("--cpu-replica", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--start-at", type=float, default=0.0, help=argparse.SUPPRESS)
     a = ap.parse_args()
+    if a.cpu_replica:
+        a.users = a.users or CFG2[0]; a.items = a.items or CFG2[1]
+        return cpu_replica_main(a)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -134,11 +377,18 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("--gpus %d needs torchrun (one process per GPU)" % a.gpus)
         a.gpus = world
+    if world > 1:
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
+
+    cfg = CFG2 if (a.workload == "cfg2" or (a.workload == "auto" and world == 1)) else CFG3
+    nu, ni, nnz = a.users or cfg[0], a.items or cfg[1], a.nnz or cfg[2]
+    k = a.k
+    cfg_name = {CFG2: "cfg2", CFG3: "cfg3"}.get((nu, ni, nnz, k), "custom")
 
     from mfrec_amd import _shim as S
     from mfrec_amd import build as B
     from mfrec_amd import synth
-    from mfrec_amd.plan import SgdPlan, Timer, LINEAR
+    from mfrec_amd.plan import SgdPlan, LINEAR
     uid = None
     if world > 1:
         # torch.distributed.run is only the launcher: no torch import in the ranks (see
@@ -150,37 +400,66 @@ def main():
         if rank != 0:
             uid = rendezvous.exchange_unique_id(rank, world, None)
     B.build(verbose=False)
-    # MFX_BENCH_DEVICE: rehearsal hook (several ranks on one GPU); the driver never sets it
-    S.init(int(os.environ.get("MFX_BENCH_DEVICE", local)))
+    try:
+        # MFX_BENCH_DEVICE: rehearsal hook (several ranks on one GPU); the driver never sets it
+        S.init(int(os.environ.get("MFX_BENCH_DEVICE", local)))
+        if world > 1:
+            def make_id():
+                idbuf = C.create_string_buffer(S.UNIQUE_ID_BYTES)
+                S.check(S.lib().mfx_comm_unique_id(idbuf))
+                return idbuf.raw
 
-    if world > 1:
-        def make_id():
-            idbuf = C.create_string_buffer(S.UNIQUE_ID_BYTES)
-            S.check(S.lib().mfx_comm_unique_id(idbuf))
-            return idbuf.raw
+            if rank == 0:
+                uid = rendezvous.exchange_unique_id(rank, world, make_id)
+            S.check(S.lib().mfx_comm_init(rank, world, uid))
+    except Exception as e:
+        fail_line(rank, world, "device / RCCL communicator init", e)
+        raise
 
-        if rank == 0:
-            uid = rendezvous.exchange_unique_id(rank, world, make_id)
-        S.check(S.lib().mfx_comm_init(rank, world, uid))
-
-    nu, ni, nnz, k = a.users, a.items, a.nnz, a.k
-    # this rank's shard: its own users (local ids 0..nu-1), the shared item catalogue
-    idx, r = synth.make_ratings(nu, ni, nnz, t0=rank * nnz, user_base=0)
+    # ---- data: the whole job's ratings are a pure function of the counter, so every rank generates them
+    # and keeps its own users (strong scaling: same 100M ratings at every N) -------------------------
+    if world > 1 and a.scaling == "weak":
+        idx, r = synth.make_ratings(nu, ni, nnz, t0=rank * nnz, user_base=0)
+        my_idx, my_r, nu_local, job_nnz = idx, r, nu, world * nnz
+        bounds = None
+    else:
+        idx, r = synth.make_ratings(nu, ni, nnz)
+        job_nnz = nnz
+        if world > 1:
+            from mfrec_amd import sharding as SH
+            bounds = SH.user_blocks(idx, nu, world)
+            my_idx, my_r, _, nu_local = SH.shard(idx, r, bounds, rank)
+        else:
+            bounds = None
+            my_idx, my_r, nu_local = idx, r, nu
     if a.order == "user-major":
-        idx, r = synth.user_major(idx, r)
+        my_idx, my_r = synth.user_major(my_idx, my_r)
     elif a.order == "balanced":
         from mfrec_amd.lib.datasets import balanced_order_gpu
-        perm, _ = balanced_order_gpu(idx, nu, ni)          # recolours the (already shuffled) synthetic order
-        idx, r = np.ascontiguousarray(idx[perm]), np.ascontiguousarray(r[perm])
+        perm, _ = balanced_order_gpu(my_idx, nu_local, ni)     # recolours the (already shuffled) synthetic order
+        my_idx, my_r = np.ascontiguousarray(my_idx[perm]), np.ascontiguousarray(my_r[perm])
     u0 = synth.init_normal(k, ni, synth.SEED_INIT)
-    v0 = synth.init_normal(k, nu, synth.SEED_INIT + 1 + rank)
-    plan = SgdPlan(idx, r, nu, ni, k, storage=a.storage)
-    plan.set_factors(u0, v0, np.zeros(ni), np.zeros(nu))
+    v0_full = synth.init_normal(k, nu, synth.SEED_INIT + 1) if (world == 1 or a.scaling == "strong") else None
+    if world > 1 and a.scaling == "strong":
+        lo = int(bounds[rank])
+        v0 = np.ascontiguousarray(v0_full[:, lo:lo + nu_local])
+    elif world > 1:
+        v0 = synth.init_normal(k, nu, synth.SEED_INIT + 1 + rank)
+    else:
+        v0 = v0_full
+    my_nnz = my_r.shape[0]
+    plan = SgdPlan(my_idx, my_r, max(nu_local, 1), ni, k, storage=a.storage)
+    plan.set_factors(u0, v0, np.zeros(ni), np.zeros(max(nu_local, 1)))
     info = plan.info()
+    kernel_name = plan.kernel_name(LINEAR)          # the instantiation the library launches, from the library
+    last_rmse = {}
 
     def run(n):
+        if n <= 0:
+            return
         if world > 1:
-            plan.run_kmf_sharded(LINEAR, n, LR, KU, KI, KB, 1.0 / world)
+            rm, se = plan.run_kmf_sharded(LINEAR, n, LR, KU, KI, KB, 1.0 / world)
+            last_rmse["se_local"] = float(se[-1])
         else:
             plan.run_kmf(LINEAR, n, LR, KU, KI, KB, want_rmse=False)
 
@@ -189,30 +468,41 @@ def main():
         if world > 1:
             S.check(S.lib().mfx_comm_barrier())       # RCCL all-reduce + sync = cross-rank barrier
 
-    run(max(a.warmup, 0))
-    barrier()
-    t0 = time.perf_counter()
-    with Timer() as tm:
-        run(a.steps)
-    barrier()
-    wall = time.perf_counter() - t0
-    if world > 1:                                     # MAX over ranks
+    def max_over_ranks(x):
+        if world == 1:
+            return x
         import ctypes as C
-        w = C.c_double(wall)
+        w = C.c_double(x)
         S.check(S.lib().mfx_comm_allreduce_max(C.byref(w)))
-        wall = w.value
+        return w.value
 
-    # Dominant kernel = k1_level (one launch per dependency level).  Its average launch
-    # duration is taken from the HIP events that bracket the timed region on the library's
-    # stream: device time of the K epochs / (K * launches per epoch).  The epoch graph holds
-    # nothing else but two tiny reduction kernels, so this is an upper bound of the kernel's
-    # own duration (inter-kernel gaps included) and agrees with rocprofv3's average.
+    try:
+        run(max(a.warmup, 0))
+        barrier()
+        S.check(S.lib().mfx_timer_start())
+        t0 = time.perf_counter()
+        run(a.steps)
+        barrier()
+        wall = time.perf_counter() - t0
+        import ctypes as C
+        ms = C.c_double(0.0)
+        S.check(S.lib().mfx_timer_stop(C.byref(ms)))
+        dev_ms = ms.value
+        wall = max_over_ranks(wall)
+    except Exception as e:
+        fail_line(rank, world, "timed region", e)
+        raise
+
+    # Dominant kernel = k1_level (one launch per dependency level).  Its average launch duration is taken
+    # from the HIP events that bracket the timed region on the library's stream: device time of the K
+    # epochs / (K * launches per epoch).  The epoch graph holds nothing else but two tiny reduction
+    # kernels (and, at N > 1, the delta / all-reduce / combine step), so this is an upper bound of the
+    # kernel's own duration and agrees with rocprofv3's average (profiles/).
     launches = info["launches_per_epoch"]
     b_read, b_total = algorithmic_bytes(k, nnz, nu)
-    avg_launch_s = tm.ms * 1e-3 / (a.steps * launches)
-    achieved = (b_read * nnz / launches) / avg_launch_s
-    # cross-check: one instrumented epoch with an event pair around every launch
-    kern_ms, _ = plan.profile_kmf(LINEAR, LR, KU, KI, KB)
+    avg_launch_s = dev_ms * 1e-3 / (a.steps * launches)
+    achieved = (b_read * my_nnz / launches) / avg_launch_s
+    kern_ms, _ = plan.profile_kmf(LINEAR, LR, KU, KI, KB)      # cross-check: an event pair around every launch
 
     # HBM traffic per launch: from the committed rocprofv3 PMC summary of this same command
     # (profiles/rNN_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes)
@@ -220,62 +510,145 @@ def main():
     try:
         import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-        if cands and a.order == "shuffled" and a.storage == "f64" and (nu, ni, nnz, k) == (100000, 50000, 10000000, 64):
+        if cands and world == 1 and a.order == "shuffled" and a.storage == "f64" and (nu, ni, nnz, k) == CFG2:
             tj = json.load(open(cands[-1]))
             traffic = (tj["read_bytes_per_rating"] + tj["write_bytes_per_rating"]) * nnz / launches
             traffic_src = os.path.basename(cands[-1])
     except Exception:
         traffic = None
 
+    also = {}
+    # ---- N > 1: the exact block-rotation mode on the same ratings, timed the same way ---------------
+    if world > 1 and a.scaling == "strong" and not a.no_also:
+        try:
+            from mfrec_amd import sharding as SH
+            plan.close()
+            plan = None
+            d = SH.DsgdKMF(idx, r, nu, ni, k, rank, world, user_bounds=bounds)
+            d.set_factors(u0, v0, np.zeros(ni), np.zeros(max(nu_local, 1)))
+            d.train(LINEAR, max(a.warmup, 1), LR, KU, KI, KB)
+            barrier()
+            t0 = time.perf_counter()
+            se = d.train(LINEAR, a.steps, LR, KU, KI, KB)
+            barrier()
+            w2 = max_over_ranks(time.perf_counter() - t0)
+            di = d.info()
+            also["dsgd_exact"] = {"value": job_nnz * a.steps / w2, "unit": "rating-updates/s",
+                                  "ms_per_step": w2 * 1e3 / a.steps, "rmse_online_last": float(np.sqrt(se[-1] / job_nnz)),
+                                  "launches_per_epoch_per_gpu": di["launches_per_epoch"],
+                                  "workload": "%s: the same ratings, %d x %d user/item blocks, block rotation over a "
+                                              "ncclSend/Recv ring; bit-identical to the sequential loop on the block "
+                                              "order (tests/test_gpu_fakeworld.py)" % (cfg_name, world, world)}
+            d.close()
+        except Exception as e:
+            fail_line(rank, world, "dsgd leg", e)
+            also["dsgd_exact"] = {"error": repr(e)}
+
     if rank == 0:
-        value = world * nnz * a.steps / wall
+        value = job_nnz * a.steps / wall
         line = {
             "metric": "rating-updates/s per epoch at k=%d" % k, "value": value,
             "unit": "rating-updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": wall * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": wall * 1e3 / a.steps, "higher_is_better": True,
+            "scaling": "weak" if (world == 1 or a.scaling == "weak") else "strong",
             "vs_baseline": None,
             "dtype": "f64" if a.storage == "f64" else "f64 arithmetic on f32-stored rows (NOT the reference precision)",
             "data": "synthetic",
-            "config": {"workload": "%s: synthetic %dK users x %dK items, %dM ratings per GPU, "
-                                   "k=%d, full-k SGD (train_linear_kernel), %s order, "
-                                   "exact level schedule" % (
-                                       "cfg2" if (nu, ni, nnz, k) == (100000, 50000, 10000000, 64) else "custom",
-                                       nu // 1000, ni // 1000, nnz // 1000000, k, a.order),
-                       "users_per_gpu": nu, "items": ni, "ratings_per_gpu": nnz, "k": k,
-                       "levels": info["n_levels"], "launches_per_epoch": info["launches_per_epoch"],
+            "config": {"workload": "%s: synthetic %dK users x %dK items, %dM ratings%s, k=%d, full-k SGD "
+                                   "(train_linear_kernel), %s order, exact level schedule%s" % (
+                                       cfg_name, nu // 1000, ni // 1000, nnz // 1000000,
+                                       " per GPU" if (world > 1 and a.scaling == "weak") else "", k, a.order,
+                                       "" if world == 1 else
+                                       ", users sharded over %d GPUs, item factors replicated, RCCL all-reduce of the "
+                                       "item deltas every epoch (parameter averaging, scale 1/%d)" % (world, world)),
+                       "users": nu, "items": ni, "ratings": job_nnz, "ratings_this_gpu": my_nnz, "k": k,
+                       "levels": info["n_levels"], "launches_per_epoch": launches,
                        "sharding": "users x%d, item-delta all-reduce (RCCL)" % world if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
-                         "traffic_unit": "bytes per launch (PMC, %s)" % traffic_src,
-                         "algorithmic_bytes_per_launch": b_read * nnz / launches,
-                         "kernel": kernel_label(k, info["ratings_per_wave"], a.storage),
+                         "algorithmic_bytes_per_launch": b_read * my_nnz / launches,
+                         "kernel": kernel_name,
                          "bytes_per_update_read": b_read, "bytes_per_update_total": b_total,
                          "avg_launch_us": avg_launch_s * 1e6, "launches_per_epoch": launches,
                          "event_pair_avg_launch_us": kern_ms * 1e3 / launches,
-                         "frac_total_bytes": (b_total * nnz / launches) / avg_launch_s / HBM_PEAK},
-            "device_ms_per_step": tm.ms / a.steps,
+                         "frac_total_bytes": (b_total * my_nnz / launches) / avg_launch_s / HBM_PEAK},
+            "device_ms_per_step": dev_ms / a.steps,
             "schedule_build_ms": info["schedule_us"] / 1e3,
         }
-        if world == 1 and a.order == "shuffled" and a.storage == "f64" and a.extra_balanced:
-            # secondary, clearly labelled data point (not `value`): the same exact kernel on a
-            # balanced input order (fewest dependency levels)
+        if traffic is not None:
+            line["roofline"]["traffic_unit"] = "bytes per launch (PMC, %s)" % traffic_src
+        if world > 1 and "se_local" in last_rmse:
+            line["rmse_online_last_rank0_shard"] = float(np.sqrt(last_rmse["se_local"] / max(my_nnz, 1)))
+
+    # ---- N = 1: the other kernels of the path (secondary, clearly labelled; never `value`) -----------
+    if rank == 0 and world == 1 and not a.no_also and a.storage == "f64" and (nu, ni, nnz, k) == CFG2 \
+            and a.order == "shuffled":
+        v0n = v0
+
+        def leg(name, fn):
+            t = time.perf_counter()
             try:
-                from mfrec_amd.lib.datasets import balanced_order_gpu
-                perm, rounds = balanced_order_gpu(idx, nu, ni)
-                with SgdPlan(np.ascontiguousarray(idx[perm]), np.ascontiguousarray(r[perm]), nu, ni, k) as p2:
-                    p2.set_factors(u0, v0, np.zeros(ni), np.zeros(nu))
-                    p2.run_kmf(LINEAR, 1, LR, KU, KI, KB, want_rmse=False)
-                    with Timer() as t2:
-                        p2.run_kmf(LINEAR, a.steps, LR, KU, KI, KB, want_rmse=False)
-                line["also"] = {"balanced_input_order": {"value": nnz * a.steps / (t2.ms * 1e-3),
-                                                         "unit": "rating-updates/s", "levels": rounds,
-                                                         "ms_per_step": t2.ms / a.steps}}
-            except Exception as e:                  # never let the extra break the bench line
-                line["also"] = {"balanced_input_order_error": repr(e)}
+                also[name] = fn()
+                also[name]["leg_wall_s"] = round(time.perf_counter() - t, 1)
+            except Exception as e:                      # never let a secondary leg break the bench line
+                also[name] = {"error": repr(e)}
+
+        plan.close()
+        plan = None
+        leg("k1_user_major", lambda: also_k1_order(idx, r, nu, ni, k, u0, v0n, a.steps, a.warmup, "user-major"))
+        leg("k1_balanced", lambda: also_k1_order(idx, r, nu, ni, k, u0, v0n, a.steps, a.warmup, "balanced"))
+        leg("k2_funk", lambda: also_funk(idx, r, nu, ni, k, "shuffled"))
+        leg("k2_funk_balanced", lambda: also_funk(idx, r, nu, ni, k, "balanced"))
+        if not a.no_cpu and "error" not in also["k2_funk"]:
+            try:
+                also["k2_funk"]["cpu_baseline"] = cpu_baseline_funk(idx, r, nu, ni)
+            except Exception as e:
+                also["k2_funk"]["cpu_baseline"] = {"error": repr(e)}
+
+        def cfg3_and_als():
+            nu3, ni3, nnz3, k3 = CFG3
+            idx3, r3 = synth.make_ratings(nu3, ni3, nnz3)
+            out = {}
+            with SgdPlan(idx3, r3, nu3, ni3, k3) as p3:
+                p3.set_factors(synth.init_normal(k3, ni3, synth.SEED_INIT), synth.init_normal(k3, nu3, synth.SEED_INIT + 1),
+                               np.zeros(ni3), np.zeros(nu3))
+                m = k1_measure(p3, nnz3, nu3, k3, a.steps, a.warmup,
+                               lambda n: p3.run_kmf(LINEAR, n, LR, KU, KI, KB, want_rmse=False))
+            m["unit"] = "rating-updates/s"
+            m["workload"] = "cfg3 whole on ONE GPU (1M x 200K, 100M ratings, k=64): the N=1 point of the strong-scaling " \
+                            "curve that `--gpus N` (N>1) continues"
+            out["k1_cfg3_whole_1gpu"] = m
+            del r3
+            t = time.perf_counter()
+            try:
+                out["k3_als_cfg4"] = also_als(idx3, nu3, ni3, 128)
+                out["k3_als_cfg4"]["leg_wall_s"] = round(time.perf_counter() - t, 1)
+            except Exception as e:
+                out["k3_als_cfg4"] = {"error": repr(e)}
+            return out
+
+        t = time.perf_counter()
+        try:
+            also.update(cfg3_and_als())
+        except Exception as e:
+            also["k1_cfg3_whole_1gpu"] = {"error": repr(e)}
+        if not a.no_cpu and "k3_als_cfg4" in also and "error" not in also["k3_als_cfg4"]:
+            try:
+                cb = cpu_baseline_als(128)
+                # scaled to cfg 4 by the FLOP model: seconds per epoch the CPU path would need
+                cb["cfg4_epoch_s_extrapolated"] = also["k3_als_cfg4"]["model_tflop_per_epoch"] * 1e3 / cb["model_gflops"]
+                also["k3_als_cfg4"]["cpu_baseline"] = cb
+            except Exception as e:
+                also["k3_als_cfg4"]["cpu_baseline"] = {"error": repr(e)}
+
+    if rank == 0:
+        if also:
+            line["also"] = also
         if not a.no_cpu and world == 1:          # rank 0 at N=1 only
-            line["cpu_baseline"] = cpu_baseline(idx, r, nu, ni, k)
+            line["cpu_baseline"] = cpu_baseline_k1(idx, r, nu, ni, k)
         print(json.dumps(line), flush=True)
-    plan.close()
+    if plan is not None:
+        plan.close()
     if world > 1:
         S.check(S.lib().mfx_comm_barrier())
         S.check(S.lib().mfx_comm_destroy())

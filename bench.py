@@ -173,11 +173,11 @@ def cpu_replica_main(a):
 
 
 def cpu_baseline_funk(idx, r, nu, ni, budget_s=8.0):
-    """estimator_loop_without_bias (gd_estimator.pyx:691-779): k = 2 features x 1 epoch each (+ the
+    """estimator_loop_without_bias (gd_estimator.pyx:691-779): k = 8 features x 1 epoch each (+ the
     cache-commit passes) on a bounded prefix, 1 thread."""
     from oracle import oracle as O
     from mfrec_amd import synth
-    kk = 2
+    kk = 8
     ref = load_reference()
 
     def run(n):
@@ -191,7 +191,7 @@ def cpu_baseline_funk(idx, r, nu, ni, budget_s=8.0):
     rate, n, dt = timed_prefix(run, idx.shape[0], budget_s / 2.0, n_probe=500000)
     return {"value": rate * kk, "unit": "scalar-updates/s", "cores": 1,
             "kind": "reference" if ref is not None else "port",
-            "sample": "first %d of %d ratings, 2 features x 1 epoch (+ commit passes), %s, single thread, %.1f s"
+            "sample": "first %d of %d ratings, 8 features x 1 epoch (+ commit passes), %s, single thread, %.1f s"
                       % (n, idx.shape[0], "the reference's Cython estimator_loop_without_bias (oracle/_ref)"
                          if ref is not None else "oracle/mfx_oracle.c", dt)}
 
@@ -202,13 +202,14 @@ def als_flops(k, nz, nu, ni):
 
 
 def cpu_baseline_als(k):
-    """als_wrmf (als_implicit.pyx:211-352) on the cfg-4 problem divided by 100 in every dimension (10K x 2K,
-    1M ratings, same k), 1 epoch, 1 thread; scaled to cfg 4 by the FLOP model of SURVEY 8(d)."""
+    """als_wrmf (als_implicit.pyx:211-352) on the cfg-4 problem divided by 200 in every dimension (5K x 1K,
+    500K ratings, same k; SURVEY 8(d) proposes / 100, which needs a minute and a half of CPU), 1 epoch,
+    1 thread; scaled to cfg 4 by the FLOP model of SURVEY 8(d)."""
     import scipy.sparse as sp
     from oracle import oracle as O
     from mfrec_amd import synth
     from mfrec_amd.lib.datasets import create_bool_sparse_col, create_bool_sparse_row
-    nu, ni, nnz = 10000, 2000, 1000000
+    nu, ni, nnz = 5000, 1000, 500000
     idx, _ = synth.make_ratings(nu, ni, nnz)
     M = sp.csr_matrix((np.ones(nnz, dtype=np.int8), (idx[:, 0], idx[:, 1])), shape=(nu, ni))
     M.sum_duplicates()
@@ -217,17 +218,28 @@ def cpu_baseline_als(k):
     rs = np.random.RandomState(0)
     u, v = rs.normal(0, 0.1, (k, ni)), rs.normal(0, 0.1, (k, nu))
     ref = load_reference()
+    # ONE thread, as the reference runs: its per-row np.linalg.inv would otherwise fan a 128 x 128 LAPACK
+    # call out over every core of the host (measured: 13x slower on a 256-thread box)
+    try:
+        from threadpoolctl import threadpool_limits
+        limit = threadpool_limits(limits=1)
+    except Exception:
+        limit = None
     t0 = time.perf_counter()
-    if ref is not None:
-        m, m_inv = np.zeros((k, k)), np.zeros((k, k))
-        ref["als_implicit"].als_wrmf(1, k, u, v, m, m_inv, *views, nu, ni, 1, 0.015, 0)
-    else:
-        O.als_wrmf(1, k, u, v, None, None, *views, nu, ni, 1, 0.015)
+    try:
+        if ref is not None:
+            m, m_inv = np.zeros((k, k)), np.zeros((k, k))
+            ref["als_implicit"].als_wrmf(1, k, u, v, m, m_inv, *views, nu, ni, 1, 0.015, 0)
+        else:
+            O.als_wrmf(1, k, u, v, None, None, *views, nu, ni, 1, 0.015)
+    finally:
+        if limit is not None:
+            limit.restore_original_limits()
     dt = time.perf_counter() - t0
     F = als_flops(k, nz, nu, ni)
     return {"value": (nu + ni) / dt, "unit": "rows/s", "cores": 1, "kind": "reference" if ref is not None else "port",
             "model_gflops": F / dt / 1e9, "seconds": dt,
-            "sample": "cfg 4 / 100: %d x %d, %d distinct ratings, k=%d, 1 epoch, %s, single thread"
+            "sample": "cfg 4 / 200: %d x %d, %d distinct ratings, k=%d, 1 epoch, %s, single thread"
                       % (nu, ni, nz, k, "the reference's Cython als_wrmf (oracle/_ref)" if ref is not None
                          else "oracle/mfx_oracle.c")}
 

@@ -195,6 +195,14 @@ int mfx_sgd_plan_kernel_name(const mfx_sgd_plan *p, int mode, char *buf, int buf
  * f64 arithmetic" fast mode of the full-k kernels: rows are widened on load and rounded once on
  * store.  NOT bit-exact (measured RMSE delta: DESIGN.md); single-GPU; call before set_factors. */
 int mfx_sgd_plan_set_storage(mfx_sgd_plan *p, int bits);
+/* How the full-k kernels (linear / logistic) form the k-term dot product ib + ub + sum_f U[f,i] V[f,u]:
+ * MFX_DOT_ORDERED (default): summed strictly left to right by one lane, no FMA -- the reference's
+ * operation order (kmf_train.pyx:75-97), bit-identical results.  MFX_DOT_BUTTERFLY: per-lane partial
+ * products and a wave butterfly (DPP + cross-row swaps) with a FIXED association, FMA in dot and row
+ * update -- deterministic, f64, but NOT bit-identical to the reference (tolerance mode: final RMSE
+ * within 1e-5, measured in DESIGN.md).  f64 rows, even k > 4. */
+enum { MFX_DOT_ORDERED = 0, MFX_DOT_BUTTERFLY = 1 };
+int mfx_sgd_plan_set_dot(mfx_sgd_plan *p, int dot);
 int mfx_sgd_set_factors(mfx_sgd_plan *p, const double *u, const double *v,
                         const double *items_bias, const double *users_bias);
 int mfx_sgd_get_factors(mfx_sgd_plan *p, double *u, double *v, double *items_bias,

@@ -67,6 +67,7 @@ SIGNATURES = {
     "mfx_sgd_plan_destroy": (None, [C.c_void_p]),
     "mfx_sgd_plan_info": (C.c_int, [C.c_void_p, _lp]),
     "mfx_sgd_plan_set_storage": (C.c_int, [C.c_void_p, C.c_int]),
+    "mfx_sgd_plan_set_dot": (C.c_int, [C.c_void_p, C.c_int]),
     "mfx_sgd_plan_kernel_name": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int]),
     "mfx_sgd_set_factors": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp]),
     "mfx_sgd_get_factors": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp]),

@@ -33,6 +33,7 @@ struct mfx_sgd_plan {
     int64_t n_levels = 0, max_level = 0;
     int batch = 16;                      // full-k kernel: ratings per wave
     int f32 = 0;                         // factor rows stored as f32 (fast mode, not exact)
+    int dot = 0;                         // 1: butterfly k-dot + FMA (tolerance mode, not bit-exact)
     std::vector<int64_t> level_off;      // n_levels + 1
     std::vector<int64_t> k1_wave_off;    // per level: first se_partial slot (full-k kernels)
     std::vector<int64_t> k2_wave_off;    // per level (Funk kernels)
@@ -164,7 +165,7 @@ struct K1Sel {
     const char *tag;
 };
 
-template <int MODE, typename TS, bool TAIL>
+template <int MODE, typename TS, bool TAIL, int DOT = 0>
 K1Sel k1_pick(int k, int batch)
 {
 #define MFX_K1(KP, FPL, B) K1Sel{TAIL ? (void *)k1_tail<KP, FPL, B, MODE, 0, TS> : (void *)k1_level<KP, FPL, B, MODE, 0, TS>, #KP "," #FPL "," #B ",8B/lane"}
@@ -174,7 +175,7 @@ K1Sel k1_pick(int k, int batch)
     // stores, vec = 2 (default) write-through stores -- no dirty lines left for the end-of-kernel
     // write-back.  cfg 2: 1.68 (8 B per lane) / 1.75 / 1.88 G updates/s; 16 or 4 ratings per wave,
     // and write-through bias stores, measured slower.
-#define MFX_K1VF(KP, FPL, B, NTF) K1Sel{TAIL ? (void *)k1_tail<KP, FPL, B, MODE, 0, TS, true> : (void *)k1_level<KP, FPL, B, MODE, NTF, TS, true>, (NTF == 2 && !TAIL) ? #KP "," #FPL "," #B ",vec16+wt" : #KP "," #FPL "," #B ",vec16"}
+#define MFX_K1VF(KP, FPL, B, NTF) K1Sel{TAIL ? (void *)k1_tail<KP, FPL, B, MODE, 0, TS, true, DOT> : (void *)k1_level<KP, FPL, B, MODE, NTF, TS, true, DOT>, (NTF == 2 && !TAIL) ? (DOT ? #KP "," #FPL "," #B ",vec16+wt,butterfly-dot" : #KP "," #FPL "," #B ",vec16+wt") : (DOT ? #KP "," #FPL "," #B ",vec16,butterfly-dot" : #KP "," #FPL "," #B ",vec16")}
     {
         // the learned-bias family stores ONE feature per row: 16-byte loads only, plain stores
         const int vec = (MODE == K1_LEARNED && k1_vec_mode()) ? 1 : k1_vec_mode();   // (write-through scalars: no gain)
@@ -215,9 +216,16 @@ K1Sel k1_pick(int k, int batch)
 #undef MFX_K1
 }
 
+// the butterfly-dot (tolerance) mode exists for f64 rows, even k > 4, linear / logistic
+bool k1_dot_eligible(int k, int f32) { return !f32 && k % 2 == 0 && k > 4 && k1_vec_mode() != 0; }
+
 template <bool TAIL>
-K1Sel k1_select(int k, int mode, int batch, int f32)
+K1Sel k1_select(int k, int mode, int batch, int f32, int dot = 0)
 {
+    if (dot && k1_dot_eligible(k, f32)) {
+        if (mode == 0) return k1_pick<K1_LINEAR, double, TAIL, 1>(k, batch);
+        if (mode == 1) return k1_pick<K1_LOGISTIC, double, TAIL, 1>(k, batch);
+    }
     switch (mode * 2 + (f32 ? 1 : 0)) {
     case 0: return k1_pick<K1_LINEAR, double, TAIL>(k, batch);
     case 1: return k1_pick<K1_LINEAR, float, TAIL>(k, batch);
@@ -228,8 +236,8 @@ K1Sel k1_select(int k, int mode, int batch, int f32)
     }
 }
 
-void *k1_kernel(int k, int mode, int batch, int f32) { return k1_select<false>(k, mode, batch, f32).fn; }
-void *k1_tail_kernel(int k, int mode, int batch, int f32) { return k1_select<true>(k, mode, batch, f32).fn; }
+void *k1_kernel(int k, int mode, int batch, int f32, int dot) { return k1_select<false>(k, mode, batch, f32, dot).fn; }
+void *k1_tail_kernel(int k, int mode, int batch, int f32, int dot) { return k1_select<true>(k, mode, batch, f32, dot).fn; }
 
 int env_int(const char *name, int dflt)
 {
@@ -266,9 +274,10 @@ int enqueue_reduce(mfx_sgd_plan *p, int64_t n_partials)
 int enqueue_k1_epoch(mfx_sgd_plan *p, int mode, const K1Params &P, std::vector<hipEvent_t> *ev)
 {
     const int batch = p->batch;
-    void *fn = k1_kernel(p->k, mode, batch, p->f32);
-    void *fn_tail = k1_tail_kernel(p->k, mode, batch, p->f32);
-    const size_t lds = k1_lds_bytes(p->k, batch);
+    void *fn = k1_kernel(p->k, mode, batch, p->f32, p->dot);
+    void *fn_tail = k1_tail_kernel(p->k, mode, batch, p->f32, p->dot);
+    // (the butterfly dot needs no product tile)
+    const size_t lds = (p->dot && mode != K1_LEARNED && k1_dot_eligible(p->k, p->f32)) ? 0 : k1_lds_bytes(p->k, batch);
     const size_t lds_tail = lds / kWaves * kTailWaves;
     if (lds_tail > 64 * 1024)
         (void)hipFuncSetAttribute(fn_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tail);
@@ -706,7 +715,7 @@ int mfx_sgd_plan_kernel_name(const mfx_sgd_plan *p, int mode, char *buf, int buf
 {
     if (!p || !buf || buflen < 1 || mode < 0 || mode > 2) return fail(MFX_E_ARG, "mfx_sgd_plan_kernel_name: bad argument");
     static const char *const mode_name[] = {"linear", "logistic", "learned"};
-    snprintf(buf, (size_t)buflen, "k1_level<%s,%s%s>", k1_select<false>(p->k, mode, p->batch, p->f32).tag,
+    snprintf(buf, (size_t)buflen, "k1_level<%s,%s%s>", k1_select<false>(p->k, mode, p->batch, p->f32, p->dot).tag,
              mode_name[mode], p->f32 ? ",f32" : "");
     return MFX_OK;
 }
@@ -717,6 +726,16 @@ int mfx_sgd_plan_set_storage(mfx_sgd_plan *p, int bits)
     if (p->have_factors) return fail(MFX_E_STATE, "mfx_sgd_plan_set_storage: call before mfx_sgd_set_factors");
     p->f32 = (bits == 32);
     drop_graph(p);
+    return MFX_OK;
+}
+
+int mfx_sgd_plan_set_dot(mfx_sgd_plan *p, int dot)
+{
+    if (!p || (dot != MFX_DOT_ORDERED && dot != MFX_DOT_BUTTERFLY)) return fail(MFX_E_ARG, "mfx_sgd_plan_set_dot: bad argument");
+    if (dot == MFX_DOT_BUTTERFLY && !k1_dot_eligible(p->k, p->f32))
+        return fail(MFX_E_ARG, "mfx_sgd_plan_set_dot: the butterfly dot needs f64 rows and an even k > 4 (k = %d)", p->k);
+    if (p->dot != dot) drop_graph(p);
+    p->dot = dot;
     return MFX_OK;
 }
 

@@ -91,6 +91,31 @@ __device__ __forceinline__ double wave_sum_fixed(double x)
     return x;
 }
 
+// ---- tolerance mode (DOT = 1): the k-term dot as north_star words it -- per-lane partial products,
+// then a wave butterfly over the KP lanes of a rating.  Still f64, still deterministic (a FIXED
+// association: quad swaps, half-row and row mirrors on DPP, then the cross-row swaps), FMA used; NOT the
+// reference's left-to-right sum (kmf_train.pyx:75-97), so results differ from it at the 1e-16 level per
+// operation -- measured final-RMSE delta in DESIGN.md.  Selected per plan (mfx_sgd_plan_set_dot).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// sum over the KP lanes of an aligned group; every lane of the group gets the same bits
+template <int KP>
+__device__ __forceinline__ double group_sum(double x)
+{
+    if constexpr (KP >= 2) x = x + dpp_f64<0xB1>(x);     // quad_perm [1,0,3,2]
+    if constexpr (KP >= 4) x = x + dpp_f64<0x4E>(x);     // quad_perm [2,3,0,1]
+    if constexpr (KP >= 8) x = x + dpp_f64<0x141>(x);    // row_half_mirror: lane i <-> 7 - i
+    if constexpr (KP >= 16) x = x + dpp_f64<0x140>(x);   // row_mirror: lane i <-> 15 - i
+    if constexpr (KP >= 32) x = x + shfl_f64(x, (int)(threadIdx.x & 63) ^ 16);
+    if constexpr (KP >= 64) x = x + shfl_f64(x, (int)(threadIdx.x & 63) ^ 32);
+    return x;
+}
+
 // KP  lanes per rating slot (8/16/32/64), SPW = 64/KP slots side by side
 // FPL features per lane (f = j*KP + q), NR ratings per slot in flight; SPW*NR == BATCH
 //
@@ -124,7 +149,7 @@ __device__ __forceinline__ void store16_sc1(TS *p, typename Chunk16<TS>::type c)
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
-template <int KP, int FPL, int BATCH, int MODE, int NT, bool FULL, typename TS, bool VEC = false>
+template <int KP, int FPL, int BATCH, int MODE, int NT, bool FULL, typename TS, bool VEC = false, int DOT = 0>
 __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cnt, int64_t base,
                                         int64_t slot, double *prod, int lane)
 {
@@ -226,8 +251,29 @@ __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cn
 #endif
     MFX_STAMP(2);
 
+    // ---- tolerance mode: per-lane partials (features ascending, FMA) + butterfly over the slot's lanes ----
+    double dotv = 0.0;
+    if constexpr (DOT == 1) {
+        double part[NR];
+#pragma unroll
+        for (int s = 0; s < NR; ++s) {
+            double a = 0.0;
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) a = __builtin_fma(uval[s][j], vval[s][j], a);
+            part[s] = a;
+        }
+#pragma unroll
+        for (int s = 0; s < NR; ++s) part[s] = group_sum<KP>(part[s]);
+        // lane n (< BATCH) owns rating n = s * SPW + g: its dot sits in every lane of slot g, register s
+#pragma unroll
+        for (int s = 0; s < NR; ++s) {
+            const double t = shfl_f64(part[s], (lane % SPW) * KP);
+            if (lane / SPW == s) dotv = t;
+        }
+    }
     // ---- products to LDS: prod[n][f] -------------------------------------------------
-    if constexpr (VEC) {
+    if constexpr (DOT == 1) {
+    } else if constexpr (VEC) {
 #pragma unroll
         for (int j = 0; j < FPL / VW; ++j) {
             const int f0 = VW * q + VW * KP * j;
@@ -252,9 +298,11 @@ __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cn
             }
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if constexpr (DOT != 1) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
 
     // ---- lane n: strictly sequential k-term sum, error, gradient, bias update ---------
     double grad = 0.0, e2 = 0.0, ubn = 0.0, ibn = 0.0;
@@ -262,18 +310,22 @@ __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cn
         double sum;
         if constexpr (MODE == K1_LEARNED) sum = P.mu + ibv + ubv;     // gd_estimator.pyx:138
         else sum = 0.0 + ibv + ubv;                                   // kmf_train.pyx:92
-        const double *row = prod + lane * stride;
-        // strictly left-to-right; LDS reads are issued 8 columns ahead of the dependent adds
-        int f = 0;
-        for (; f + 8 <= k; f += 8) {
-            const double2 a = *reinterpret_cast<const double2 *>(row + f);
-            const double2 b = *reinterpret_cast<const double2 *>(row + f + 2);
-            const double2 c = *reinterpret_cast<const double2 *>(row + f + 4);
-            const double2 d = *reinterpret_cast<const double2 *>(row + f + 6);
-            sum += a.x; sum += a.y; sum += b.x; sum += b.y;
-            sum += c.x; sum += c.y; sum += d.x; sum += d.y;
+        if constexpr (DOT == 1) {
+            sum += dotv;
+        } else {
+            const double *row = prod + lane * stride;
+            // strictly left-to-right; LDS reads are issued 8 columns ahead of the dependent adds
+            int f = 0;
+            for (; f + 8 <= k; f += 8) {
+                const double2 a = *reinterpret_cast<const double2 *>(row + f);
+                const double2 b = *reinterpret_cast<const double2 *>(row + f + 2);
+                const double2 c = *reinterpret_cast<const double2 *>(row + f + 4);
+                const double2 d = *reinterpret_cast<const double2 *>(row + f + 6);
+                sum += a.x; sum += a.y; sum += b.x; sum += b.y;
+                sum += c.x; sum += c.y; sum += d.x; sum += d.y;
+            }
+            for (; f < k; ++f) sum += row[f];
         }
-        for (; f < k; ++f) sum += row[f];
         double err;
         if constexpr (MODE == K1_LINEAR) {
             err = rec.r - sum;                                        // kmf_train.pyx:251-256
@@ -329,8 +381,13 @@ __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cn
 #pragma unroll
                         for (int e = 0; e < VW; ++e) {
                             const double mf = uval[s][VW * j + e], cf = vval[s][VW * j + e];
-                            un[e] = (TS)(mf + P.lr * (gr[s] * cf - P.Ki * mf));       // kmf_train.pyx:267-270
-                            vn[e] = (TS)(cf + P.lr * (gr[s] * mf - P.Ku * cf));
+                            if constexpr (DOT == 1) {
+                                un[e] = (TS)__builtin_fma(P.lr, __builtin_fma(gr[s], cf, -(P.Ki * mf)), mf);
+                                vn[e] = (TS)__builtin_fma(P.lr, __builtin_fma(gr[s], mf, -(P.Ku * cf)), cf);
+                            } else {
+                                un[e] = (TS)(mf + P.lr * (gr[s] * cf - P.Ki * mf));       // kmf_train.pyx:267-270
+                                vn[e] = (TS)(cf + P.lr * (gr[s] * mf - P.Ku * cf));
+                            }
                         }
                         TS *up = ur[s] + f0, *vp = vr[s] + f0;
                         if constexpr (NT == 2) {               // 16-byte write-through stores
@@ -403,7 +460,7 @@ __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cn
     if (lane == 0) P.se_partial[slot] = wsum;
 }
 
-template <int KP, int FPL, int BATCH, int MODE, int NT, typename TS = double, bool VEC = false>
+template <int KP, int FPL, int BATCH, int MODE, int NT, typename TS = double, bool VEC = false, int DOT = 0>
 __global__ __launch_bounds__(kWaves * 64) void k1_level(K1Params P, int64_t start, int count,
                                                        int64_t wave_off)
 {
@@ -419,9 +476,9 @@ __global__ __launch_bounds__(kWaves * 64) void k1_level(K1Params P, int64_t star
     const int cnt = (count - base) < BATCH ? (int)(count - base) : BATCH;
     double *prod = lds + (size_t)wid * BATCH * k1_stride(P.k);
     if (cnt == BATCH && P.upd_u && P.upd_i)
-        k1_body<KP, FPL, BATCH, MODE, NT, true, TS, VEC>(P, start, cnt, base, wave_off + wave_g, prod, lane);
+        k1_body<KP, FPL, BATCH, MODE, NT, true, TS, VEC, DOT>(P, start, cnt, base, wave_off + wave_g, prod, lane);
     else
-        k1_body<KP, FPL, BATCH, MODE, NT, false, TS, VEC>(P, start, cnt, base, wave_off + wave_g, prod, lane);
+        k1_body<KP, FPL, BATCH, MODE, NT, false, TS, VEC, DOT>(P, start, cnt, base, wave_off + wave_g, prod, lane);
 }
 
 // Tail kernel: a run of consecutive SMALL levels (each <= kTailWaves*BATCH ratings) in ONE
@@ -430,7 +487,7 @@ __global__ __launch_bounds__(kWaves * 64) void k1_level(K1Params P, int64_t star
 // chain of a few hot items/users with a handful of ratings each; a launch per level would
 // cost ~9 us for ~no work.
 static constexpr int kTailWaves = 16;
-template <int KP, int FPL, int BATCH, int MODE, int NT, typename TS = double, bool VEC = false>
+template <int KP, int FPL, int BATCH, int MODE, int NT, typename TS = double, bool VEC = false, int DOT = 0>
 __global__ __launch_bounds__(kTailWaves * 64) void k1_tail(K1Params P, const int64_t *level_off,
                                                           const int64_t *wave_off, int l0, int l1)
 {
@@ -450,9 +507,9 @@ __global__ __launch_bounds__(kTailWaves * 64) void k1_tail(K1Params P, const int
             } else {
                 const int cnt = (count - base) < BATCH ? (count - base) : BATCH;
                 if (cnt == BATCH && P.upd_u && P.upd_i)
-                    k1_body<KP, FPL, BATCH, MODE, NT, true, TS, VEC>(P, start, cnt, base, woff + wid, prod, lane);
+                    k1_body<KP, FPL, BATCH, MODE, NT, true, TS, VEC, DOT>(P, start, cnt, base, woff + wid, prod, lane);
                 else
-                    k1_body<KP, FPL, BATCH, MODE, NT, false, TS, VEC>(P, start, cnt, base, woff + wid, prod, lane);
+                    k1_body<KP, FPL, BATCH, MODE, NT, false, TS, VEC, DOT>(P, start, cnt, base, woff + wid, prod, lane);
             }
         }
         __syncthreads();

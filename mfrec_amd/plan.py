@@ -14,7 +14,8 @@ LINEAR, LOGISTIC = 0, 1
 class SgdPlan(object):
     SCHEDULE = {"auto": 0, "host": 1, "device": 2}
 
-    def __init__(self, ratings_index, ratings, nbr_users, nbr_items, dim, storage="f64", schedule="auto"):
+    def __init__(self, ratings_index, ratings, nbr_users, nbr_items, dim, storage="f64", schedule="auto",
+                 dot="ordered"):
         """schedule: who builds the dependency-level schedule -- "host" (sequential pass + threaded
         counting sort), "device" (radix sorts + one frontier launch per level in HBM) or "auto"
         (device for >= 2^20 ratings unless the data needs more than nnz/1000 levels).  Same result."""
@@ -31,6 +32,13 @@ class SgdPlan(object):
         self.storage = storage
         if storage == "f32":
             S.check(S.lib().mfx_sgd_plan_set_storage(self._h, 32))
+        # dot: "ordered" = the reference's left-to-right sum (bit-exact); "butterfly" = tolerance mode
+        # (wave butterfly with a fixed association + FMA: deterministic, not bit-identical)
+        if dot not in ("ordered", "butterfly"):
+            raise ValueError("dot must be 'ordered' (exact) or 'butterfly' (tolerance mode)")
+        self.dot = dot
+        if dot == "butterfly":
+            S.check(S.lib().mfx_sgd_plan_set_dot(self._h, 1))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -341,3 +341,55 @@ def test_f32_storage_fast_mode_rmse_budget(golden):
     np.testing.assert_allclose(u, g["out_lin_u"], rtol=0, atol=2e-5)
     with pytest.raises(ValueError):
         SgdPlan(idx, r, nu, ni, k, storage="bf16")
+
+
+def test_butterfly_dot_tolerance_mode(golden):
+    """North-star's own wording of the kernel ("wavefront __shfl/ds_swizzle reductions for the k-dim dot
+    product"): per-lane partial products + a wave butterfly with a FIXED association, FMA in dot and row
+    update.  Deterministic and f64, but not the reference's left-to-right sum (kmf_train.pyx:75-97): the
+    contract is the tolerance north_star states -- final RMSE within 1e-5 (cfg-1 shape, 10 epochs; measured:
+    ~1e-13) -- plus run-to-run bit-reproducibility.  Never the default."""
+    from mfrec_amd.plan import SgdPlan
+    from oracle import oracle as O
+    g = golden("g7_cfg1")
+    nu, ni, k, E = int(g["p_nu"]), int(g["p_ni"]), int(g["p_k"]), int(g["p_epochs"])
+    idx, r = g["in_idx"], g["in_r"].astype(np.float64)
+    seed = int(g["p_seed_init"])
+    outs = []
+    for rep in range(2):
+        u, v = synth.init_normal(k, ni, seed), synth.init_normal(k, nu, seed + 1)
+        ib, ub = np.zeros(ni), np.zeros(nu)
+        with SgdPlan(idx, r, nu, ni, k, dot="butterfly") as p:
+            assert "butterfly-dot" in p.kernel_name(0)
+            p.set_factors(u, v, ib, ub)
+            rm = p.run_kmf(0, E, 0.01, 0.1, 0.1, 0.007)
+            p.get_factors(u, v, ib, ub)
+        outs.append((u, v, ib, ub, rm))
+    u, v, ib, ub, rm = outs[0]
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)                                # deterministic
+    rmse = O.rmse(O.RMSE_KMF_LINEAR, u, v, idx, r, ib, ub)
+    assert abs(rmse - float(g["out_lin_final_rmse"])) <= 1e-5      # north_star's bar
+    assert abs(rmse - float(g["out_lin_final_rmse"])) <= 1e-10     # what is actually measured
+    assert np.max(np.abs(rm - g["out_lin_rmse"])) <= 1e-10
+    assert not np.array_equal(u, g["out_lin_u"])                   # it is NOT the exact mode
+    np.testing.assert_allclose(u, g["out_lin_u"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(v, g["out_lin_v"], rtol=0, atol=1e-10)
+    # several k (lanes per rating 8 / 16 / 32 / 64, partial batches, logistic) against the oracle
+    for kk, mode in ((6, 0), (16, 0), (24, 1), (64, 0), (100, 0), (128, 1), (200, 0)):
+        nu2, ni2, nnz2 = 211, 97, 5003
+        i2, r2 = synth.make_ratings(nu2, ni2, nnz2, seed=kk)
+        u0, v0 = synth.init_normal(kk, ni2, 1), synth.init_normal(kk, nu2, 2)
+        ua, va, iba, uba = u0.copy(), v0.copy(), np.zeros(ni2), np.zeros(nu2)
+        with SgdPlan(i2, r2, nu2, ni2, kk, dot="butterfly") as p:
+            p.set_factors(ua, va, iba, uba)
+            p.run_kmf(mode, 3, 0.01, 0.1, 0.1, 0.007)
+            p.get_factors(ua, va, iba, uba)
+        ub_, vb, ibb, ubb = u0.copy(), v0.copy(), np.zeros(ni2), np.zeros(nu2)
+        fn = O.train_linear_kernel if mode == 0 else O.train_logistic_kernel
+        fn(3, kk, 0.1, 0.01, 0, 0, 0.1, 0.1, 0.007, 0.0, ub_, vb, i2, r2, ibb, ubb)
+        np.testing.assert_allclose(ua, ub_, rtol=0, atol=1e-11)
+        np.testing.assert_allclose(va, vb, rtol=0, atol=1e-11)
+        np.testing.assert_allclose(iba, ibb, rtol=0, atol=1e-11)
+    with pytest.raises(ValueError):
+        SgdPlan(idx, r, nu, ni, 7, dot="butterfly")                 # odd k: no 16-byte feature pairs

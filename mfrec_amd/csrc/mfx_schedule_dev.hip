@@ -14,8 +14,10 @@
 // The host pass is sequential (3 ns per rating, cache-missing); this one wins while the level count
 // stays below ~nnz/1000 and gives up (caller falls back to the host) beyond a level budget, which
 // is what heavily skewed data (a user with 10^5 ratings) produces.
-// Radix sort: hipCUB (rocPRIM) DeviceRadixSort -- a library primitive, not part of the hot path.
-#include <hipcub/hipcub.hpp>
+// Radix sort: rocprim::radix_sort_pairs (ROCm's native primitive library, stable) -- off the hot path.
+#include <string.h>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
 #include <vector>
 #include "mfx_common.h"
 
@@ -158,6 +160,14 @@ __global__ void k_class_bounds(const int32_t *__restrict__ keys, int64_t nnz, un
         if (p == 0 || keys[p - 1] != keys[p]) start[keys[p] - 1] = (unsigned long long)p;
 }
 
+// stable LSD radix sort of (key, value) pairs on bits [0, end_bit)
+template <typename K, typename V>
+hipError_t sort_pairs(void *tmp, size_t &tmp_bytes, const K *kin, K *kout, const V *vin, V *vout, int64_t n,
+                      int end_bit, hipStream_t st)
+{
+    return rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, (unsigned int)n, 0u, (unsigned int)end_bit, st);
+}
+
 int bits_for(int64_t n)      // radix bits that cover keys 0 .. n-1
 {
     int b = 1;
@@ -236,14 +246,14 @@ int schedule_device(const int32_t *h_idx, const double *h_r, int64_t nnz, int nu
 
     // ---- chains -------------------------------------------------------------------------------
     size_t tmp_bytes = 0, tb2 = 0;
-    MFX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, users, ka, tvals, va, (int)nnz, 0, 32, st));
-    MFX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, level, ka, tvals, va, (int)nnz, 0, 32, st));
+    MFX_HIP(sort_pairs(nullptr, tmp_bytes, users, ka, tvals, va, nnz, 32, st));
+    MFX_HIP(sort_pairs(nullptr, tb2, level, ka, tvals, va, nnz, 32, st));
     if (tb2 > tmp_bytes) tmp_bytes = tb2;
     char *tmp = nullptr;
     if (S.get(&tmp, tmp_bytes)) return last_code();
-    MFX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, users, ka, tvals, va, (int)nnz, 0, bits_for(nu), st));
+    MFX_HIP(sort_pairs(tmp, tmp_bytes, users, ka, tvals, va, nnz, bits_for(nu), st));
     k_link<<<blocks, kBfsThreads, 0, st>>>(ka, va, nnz, next_u, indeg, 1);
-    MFX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, items, ka, tvals, va, (int)nnz, 0, bits_for(ni), st));
+    MFX_HIP(sort_pairs(tmp, tmp_bytes, items, ka, tvals, va, nnz, bits_for(ni), st));
     k_link<<<blocks, kBfsThreads, 0, st>>>(ka, va, nnz, next_i, indeg, 0);
 
     // ---- levels (frontier buffers rotate over ka / va / fr2, like the counters) ----------------
@@ -283,8 +293,7 @@ int schedule_device(const int32_t *h_idx, const double *h_r, int64_t nnz, int nu
         unsigned long long *bits = nullptr, *starts = nullptr;
         if (S.get(&bits, words) || S.get(&starts, (size_t)nl + 1)) return last_code();
         MFX_HIP(hipMemsetAsync(bits, 0, words * sizeof(unsigned long long), st));
-        MFX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, level, ka, tvals, va, (int)nnz, 0,
-                                                   bits_for(nl + 1), st));
+        MFX_HIP(sort_pairs(tmp, tmp_bytes, level, ka, tvals, va, nnz, bits_for(nl + 1), st));
         int32_t *colour = next_u;           // the chain arrays are free now
         for (int64_t l = 0; l < nl; ++l) {
             const int cnt = (int)(level_off[(size_t)l + 1] - level_off[(size_t)l]);
@@ -292,8 +301,7 @@ int schedule_device(const int32_t *h_idx, const double *h_r, int64_t nnz, int nu
                                                                 bits + (size_t)nu * W, W, colour);
         }
         // colour-major order (stable: ascending input index inside a colour) and the class offsets
-        MFX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, colour, ka, tvals, va, (int)nnz, 0,
-                                                   bits_for(nl + 1), st));
+        MFX_HIP(sort_pairs(tmp, tmp_bytes, colour, ka, tvals, va, nnz, bits_for(nl + 1), st));
         MFX_HIP(hipMemsetAsync(starts, 0xff, ((size_t)nl + 1) * sizeof(unsigned long long), st));
         k_class_bounds<<<blocks, kBfsThreads, 0, st>>>(ka, nnz, starts);
         std::vector<unsigned long long> hb((size_t)nl);
@@ -316,8 +324,7 @@ int schedule_device(const int32_t *h_idx, const double *h_r, int64_t nnz, int nu
     // ---- level-major order and records -----------------------------------------------------------
     if (d_recs || h_order) {
         if (!sorted)
-            MFX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, level, ka, tvals, va, (int)nnz, 0,
-                                                       bits_for(nl + 1), st));
+            MFX_HIP(sort_pairs(tmp, tmp_bytes, level, ka, tvals, va, nnz, bits_for(nl + 1), st));
         if (d_recs) k_gather_recs<<<blocks, kBfsThreads, 0, st>>>(va, d_idx, d_r, nnz, d_recs);
         if (h_order) {
             std::vector<int32_t> o32(n);
@@ -331,6 +338,74 @@ int schedule_device(const int32_t *h_idx, const double *h_r, int64_t nnz, int nu
     return MFX_OK;
 }
 
+}  // namespace mfx
+
+// ---------------------------------------------------------------------------------------------
+// Re-order the ratings INSIDE every dependency level by (user group, item) and return the segment
+// table seg_off[l * n_groups + g] = first position of (level l, group g), seg_off[n_levels * n_groups]
+// = nnz.  The order inside a level is free (its ratings share no user and no item), so every kernel
+// keeps its exact result; the XCD-resident Funk pass (mfx_sgd.hip: k2_xcd_pass) wants it this way:
+// a workgroup owns a user group (its slice of V[f,:] lives in LDS) and walks ascending items.
+// User groups are equal contiguous id ranges: group(u) = u * n_groups / nu.
+namespace mfx {
+namespace {
+__global__ void k_group_keys(const Rec *__restrict__ recs, int64_t nnz, const int64_t *__restrict__ level_off,
+                             int n_levels, int nu, int n_groups, unsigned long long *keys)
+{
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < nnz; p += (int64_t)gridDim.x * blockDim.x) {
+        int lo = 0, hi = n_levels;                       // level_off[lo] <= p < level_off[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (level_off[mid] <= p) lo = mid; else hi = mid;
+        }
+        const Rec q = recs[p];
+        const unsigned long long g = (unsigned long long)((int64_t)q.user * n_groups / nu);
+        keys[p] = ((unsigned long long)lo << 36) | (g << 31) | (unsigned long long)(unsigned)q.item;
+    }
+}
+__global__ void k_seg_bounds(const unsigned long long *__restrict__ keys, int64_t nnz, int n_levels, int n_groups,
+                             int32_t *seg_off)
+{
+    const int64_t nseg = (int64_t)n_levels * n_groups;
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q <= nseg; q += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long want = ((unsigned long long)(q / n_groups) << 36) | ((unsigned long long)(q % n_groups) << 31);
+        int64_t lo = 0, hi = nnz;                        // first position with key >= want
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (keys[mid] < want) lo = mid + 1; else hi = mid;
+        }
+        seg_off[q] = (int32_t)lo;
+    }
+}
+}  // namespace
+
+int levels_group_sort(Rec *d_recs, int64_t nnz, const int64_t *d_level_off, int64_t n_levels, int nu,
+                      int n_groups, int32_t *d_seg_off)
+{
+    mfx::TraceRange trace_("mfx:levels_group_sort");
+    if (nnz <= 0 || nnz >= ((int64_t)1 << 31) - 1 || n_levels >= ((int64_t)1 << 24) || n_groups < 1 || n_groups > 32)
+        return fail(MFX_E_ARG, "levels_group_sort: unsupported size");
+    hipStream_t st = stream();
+    Scratch S;
+    unsigned long long *k0, *k1;
+    Rec *r1;
+    const size_t n = (size_t)nnz;
+    if (S.get(&k0, n) || S.get(&k1, n) || S.get(&r1, n)) return last_code();
+    const int blocks = (int)std::min<int64_t>(ceil_div<int64_t>(nnz, 256), 8192);
+    k_group_keys<<<blocks, 256, 0, st>>>(d_recs, nnz, d_level_off, (int)n_levels, nu, n_groups, k0);
+    size_t tmp_bytes = 0;
+    const int key_bits = 36 + bits_for(n_levels + 1);
+    MFX_HIP(sort_pairs(nullptr, tmp_bytes, k0, k1, d_recs, r1, nnz, key_bits, st));
+    char *tmp = nullptr;
+    if (S.get(&tmp, tmp_bytes)) return last_code();
+    MFX_HIP(sort_pairs(tmp, tmp_bytes, k0, k1, d_recs, r1, nnz, key_bits, st));
+    MFX_HIP(hipMemcpyAsync(d_recs, r1, n * sizeof(Rec), hipMemcpyDeviceToDevice, st));
+    k_seg_bounds<<<(int)std::min<int64_t>(ceil_div<int64_t>(n_levels * n_groups + 1, 256), 4096), 256, 0, st>>>(
+        k1, nnz, (int)n_levels, n_groups, d_seg_off);
+    MFX_HIP(hipGetLastError());
+    MFX_HIP(hipStreamSynchronize(st));
+    return MFX_OK;
+}
 }  // namespace mfx
 
 // include/mfx.h: the GPU counterpart of mfx_schedule_levels (same arguments, same result)

@@ -12,6 +12,8 @@
 using namespace mfx;
 
 namespace mfx {
+int levels_group_sort(Rec *d_recs, int64_t nnz, const int64_t *d_level_off, int64_t n_levels, int nu,
+                      int n_groups, int32_t *d_seg_off);                                          // mfx_schedule_dev.hip
 int schedule_device(const int32_t *h_idx, const double *h_r, int64_t nnz, int nu, int ni, Rec *d_recs,
                     int32_t *h_level, std::vector<int64_t> &level_off, int64_t *n_levels,
                     int64_t level_budget, bool *over_budget, bool compact, int64_t *h_order);   // mfx_schedule_dev.hip
@@ -57,6 +59,14 @@ struct mfx_sgd_plan {
     bool nk_current = false, km_current = false;
     bool owns_users = true;              // false: d_V_*, d_ub belong to another plan (plan_alias_users)
 
+    // XCD-resident Funk pass (k2_xcd_pass): 0 = not decided, 1 = ready, -1 = not applicable / disabled
+    int k2x_state = 0;
+    int32_t *d_seg_off = nullptr;        // [n_levels * kXGroups + 1] after levels_group_sort
+    unsigned *d_xctl = nullptr;          // registration counters, status, barrier flags
+    double *d_se_x = nullptr;            // its squared-error partials (sparse slots, zero elsewhere)
+    int64_t k2x_slots = 0;
+    unsigned x_gen = 1;                  // barrier generation base of the next pass
+    int x_lds_doubles = 0;
     K2Dyn *d_k2dyn = nullptr;            // Funk per-feature record (lazy)
     hipGraphExec_t graph2 = nullptr;     // cached hipGraph of one Funk epoch
     K2Params graph2_params{};
@@ -259,9 +269,9 @@ int plan_batch(int k)
 constexpr int kMaxK = 512;
 constexpr size_t kMaxGraphNodes = 65536;
 
-int enqueue_reduce(mfx_sgd_plan *p, int64_t n_partials)
+int enqueue_reduce(mfx_sgd_plan *p, int64_t n_partials, const double *partials = nullptr)
 {
-    hipLaunchKernelGGL(k_reduce_se1, dim3(kReduceBlocks), dim3(256), 0, stream(), p->d_se_partial,
+    hipLaunchKernelGGL(k_reduce_se1, dim3(kReduceBlocks), dim3(256), 0, stream(), partials ? partials : p->d_se_partial,
                        n_partials, p->d_se_tmp);
     hipLaunchKernelGGL(k_reduce_se2, dim3(1), dim3(64), 0, stream(), p->d_se_tmp, p->d_se_epoch,
                        p->d_counter);
@@ -679,7 +689,7 @@ void mfx_sgd_plan_destroy(mfx_sgd_plan *p)
     drop_graph(p);
     if (!p->owns_users) p->d_V_km = p->d_V_nk = p->d_ub = nullptr;
     void *ptrs[] = {p->d_recs, p->d_U_km, p->d_V_km, p->d_U_nk, p->d_V_nk, p->d_ib, p->d_ub,
-                    p->d_cache, p->d_k2dyn, p->d_level_off, p->d_k1_wave_off, p->d_k2_wave_off, p->d_se_partial, p->d_se_tmp, p->d_se_epoch, p->d_counter, p->d_U_start,
+                    p->d_cache, p->d_k2dyn, p->d_seg_off, p->d_xctl, p->d_se_x, p->d_level_off, p->d_k1_wave_off, p->d_k2_wave_off, p->d_se_partial, p->d_se_tmp, p->d_se_epoch, p->d_counter, p->d_U_start,
                     p->d_ib_start};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -853,6 +863,57 @@ namespace mfx {
 // epoch and make the squared error global, so that every rank takes the same decision in the
 // data-dependent stopping rule)
 
+// Decide once per plan whether the XCD-resident pass applies, and prepare it: ratings re-ordered inside
+// their levels by (user group, item), segment table, control block, sparse squared-error slots.
+static int ensure_k2x(mfx_sgd_plan *p)
+{
+    if (p->k2x_state != 0) return MFX_OK;
+    p->k2x_state = -1;
+    const int mode = env_int("MFX_K2_XCD", -1);          // 0 = off, 1 = forced, default: by size
+    if (mode == 0 || p->nnz <= 0 || p->n_levels <= 0) return MFX_OK;
+    if (p->nnz >= ((int64_t)1 << 31) - 1 || p->n_levels >= ((int64_t)1 << 24) / 2) return MFX_OK;
+    if (mode != 1 && p->nnz / p->n_levels < 4096) return MFX_OK;    // small levels: the tail kernel's territory
+    // LDS: a workgroup holds one user group (32 workgroups on the XCD) -- room for two when it fits, so
+    // that an XCD that received fewer workgroups still works
+    const int64_t per_group = ceil_div((int64_t)p->nu, (int64_t)kXGroups) + 1;
+    const int64_t cap_doubles = (150 * 1024) / 8;
+    if (per_group > cap_doubles) return MFX_OK;
+    p->x_lds_doubles = (int)(2 * per_group <= cap_doubles ? 2 * per_group : per_group);
+    const int64_t nseg = p->n_levels * kXGroups;
+    p->k2x_slots = p->nnz / 64 + nseg + 2;
+    if (dev_alloc(p, &p->d_seg_off, (size_t)nseg + 1) || dev_alloc(p, &p->d_xctl, 4096) ||
+        dev_alloc(p, &p->d_se_x, (size_t)p->k2x_slots))
+        return last_code();
+    MFX_HIP(hipMemsetAsync(p->d_xctl, 0, 4096 * sizeof(unsigned), stream()));
+    MFX_HIP(hipMemsetAsync(p->d_se_x, 0, (size_t)p->k2x_slots * sizeof(double), stream()));
+    int rc = levels_group_sort(p->d_recs, p->nnz, p->d_level_off, p->n_levels, p->nu, kXGroups, p->d_seg_off);
+    if (rc) return rc;
+    const size_t lds = (size_t)p->x_lds_doubles * sizeof(double);
+    if (lds > 64 * 1024)
+        MFX_HIP(hipFuncSetAttribute((const void *)k2_xcd_pass, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    p->k2x_state = 1;
+    return MFX_OK;
+}
+
+static int enqueue_k2x_pass(mfx_sgd_plan *p, const K2Params &P)
+{
+    K2XParams X;
+    memset(&X, 0, sizeof(X));
+    X.recs = P.recs; X.dyn = P.dyn; X.cache = P.cache; X.ib = P.ib; X.ub = P.ub;
+    X.seg_off = p->d_seg_off; X.se_partial = p->d_se_x; X.ctl = p->d_xctl;
+    X.n_levels = (int)p->n_levels; X.nu = p->nu; X.lds_doubles = p->x_lds_doubles;
+    X.gen_base = p->x_gen;
+    X.lr = P.lr; X.K = P.K; X.mu = P.mu; X.upd_u = P.upd_u; X.upd_i = P.upd_i;
+    p->x_gen += (unsigned)p->n_levels + 1u;
+    // registration counters + status are cleared per pass; the flags keep counting
+    MFX_HIP(hipMemsetAsync(p->d_xctl, 0, 1024 * sizeof(unsigned), stream()));
+    void *args[] = {&X};
+    // one workgroup per CU: 256 launched, those on the chosen XCD stay
+    MFX_HIP(hipLaunchKernel((const void *)k2_xcd_pass, dim3(256), dim3((kXWorkers + 1) * 64), args,
+                            (size_t)p->x_lds_doubles * sizeof(double), stream()));
+    return enqueue_reduce(p, p->k2x_slots, p->d_se_x);
+}
+
 int funk_core(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_init, double lr,
               double K, double mu, int use_bias, int upd_u, int upd_i, int epoch_cap,
               double *rmse_hist, int64_t hist_cap, int64_t *n_hist, const FunkHooks *hk)
@@ -867,6 +928,8 @@ int funk_core(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_
         if (!rc) rc = dev_alloc(p, &p->d_k2dyn, 1);
         if (rc) return rc;
     }
+    rc = ensure_k2x(p);                  // may re-order the ratings inside their levels: before the cache is used
+    if (rc) return rc;
     MFX_HIP(hipMemsetAsync(p->d_cache, 0, (size_t)(p->nnz ? p->nnz : 1) * sizeof(double), stream()));
     double rmse = 2.0, rmse_last = 0.0;
     int64_t nh = 0;
@@ -919,16 +982,35 @@ int funk_core(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_
             if (epoch_cap > 0 && epoch >= epoch_cap) break;
             rmse_last = rmse;
             if (hk && (rc = hk->pre(hk->ctx, dyn.uf, p->ni))) return rc;
-            MFX_HIP(hipMemsetAsync(p->d_counter, 0, sizeof(int), stream()));
-            if (graph) MFX_HIP(hipGraphLaunch(p->graph2, stream()));
-            else {
-                rc = enqueue_k2_epoch(p, P);
-                if (rc) return rc;
-            }
-            if (hk && (rc = hk->post(hk->ctx, dyn.uf, p->ni))) return rc;
             double se = 0.0, nn = (double)p->nnz;
-            MFX_HIP(hipMemcpyAsync(&se, p->d_se_epoch, sizeof(double), hipMemcpyDeviceToHost, stream()));
-            MFX_HIP(hipStreamSynchronize(stream()));
+            for (;;) {
+                const bool xcd = p->k2x_state == 1;
+                MFX_HIP(hipMemsetAsync(p->d_counter, 0, sizeof(int), stream()));
+                if (xcd) rc = enqueue_k2x_pass(p, P);
+                else if (graph) {
+                    MFX_HIP(hipGraphLaunch(p->graph2, stream()));
+                    rc = MFX_OK;
+                } else rc = enqueue_k2_epoch(p, P);
+                if (rc) return rc;
+                unsigned status = 0;
+                if (xcd) MFX_HIP(hipMemcpyAsync(&status, p->d_xctl + 512, sizeof(unsigned), hipMemcpyDeviceToHost, stream()));
+                if (xcd && status == 0 && hk) { /* hooks run after the status is known */ }
+                if (!xcd && hk && (rc = hk->post(hk->ctx, dyn.uf, p->ni))) return rc;
+                MFX_HIP(hipMemcpyAsync(&se, p->d_se_epoch, sizeof(double), hipMemcpyDeviceToHost, stream()));
+                MFX_HIP(hipStreamSynchronize(stream()));
+                if (!xcd) break;
+                if (status == 0) {
+                    if (hk) {
+                        if ((rc = hk->post(hk->ctx, dyn.uf, p->ni))) return rc;
+                        MFX_HIP(hipStreamSynchronize(stream()));
+                    }
+                    break;
+                }
+                if (status == 3)
+                    return fail(MFX_E_HIP, "mfx_sgd_run_funk: the XCD-resident pass lost a workgroup mid-pass");
+                // registration failed or LDS too small: nothing was modified -- use the launch path from here on
+                p->k2x_state = -1;
+            }
             if (hk && (rc = hk->global_se(hk->ctx, &se, &nn))) return rc;
             rmse = sqrt(se / nn);
             if (rmse_hist && nh < hist_cap) rmse_hist[nh] = rmse;

@@ -623,6 +623,180 @@ __global__ __launch_bounds__(kTail2) void k2_tail(K2Params P, const int64_t *lev
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K2, XCD-resident form: ONE persistent launch per (feature, epoch) pass that runs on a SINGLE XCD.
+//
+// A pass is a chain of dependency levels of a few thousand scalar updates each; with a launch per level it
+// costs ~3.4 us per level whatever the level's size.  The two feature vectors U[f,:] + V[f,:] are ~1 MB:
+// inside ONE XCD the L2 is the coherence point (plain stores stay there, sc1 loads bypass the CU's L1),
+// so a level hand-off costs L2 round trips instead of a kernel boundary.  Users are cut into kXGroups
+// groups; a workgroup keeps its groups' slice of V[f,:] in LDS for the whole pass (a user's ratings all
+// belong to one workgroup), only the item side travels through L2; the ratings of a level are ordered
+// (group, item) (mfx_schedule_dev.hip: levels_group_sort).  Workgroup = 1 sync wave + kXWorkers worker
+// waves; flat barrier: every workgroup stores its flag (own 128-B line), every sync wave polls all flags.
+// Measured (tools/k2_xcd.hip, cfg 2): 2.2 us per level against 3.4; per-rating tagged hand-offs instead
+// of the barrier: 2.9-3.6 us (poll storms), both vectors through L2: 2.5-3.5 us.
+// The 256 launched workgroups register by XCC id, the XCD with the most is chosen, the others leave.
+// Nothing is modified before every participant has passed a first barrier: a failed registration (grid
+// not co-resident, LDS too small) leaves the data untouched and the host falls back to the launch path.
+static constexpr int kXWorkers = 15;
+static constexpr int kXGroups = 32;
+static constexpr unsigned kXSpinSetup = 1u << 22;     // ~1 s: registration / first barrier
+static constexpr unsigned kXSpinRun = 0x7fffffffu;    // minutes: only a lost workgroup ends here
+
+struct K2XParams {
+    const Rec *recs;
+    const K2Dyn *dyn;
+    const double *cache;
+    const double *ib;          // nullable (without_bias)
+    const double *ub;
+    const int32_t *seg_off;    // [n_levels * kXGroups + 1]
+    double *se_partial;        // slot of a chunk starting at position tb of segment q: (tb >> 6) + q
+    unsigned *ctl;             // [x*32] registrations of XCD x, [512] status, [1024 + slot*32] flags
+    int n_levels, nu;
+    int lds_doubles;
+    unsigned gen_base;         // flags count up across passes: gen = gen_base + level + 1
+    double lr, K, mu;
+    int upd_u, upd_i;
+};
+
+__device__ __forceinline__ unsigned ld_sc1_u32(const unsigned *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__((kXWorkers + 1) * 64) void k2_xcd_pass(K2XParams P)
+{
+    extern __shared__ double vlds[];           // this workgroup's slices of vf
+    __shared__ unsigned sh[6];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    // ---- registration ------------------------------------------------------------------------
+    if (threadIdx.x == 0) {
+        unsigned x;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+        x &= 7u;
+        const unsigned slot = atomicAdd(P.ctl + x * 32, 1u);
+        unsigned spins = 0, cnt[8], tot = 0;
+        bool ok = true;
+        for (;;) {
+            tot = 0;
+            for (int y = 0; y < 8; ++y) { cnt[y] = ld_sc1_u32(P.ctl + y * 32); tot += cnt[y]; }
+            if (tot >= gridDim.x) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kXSpinSetup || ld_sc1_u32(P.ctl + 512)) { ok = false; break; }
+        }
+        unsigned best = 0;
+        for (int y = 1; y < 8; ++y) if (cnt[y] > cnt[best]) best = y;
+        if (!ok) atomicExch(P.ctl + 512, 1u);
+        sh[0] = x; sh[1] = slot; sh[2] = cnt[best]; sh[3] = ok ? 1u : 0u; sh[4] = best;
+    }
+    __syncthreads();
+    if (!sh[3] || sh[0] != sh[4]) return;               // not on the chosen XCD (or failed): leave
+    const unsigned slot = sh[1], nx = sh[2] > 64 ? 64 : sh[2];
+    if (slot >= nx) return;
+    unsigned *flags = P.ctl + 1024;
+    double *const uf = P.dyn->uf, *const vf = P.dyn->vf;
+    const double trail = P.dyn->trail, lr = P.lr, K = P.K;
+    const int NG = kXGroups, nu = P.nu;
+    auto glo = [nu](int g) { return (int)(((int64_t)nu * g + kXGroups - 1) / kXGroups); };   // first user of group g
+    // (group(u) = u * NG / nu  <=>  u in [ceil(nu * g / NG), ceil(nu * (g+1) / NG)))
+
+    // my groups' user slices -> LDS (groups slot, slot + nx, ...)
+    int need = 0;
+    for (int g = slot; g < NG; g += nx) need += glo(g + 1) - glo(g);
+    if (need > P.lds_doubles) {                          // uniform over the workgroup
+        if (threadIdx.x == 0) atomicExch(P.ctl + 512, 2u);
+        return;
+    }
+    {
+        int base = 0;
+        for (int g = slot; g < NG; g += nx) {
+            const int lo = glo(g), n = glo(g + 1) - lo;
+            for (int i = threadIdx.x; i < n; i += (kXWorkers + 1) * 64) vlds[base + i] = vf[lo + i];
+            base += n;
+        }
+    }
+    const int worker = wid - 1;                          // -1 = the sync wave
+    // barrier(gen): A = my workgroup is done, flag, poll everybody's flag, B
+    auto barrier = [&](unsigned gen, unsigned limit) -> bool {
+        __syncthreads();
+        if (worker < 0) {
+            if (lane == 0) flags[slot * 32] = gen;       // plain store: stays in this XCD's L2
+            unsigned spins = 0;
+            for (;;) {
+                const bool ok = lane >= (int)nx || (int)(ld_sc1_u32(flags + lane * 32) - gen) >= 0;
+                if (__all(ok)) break;
+                if (++spins > limit || ld_sc1_u32(P.ctl + 512)) {
+                    if (lane == 0) atomicExch(P.ctl + 512, limit == kXSpinSetup ? 1u : 3u);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        return ld_sc1_u32(P.ctl + 512) == 0;
+    };
+    if (!barrier(P.gen_base, kXSpinSetup)) return;      // nothing has been modified yet
+
+    // records and cache words do not depend on the updates: the first chunk of the NEXT level is requested
+    // before the barrier
+    Rec nrec; nrec.user = 0; nrec.item = 0; nrec.r = 0.0;
+    double ncache = 0.0;
+    if (worker >= 0 && P.n_levels > 0 && (int)slot < NG) {
+        const int tb = P.seg_off[slot] + worker * 64, s1 = P.seg_off[slot + 1];
+        if (tb + lane < s1) { nrec = P.recs[tb + lane]; ncache = P.cache[tb + lane]; }
+    }
+    for (int l = 0; l < P.n_levels; ++l) {
+        if (worker >= 0) {
+            int base = 0;
+            bool first = true;
+            for (int g = slot; g < NG; g += nx) {
+                const int lo = glo(g);
+                const int q = l * NG + g;
+                const int s0 = P.seg_off[q], s1 = P.seg_off[q + 1];
+                for (int tb = s0 + worker * 64; tb < s1; tb += kXWorkers * 64) {      // wave-uniform
+                    const int t = tb + lane;
+                    double e2 = 0.0;
+                    if (t < s1) {
+                        const Rec rec = first ? nrec : P.recs[t];
+                        const double c = first ? ncache : P.cache[t];
+                        double bs;
+                        if (P.ib) bs = P.mu + P.ib[rec.item] + P.ub[rec.user];
+                        else bs = P.mu + 0.0 + 0.0;
+                        const double mf = __hip_atomic_load(uf + rec.item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const double cf = vlds[base + rec.user - lo];
+                        const double p = funk_estimate(mf, cf, c, bs, trail, true);
+                        const double err = rec.r - p;
+                        e2 = err * err;
+                        if (P.upd_i) uf[rec.item] = mf + lr * (err * cf - K * mf);
+                        if (P.upd_u) vlds[base + rec.user - lo] = cf + lr * (err * mf - K * cf);
+                    }
+                    first = false;
+                    const double ws = wave_sum_fixed(e2);
+                    if (lane == 0) P.se_partial[(tb >> 6) + q] = ws;
+                }
+                first = false;
+                base += glo(g + 1) - lo;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my stores are in L2
+            if (l + 1 < P.n_levels && (int)slot < NG) {
+                const int q = (l + 1) * NG + (int)slot;
+                const int tb = P.seg_off[q] + worker * 64, s1 = P.seg_off[q + 1];
+                if (tb + lane < s1) { nrec = P.recs[tb + lane]; ncache = P.cache[tb + lane]; }
+            }
+        }
+        if (!barrier(P.gen_base + (unsigned)l + 1u, kXSpinRun)) return;
+    }
+    // LDS slices back to V[f,:]
+    if (P.upd_u) {
+        int base = 0;
+        for (int g = slot; g < NG; g += nx) {
+            const int lo = glo(g), n = glo(g + 1) - lo;
+            for (int i = threadIdx.x; i < n; i += (kXWorkers + 1) * 64) vf[lo + i] = vlds[base + i];
+            base += n;
+        }
+    }
+}
+
 // cache-commit pass (gd_estimator.pyx:771-777): embarrassingly parallel over all ratings
 __global__ __launch_bounds__(256) void k2_commit(K2Params P, int64_t nnz)
 {

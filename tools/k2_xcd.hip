@@ -221,6 +221,117 @@ __global__ __launch_bounds__((W + 1) * 64) void k2_xcd_pass(XParams P)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Variants 4 / 5: no barrier at all.  Every feature-vector element travels as a 16-byte granule
+// {value, tag}; tag = pass << 32 | number of updates the element has received in this pass.  A rating knows
+// (from the schedule) how many updates of its item / its user precede it, polls the two granules until
+// the tags say so, and publishes its own results with ONE 16-byte store each.  The first rating of an
+// element in a pass reads the plain array (settled at the kernel boundary), the last one also writes it.
+//   4: workgroups on ALL XCDs, granules stored write-through (sc1), read sc1
+//   5: one XCD (registration as above), granules stored plain (stay in that XCD's L2), read sc1
+struct Gran { double v; unsigned long long tag; };
+__device__ __forceinline__ Gran ld16_sc1(const Gran *p)
+{
+    typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+    v4u32 r;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+    return __builtin_bit_cast(Gran, r);
+}
+__device__ __forceinline__ void st16_sc1(Gran *p, Gran g)
+{
+    typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+    const v4u32 v = __builtin_bit_cast(v4u32, g);
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+struct DParams {
+    const Rec *recs;
+    const double *cache;
+    const int2 *seq;            // per rating: .x = updates of its user before it (bit 31: it is the last), .y = same for its item
+    double *uf, *vf;            // plain arrays
+    Gran *ug, *vg;              // granule arrays
+    const int *level_off;
+    double *se_partial;
+    unsigned *ctl;
+    int n_levels;
+    unsigned pass;
+    double lr, K, mu, trail;
+};
+template <int VARIANT>
+__global__ __launch_bounds__(256) void k2_flow_pass(DParams P)
+{
+    __shared__ unsigned sh[6];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    unsigned slot = blockIdx.x, nx = gridDim.x;
+    if constexpr (VARIANT == 5) {
+        if (threadIdx.x == 0) {
+            unsigned x;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+            x &= 7u;
+            const unsigned sl = atomicAdd(P.ctl + x * 32, 1u);
+            unsigned spins = 0, cnt[8], tot = 0;
+            bool ok = true;
+            for (;;) {
+                tot = 0;
+                for (int y = 0; y < 8; ++y) { cnt[y] = ld_sc1_u32(P.ctl + y * 32); tot += cnt[y]; }
+                if (tot >= gridDim.x) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > SPIN_LIMIT) { ok = false; break; }
+            }
+            unsigned best = 0;
+            for (int y = 1; y < 8; ++y) if (cnt[y] > cnt[best]) best = y;
+            if (!ok) atomicExch(P.ctl + 512, 1u);
+            sh[0] = x; sh[1] = sl; sh[2] = cnt[best]; sh[3] = ok ? 1u : 0u; sh[4] = best;
+        }
+        __syncthreads();
+        if (!sh[3] || sh[0] != sh[4]) return;
+        slot = sh[1]; nx = sh[2];
+    }
+    const int nw = (int)nx * 4, w = (int)slot * 4 + wid;
+    const unsigned long long hi = (unsigned long long)P.pass << 32;
+    const double lr = P.lr, K = P.K, trail = P.trail;
+    for (int l = 0; l < P.n_levels; ++l) {
+        const int s0 = P.level_off[l], s1 = P.level_off[l + 1];
+        for (int t0 = s0 + w * 64; t0 < s1; t0 += nw * 64) {
+            const int t = t0 + lane;
+            double e2 = 0.0;
+            if (t < s1) {
+                const Rec rec = P.recs[t];
+                const double c = P.cache[t];
+                const int2 sq = P.seq[t];
+                const unsigned useq = (unsigned)sq.x & 0x7fffffffu, iseq = (unsigned)sq.y & 0x7fffffffu;
+                double mf = 0.0, cf = 0.0;
+                bool need_i = iseq != 0, need_u = useq != 0;
+                if (!need_i) mf = P.uf[rec.item];
+                if (!need_u) cf = P.vf[rec.user];
+                unsigned spins = 0;
+                while (need_i || need_u) {
+                    if (need_i) {
+                        const Gran g = ld16_sc1(P.ug + rec.item);
+                        if (g.tag == (hi | iseq)) { mf = g.v; need_i = false; }
+                    }
+                    if (need_u) {
+                        const Gran g = ld16_sc1(P.vg + rec.user);
+                        if (g.tag == (hi | useq)) { cf = g.v; need_u = false; }
+                    }
+                    if (++spins > SPIN_LIMIT) { atomicExch(P.ctl + 512, 3u); break; }
+                }
+                const double p = funk_estimate(mf, cf, c, P.mu + 0.0 + 0.0, trail, true);
+                const double err = rec.r - p;
+                e2 = err * err;
+                const double un = mf + lr * (err * cf - K * mf), vn = cf + lr * (err * mf - K * cf);
+                const Gran gi{un, hi | (iseq + 1)}, gu{vn, hi | (useq + 1)};
+                if constexpr (VARIANT == 4) { st16_sc1(P.ug + rec.item, gi); st16_sc1(P.vg + rec.user, gu); }
+                else { P.ug[rec.item] = gi; P.vg[rec.user] = gu; }
+                if (sq.y < 0) P.uf[rec.item] = un;
+                if (sq.x < 0) P.vf[rec.user] = vn;
+            }
+            const double ws = wave_sum_fixed(e2);
+            if (lane == 0) P.se_partial[t0 >> 6] = ws;
+        }
+        if (ld_sc1_u32(P.ctl + 512)) return;
+    }
+}
+
 int main(int argc, char **argv)
 {
     const int nu = 100000, ni = 50000;
@@ -247,10 +358,10 @@ int main(int argc, char **argv)
     auto group_of = [&](int u) { int g = (int)((int64_t)u * NG / nu); while (u < glo[g]) --g; while (u >= glo[g + 1]) ++g; return g; };
     std::vector<Rec> recsX = recsA;
     std::vector<int> seg;
-    if (variant == 2 || variant == 3) {
+    if (variant == 2 || variant == 3 || (variant >= 4 && argc > 4 && atoi(argv[4]) == 1)) {      // argv[4] = 1: item-sorted levels
         for (int64_t l = 0; l < n_levels; ++l) {
             auto b = recsX.begin() + off[l], e = recsX.begin() + off[l + 1];
-            if (variant == 2) std::sort(b, e, [](const Rec &a, const Rec &c) { return a.item < c.item; });
+            if (variant != 3) std::sort(b, e, [](const Rec &a, const Rec &c) { return a.item < c.item; });
             else std::sort(b, e, [&](const Rec &a, const Rec &c) { const int ga = group_of(a.user), gc = group_of(c.user); return ga != gc ? ga < gc : a.item < c.item; });
         }
     }
@@ -301,6 +412,44 @@ int main(int argc, char **argv)
             if (ps == passes - 1) { CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms_ref, e0, e1)); }
         }
         CK(hipDeviceSynchronize());
+    }
+    if (variant == 4 || variant == 5) {
+        std::vector<int2> seq((size_t)nnz);
+        std::vector<int> uc(nu, 0), ic(ni, 0), ulast(nu, -1), ilast(ni, -1);
+        for (int64_t j = 0; j < nnz; ++j) {
+            const Rec &q = recsX[j];
+            seq[j].x = uc[q.user]++; seq[j].y = ic[q.item]++;
+            ulast[q.user] = (int)j; ilast[q.item] = (int)j;
+        }
+        for (int u = 0; u < nu; ++u) if (ulast[u] >= 0) seq[ulast[u]].x |= (int)0x80000000;
+        for (int i = 0; i < ni; ++i) if (ilast[i] >= 0) seq[ilast[i]].y |= (int)0x80000000;
+        int2 *d_seq; Gran *d_ug, *d_vg;
+        CK(hipMalloc(&d_seq, nnz * sizeof(int2))); CK(hipMalloc(&d_ug, ni * sizeof(Gran))); CK(hipMalloc(&d_vg, nu * sizeof(Gran)));
+        CK(hipMemcpy(d_seq, seq.data(), nnz * sizeof(int2), hipMemcpyHostToDevice));
+        CK(hipMemset(d_ug, 0, ni * sizeof(Gran))); CK(hipMemset(d_vg, 0, nu * sizeof(Gran)));
+        DParams D{}; D.recs = dX; D.cache = dcX; D.seq = d_seq; D.uf = duf[1]; D.vf = dvf[1]; D.ug = d_ug; D.vg = d_vg; D.level_off = d_seg;
+        D.se_partial = d_se; D.ctl = d_ctl; D.n_levels = (int)n_levels; D.lr = lr; D.K = K; D.mu = mu; D.trail = trail;
+        void *fn = variant == 4 ? (void *)k2_flow_pass<4> : (void *)k2_flow_pass<5>;
+        unsigned err = 0;
+        for (int ps = 0; ps < passes && !err; ++ps) {
+            CK(hipMemsetAsync(d_ctl, 0, 8192 * 4));
+            D.pass = (unsigned)(ps + 1);
+            if (ps == passes - 1) CK(hipEventRecord(e0));
+            void *args[] = {&D};
+            CK(hipLaunchKernel(fn, dim3(grid), dim3(256), args, 0, 0));
+            if (ps == passes - 1) { CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms_x, e0, e1)); }
+            CK(hipMemcpy(&err, d_ctl + 512, 4, hipMemcpyDeviceToHost));
+        }
+        CK(hipDeviceSynchronize());
+        std::vector<double> a(ni), b(ni), c(nu), d(nu);
+        CK(hipMemcpy(a.data(), duf[0], ni * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), duf[1], ni * 8, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(c.data(), dvf[0], nu * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(d.data(), dvf[1], nu * 8, hipMemcpyDeviceToHost));
+        size_t du = 0, dv = 0;
+        for (int i = 0; i < ni; ++i) du += memcmp(&a[i], &b[i], 8) != 0;
+        for (int i = 0; i < nu; ++i) dv += memcmp(&c[i], &d[i], 8) != 0;
+        printf("K2 pass: level-per-launch %.3f ms = %.2f G scalar-updates/s | tagged dataflow (variant %d, grid %d): %.3f ms = %.2f G/s = %.2f us per level | error %u | differing uf %zu vf %zu\n",
+               ms_ref, nnz / ms_ref / 1e6, variant, grid, ms_x, nnz / ms_x / 1e6, ms_x * 1e3 / n_levels, err, du, dv);
+        return (err || du || dv) ? 2 : 0;
     }
     XParams X{}; X.recs = dX; X.cache = dcX; X.uf = duf[1]; X.vf = dvf[1]; X.seg_off = d_seg; X.group_lo = d_glo; X.se_partial = d_se; X.ctl = d_ctl;
     X.n_levels = (int)n_levels; X.lr = lr; X.K = K; X.mu = mu; X.trail = trail;

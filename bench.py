@@ -305,9 +305,11 @@ def also_funk(idx, r, nu, ni, k, order, epochs_per_feature=2):
         with Timer() as tm:
             hist = p.run_funk(epochs_per_feature, 1e9, FUNK_INIT, FUNK_LR, FUNK_K)
         info = p.info()
+        kname = p.kernel_name(3)
     n = len(hist)
     rate = nnz * n / (tm.ms * 1e-3)
-    launches = info["funk_launches_per_epoch"]
+    xcd = kname.startswith("k2_xcd_pass")
+    launches = 1 if xcd else info["funk_launches_per_epoch"]
     ms_pass = tm.ms / n
     # algorithmic bytes: 24 B per scalar update (16-B record + 8-B cache word)
     return {"value": rate, "unit": "scalar-updates/s", "row_equivalents_per_s": rate / k,
@@ -316,8 +318,9 @@ def also_funk(idx, r, nu, ni, k, order, epochs_per_feature=2):
             "workload": "cfg2 shape, %s order, k=%d features x %d epochs each + cache-commit passes "
                         "(estimator_loop_without_bias), exact level schedule" % (order, k, epochs_per_feature),
             "roofline": {"bound": "hbm", "achieved": rate * 24 / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": rate * 24 / HBM_PEAK, "bytes_per_scalar_update": 24, "kernel": "k2_level",
-                         "avg_launch_us": ms_pass * 1e3 / max(launches, 1), "traffic": None}}
+                         "frac": rate * 24 / HBM_PEAK, "bytes_per_scalar_update": 24, "kernel": kname,
+                         "avg_launch_us": ms_pass * 1e3 / max(launches, 1),
+                         "us_per_level": ms_pass * 1e3 / max(info["n_levels"], 1), "traffic": None}}
 
 
 def also_als(idx3, nu, ni, k):

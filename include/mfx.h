@@ -189,7 +189,9 @@ void mfx_sgd_plan_destroy(mfx_sgd_plan *p);
  * [7]=launches per epoch (Funk) */
 int mfx_sgd_plan_info(const mfx_sgd_plan *p, int64_t info[8]);
 /* Name of the k1_level instantiation this plan launches for `mode` (0 linear, 1 logistic, 2 learned
- * bias): "k1_level<lanes per rating,features per lane,ratings per wave,access form,mode>". */
+ * bias): "k1_level<lanes per rating,features per lane,ratings per wave,access form,mode>"; mode 3: the
+ * kernel of the Funk pass ("k2_xcd_pass<...>", the single-XCD persistent pass chosen for large levels,
+ * or "k2_level<...>", one launch per level). */
 int mfx_sgd_plan_kernel_name(const mfx_sgd_plan *p, int mode, char *buf, int buflen);
 /* Storage type of the factor rows inside the plan: 64 (default; exact) or 32 -- "f32 storage,
  * f64 arithmetic" fast mode of the full-k kernels: rows are widened on load and rounded once on

@@ -723,7 +723,12 @@ int mfx_sgd_plan_info(const mfx_sgd_plan *p, int64_t info[8])
 
 int mfx_sgd_plan_kernel_name(const mfx_sgd_plan *p, int mode, char *buf, int buflen)
 {
-    if (!p || !buf || buflen < 1 || mode < 0 || mode > 2) return fail(MFX_E_ARG, "mfx_sgd_plan_kernel_name: bad argument");
+    if (!p || !buf || buflen < 1 || mode < 0 || mode > 3) return fail(MFX_E_ARG, "mfx_sgd_plan_kernel_name: bad argument");
+    if (mode == 3) {                      // the Funk pass: known once a Funk run has decided
+        if (p->k2x_state == 1) snprintf(buf, (size_t)buflen, "k2_xcd_pass<%d worker waves,%d user groups>", kXWorkers, kXGroups);
+        else snprintf(buf, (size_t)buflen, "k2_level<%d threads>%s", kK2Block, p->k2x_state == 0 ? " (undecided: no Funk run yet)" : "");
+        return MFX_OK;
+    }
     static const char *const mode_name[] = {"linear", "logistic", "learned"};
     snprintf(buf, (size_t)buflen, "k1_level<%s,%s%s>", k1_select<false>(p->k, mode, p->batch, p->f32, p->dot).tag,
              mode_name[mode], p->f32 ? ",f32" : "");
@@ -905,8 +910,9 @@ static int enqueue_k2x_pass(mfx_sgd_plan *p, const K2Params &P)
     X.gen_base = p->x_gen;
     X.lr = P.lr; X.K = P.K; X.mu = P.mu; X.upd_u = P.upd_u; X.upd_i = P.upd_i;
     p->x_gen += (unsigned)p->n_levels + 1u;
-    // registration counters + status are cleared per pass; the flags keep counting
-    MFX_HIP(hipMemsetAsync(p->d_xctl, 0, 1024 * sizeof(unsigned), stream()));
+    // the registration counters are cleared per pass (the status word per batch, by the caller); the flags
+    // keep counting
+    MFX_HIP(hipMemsetAsync(p->d_xctl, 0, 256 * sizeof(unsigned), stream()));
     void *args[] = {&X};
     // one workgroup per CU: 256 launched, those on the chosen XCD stay
     MFX_HIP(hipLaunchKernel((const void *)k2_xcd_pass, dim3(256), dim3((kXWorkers + 1) * 64), args,
@@ -980,23 +986,34 @@ int funk_core(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_
         int epoch = 0;
         while (epoch < min_epochs || rmse <= rmse_last - min_improvement) {
             if (epoch_cap > 0 && epoch >= epoch_cap) break;
-            rmse_last = rmse;
-            if (hk && (rc = hk->pre(hk->ctx, dyn.uf, p->ni))) return rc;
-            double se = 0.0, nn = (double)p->nnz;
+            // Epochs below min_epochs run whatever their rmse turns out to be: they are enqueued back to
+            // back and their squared errors read together (one host round trip per batch, not per epoch).
+            // The sharded mode (hooks) combines and decides after every epoch.
+            int batch = 1;
+            if (!hk && epoch < min_epochs) {
+                batch = min_epochs - epoch;
+                if (epoch_cap > 0 && batch > epoch_cap - epoch) batch = epoch_cap - epoch;
+                if (batch > 32) batch = 32;
+            }
+            double se_b[32];
+            double nn = (double)p->nnz;
             for (;;) {
                 const bool xcd = p->k2x_state == 1;
                 MFX_HIP(hipMemsetAsync(p->d_counter, 0, sizeof(int), stream()));
-                if (xcd) rc = enqueue_k2x_pass(p, P);
-                else if (graph) {
-                    MFX_HIP(hipGraphLaunch(p->graph2, stream()));
-                    rc = MFX_OK;
-                } else rc = enqueue_k2_epoch(p, P);
-                if (rc) return rc;
+                if (xcd) MFX_HIP(hipMemsetAsync(p->d_xctl + 512, 0, sizeof(unsigned), stream()));   // status: sticky inside a batch
+                for (int b = 0; b < batch; ++b) {
+                    if (hk && (rc = hk->pre(hk->ctx, dyn.uf, p->ni))) return rc;
+                    if (xcd) rc = enqueue_k2x_pass(p, P);
+                    else if (graph) {
+                        MFX_HIP(hipGraphLaunch(p->graph2, stream()));
+                        rc = MFX_OK;
+                    } else rc = enqueue_k2_epoch(p, P);
+                    if (rc) return rc;
+                }
                 unsigned status = 0;
                 if (xcd) MFX_HIP(hipMemcpyAsync(&status, p->d_xctl + 512, sizeof(unsigned), hipMemcpyDeviceToHost, stream()));
-                if (xcd && status == 0 && hk) { /* hooks run after the status is known */ }
                 if (!xcd && hk && (rc = hk->post(hk->ctx, dyn.uf, p->ni))) return rc;
-                MFX_HIP(hipMemcpyAsync(&se, p->d_se_epoch, sizeof(double), hipMemcpyDeviceToHost, stream()));
+                MFX_HIP(hipMemcpyAsync(se_b, p->d_se_epoch, (size_t)batch * sizeof(double), hipMemcpyDeviceToHost, stream()));
                 MFX_HIP(hipStreamSynchronize(stream()));
                 if (!xcd) break;
                 if (status == 0) {
@@ -1008,14 +1025,19 @@ int funk_core(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_
                 }
                 if (status == 3)
                     return fail(MFX_E_HIP, "mfx_sgd_run_funk: the XCD-resident pass lost a workgroup mid-pass");
-                // registration failed or LDS too small: nothing was modified -- use the launch path from here on
+                // registration failed or LDS too small: NOTHING was modified (the status is sticky: the later
+                // passes of the batch left at once) -- redo the batch on the launch path, and stay there
                 p->k2x_state = -1;
             }
-            if (hk && (rc = hk->global_se(hk->ctx, &se, &nn))) return rc;
-            rmse = sqrt(se / nn);
-            if (rmse_hist && nh < hist_cap) rmse_hist[nh] = rmse;
-            ++nh;
-            ++epoch;
+            for (int b = 0; b < batch; ++b) {
+                double se = se_b[b];
+                if (hk && (rc = hk->global_se(hk->ctx, &se, &nn))) return rc;
+                rmse_last = rmse;
+                rmse = sqrt(se / nn);
+                if (rmse_hist && nh < hist_cap) rmse_hist[nh] = rmse;
+                ++nh;
+                ++epoch;
+            }
         }
         hipLaunchKernelGGL(k2_commit, dim3(commit_blocks), dim3(256), 0, stream(), P, p->nnz);
         MFX_HIP(hipGetLastError());

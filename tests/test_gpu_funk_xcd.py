@@ -81,7 +81,7 @@ def test_large_levels_take_the_xcd_path_by_default(monkeypatch):
     monkeypatch.delenv("MFX_K2_XCD")
     from mfrec_amd.plan import SgdPlan, Timer
     from oracle import oracle as O
-    nu, ni, nnz, k = 20000, 10000, 5000000, 2          # ~1100 levels of ~4.5 K ratings
+    nu, ni, nnz, k = 60000, 12000, 8000000, 2          # ~1200 levels of ~6.5 K ratings
     idx, r = synth.make_ratings(nu, ni, nnz, seed=4)
     u, v = synth.init_const(k, ni), synth.init_const(k, nu)
     with SgdPlan(idx, r, nu, ni, k) as p:

@@ -890,6 +890,266 @@ __global__ __launch_bounds__(256, OCC) void k_als_rows3(const double *__restrict
     }
 }
 
+// ------------------------------------------------------------------------------------
+// k > 128 (als_implicit.pyx:211-225 takes any dim): the same algorithm with the bordered matrix
+// [A; b^T] in a per-workgroup GLOBAL scratch slot (L2 resident: (KP+1) x (KP+2) doubles) instead of
+// LDS / registers, KP a run-time multiple of 16.  Y_N^T Y_N is accumulated on the matrix cores in
+// ROUNDS of 8 tiles per wave (the neighbour chunks are re-streamed every round), the blocked
+// Cholesky and the blocked back substitution walk the scratch with workgroup barriers in between.
+// A fallback, far from the tuned kernels' speed -- but a legal argument is served, not refused.
+// ------------------------------------------------------------------------------------
+constexpr int BIG_NW = 8;              // waves per workgroup
+constexpr int BIG_TPR = 8;             // tiles per wave per accumulation round
+constexpr int BIG_CH = 16;             // neighbour rows per LDS chunk
+constexpr int kBigMaxK = 512;
+
+// partial[slab][KP*KP] of G = Y^T Y: one block per (tile, slab), operands straight from global
+__global__ __launch_bounds__(256) void k_gram_big(const double *__restrict__ Y, int ny, int k, int KP,
+                                                  int rows_per_slab, double *partial)
+{
+    __shared__ double red[3][64][4];
+    const int NT = KP / 16;
+    const int I = blockIdx.x / NT, J = blockIdx.x % NT;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_slab, r1 = min(ny, r0 + rows_per_slab);
+    const int ca = I * 16 + (lane & 15), cb = J * 16 + (lane & 15);
+    double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+    for (int n0 = r0 + wid * 4; n0 < r1; n0 += 16) {
+        const int row = n0 + (lane >> 4);
+        double a = 0.0, b = 0.0;
+        if (row < r1) {
+            if (ca < k) a = Y[(size_t)row * k + ca];
+            if (cb < k) b = Y[(size_t)row * k + cb];
+        }
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    if (wid > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[wid - 1][lane][q] = acc[q];
+    }
+    __syncthreads();
+    if (wid == 0) {
+        double *out = partial + (size_t)blockIdx.y * KP * KP;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double v = ((acc[q] + red[0][lane][q]) + red[1][lane][q]) + red[2][lane][q];
+            out[(I * 16 + (lane >> 4) + 4 * q) * KP + J * 16 + (lane & 15)] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * BIG_NW) void k_als_rows_big(const double *__restrict__ Y, int k, int KP,
+                                                             const double *__restrict__ G,
+                                                             const int64_t *__restrict__ off,
+                                                             const int32_t *__restrict__ col, double c_pos,
+                                                             double one_plus_c, double lambda, double *X,
+                                                             int *status, double *scratch, int n_rows)
+{
+    constexpr int NW = BIG_NW, NTHR = 64 * BIG_NW;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int NT = KP / 16, LD = KP + 2, S = ych_stride(KP);
+    double *ych = lds;                               // [BIG_CH][S]
+    double *dinv = ych + BIG_CH * S;                 // [KP]
+    double *z = dinv + KP;                           // [KP] right-hand side / solution
+    double *dblk = z + KP;                           // [16][17] current diagonal block
+    int *cidx = (int *)(dblk + 16 * 17);             // [BIG_CH]
+    int *bad = cidx + BIG_CH;
+    double *A = scratch + (size_t)blockIdx.x * (size_t)(KP + 1) * LD;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int NTT = NT * (NT + 1) / 2;
+
+    for (int j = blockIdx.x; j < n_rows; j += gridDim.x) {
+        const int64_t start = off[j];
+        const int span = (int)(off[j + 1] - start);
+        double *xrow = X + (size_t)j * k;
+        if (span == 0) {                             // b = 0 => x = 0 (als_implicit.pyx:298-302)
+            for (int f = tid; f < k; f += NTHR) xrow[f] = 0.0;
+            continue;
+        }
+        if (tid == 0) *bad = 0;
+        // ---- A = G + c * Y_N^T Y_N + lambda I, b: rounds of NW * BIG_TPR tiles ----------------
+        const int nchunks = (span + BIG_CH - 1) / BIG_CH;
+        double bsum = 0.0;
+        for (int t0 = 0; t0 < NTT; t0 += NW * BIG_TPR) {
+            int tI[BIG_TPR], tJ[BIG_TPR];
+            double4_t acc[BIG_TPR];
+#pragma unroll
+            for (int t = 0; t < BIG_TPR; ++t) {
+                tI[t] = 0; tJ[t] = 0;
+                const int tt = t0 + t * NW + wid;
+                if (tt < NTT) tile_ij(tt, tI[t], tJ[t]);
+                acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+            }
+            for (int c = 0; c < nchunks; ++c) {
+                __syncthreads();                     // the previous chunk's readers are done
+                if (tid < BIG_CH) cidx[tid] = (c * BIG_CH + tid < span) ? col[start + c * BIG_CH + tid] : -1;
+                __syncthreads();
+                for (int e = tid; e < BIG_CH * KP; e += NTHR) {
+                    const int n = e / KP, f = e % KP;
+                    const int id = cidx[n];
+                    ych[n * S + f] = (id >= 0 && f < k) ? Y[(size_t)id * k + f] : 0.0;
+                }
+                __syncthreads();
+                if (t0 == 0 && tid < KP) {
+#pragma unroll
+                    for (int n = 0; n < BIG_CH; ++n) bsum += ych[n * S + tid] * one_plus_c;
+                }
+#pragma unroll
+                for (int n0 = 0; n0 < BIG_CH; n0 += 4) {
+                    const double *base = ych + (n0 + (lane >> 4)) * S + (lane & 15);
+#pragma unroll
+                    for (int t = 0; t < BIG_TPR; ++t)
+                        if (t0 + t * NW + wid < NTT)
+                            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(base[tI[t] * 16], base[tJ[t] * 16], acc[t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < BIG_TPR; ++t) {
+                if (t0 + t * NW + wid < NTT) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int r = tI[t] * 16 + (lane >> 4) + 4 * q, c = tJ[t] * 16 + (lane & 15);
+                        double a;
+                        if (r < k && c < k) {
+                            a = G[(size_t)r * KP + c] + c_pos * acc[t][q];
+                            if (r == c) a += lambda;
+                        } else {
+                            a = (r == c) ? 1.0 : 0.0;
+                        }
+                        A[(size_t)r * LD + c] = a;
+                    }
+                }
+            }
+        }
+        if (tid < KP) A[(size_t)KP * LD + tid] = (tid < k) ? bsum : 0.0;     // border row = b
+        __syncthreads();
+
+        // ---- blocked Cholesky of the bordered matrix, 16-wide panels ---------------------------
+        for (int Jb = 0; Jb < NT; ++Jb) {
+            const int c0 = Jb * 16;
+            // (a) diagonal block: lane r (< 16) factors row r, pivots broadcast with shuffles
+            if (wid == 0) {
+                const int r = lane & 15;
+                double d[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) d[c] = A[(size_t)(c0 + r) * LD + c0 + c];
+                double myinv = 1.0;
+                bool ok = true;
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) {
+                    const double pj = __shfl(d[jj], jj, 16);          // L-updated pivot
+                    ok = ok && (pj > 0.0);
+                    const double inv = rsqrt_fma(pj);
+                    if (r == jj) myinv = inv;
+                    d[jj] *= inv;                                     // column jj of L (rows >= jj matter)
+#pragma unroll
+                    for (int c = jj + 1; c < 16; ++c) {
+                        const double lc = __shfl(d[jj], c, 16);       // L[c][jj]
+                        d[c] -= d[jj] * lc;
+                    }
+                }
+                if (lane < 16) {
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        if (c <= r) A[(size_t)(c0 + r) * LD + c0 + c] = d[c];
+                        dblk[r * 17 + c] = (c <= r) ? d[c] : 0.0;
+                    }
+                    dinv[c0 + r] = myinv;
+                }
+                if (!ok && lane == 0) *bad = 1;
+            }
+            __syncthreads();
+            // (b) panel: rows below the block and the border row:  X = A21 * L11^{-T}
+            for (int pr = c0 + 16 + tid; pr <= KP; pr += NTHR) {
+                double *prow = A + (size_t)pr * LD + c0;
+                double a[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) a[c] = prow[c];
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) {
+                    double x = a[jj];
+#pragma unroll
+                    for (int m = 0; m < jj; ++m) x -= a[m] * dblk[jj * 17 + m];
+                    a[jj] = x * dinv[c0 + jj];
+                }
+#pragma unroll
+                for (int c = 0; c < 16; ++c) prow[c] = a[c];
+            }
+            __syncthreads();
+            // (c) trailing update: border row (VALU), then the lower tiles on the matrix cores
+            for (int c = c0 + 16 + tid; c < KP; c += NTHR) {
+                double sum = 0.0;
+                const double *crow = A + (size_t)c * LD + c0, *brow = A + (size_t)KP * LD + c0;
+#pragma unroll
+                for (int m = 0; m < 16; ++m) sum += brow[m] * crow[m];
+                A[(size_t)KP * LD + c] -= sum;
+            }
+            const int nt = NT - Jb - 1, ntt = nt * (nt + 1) / 2;
+            for (int tt = wid; tt < ntt; tt += NW) {
+                int I, J2;
+                tile_ij(tt, I, J2);
+                I += Jb + 1;
+                J2 += Jb + 1;
+                double4_t cacc;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    cacc[q] = A[(size_t)(I * 16 + (lane >> 4) + 4 * q) * LD + J2 * 16 + (lane & 15)];
+                const double *pa = A + (size_t)(I * 16 + (lane & 15)) * LD + c0 + (lane >> 4);
+                const double *pb = A + (size_t)(J2 * 16 + (lane & 15)) * LD + c0 + (lane >> 4);
+#pragma unroll
+                for (int s4 = 0; s4 < 16; s4 += 4)
+                    cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[s4], pb[s4], cacc, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    A[(size_t)(I * 16 + (lane >> 4) + 4 * q) * LD + J2 * 16 + (lane & 15)] = cacc[q];
+            }
+            __syncthreads();
+        }
+        if (*bad) {
+            if (tid == 0) atomicExch(status, j + 1);
+            __syncthreads();
+            continue;
+        }
+        // ---- blocked back substitution L^T x = z (z = the border row after the forward sweep) ----
+        for (int c = tid; c < KP; c += NTHR) z[c] = A[(size_t)KP * LD + c];
+        __syncthreads();
+        for (int Jb = NT - 1; Jb >= 0; --Jb) {
+            const int c0 = Jb * 16;
+            if (wid == 0) {
+                // lane m (< 16) owns x_m of the block; 16 dependent steps, broadcast with shuffles
+                const int m = lane & 15;
+                double zm = z[c0 + m];
+                double lcol[16];                                      // L[c0 + jj][c0 + m], jj = 0..15
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) lcol[jj] = (jj > m) ? A[(size_t)(c0 + jj) * LD + c0 + m] : 0.0;
+                const double di = dinv[c0 + m];
+#pragma unroll
+                for (int jj = 15; jj >= 0; --jj) {
+                    const double xj = __shfl(zm * di, jj, 16);       // x_jj is final when its turn comes
+                    if (m == jj) zm = xj;
+                    else if (m < jj) zm -= lcol[jj] * xj;
+                }
+                if (lane < 16) z[c0 + m] = zm;
+            }
+            __syncthreads();
+            for (int r = tid; r < c0; r += NTHR) {
+                double sum = 0.0;
+#pragma unroll
+                for (int m = 0; m < 16; ++m) sum += A[(size_t)(c0 + m) * LD + r] * z[c0 + m];
+                z[r] -= sum;
+            }
+            __syncthreads();
+        }
+        for (int f = tid; f < k; f += NTHR) xrow[f] = z[f];
+        __syncthreads();
+    }
+}
+
+size_t rows_big_lds_bytes(int KP)
+{
+    return ((size_t)BIG_CH * ych_stride(KP) + 2 * (size_t)KP + 16 * 17) * sizeof(double) + (BIG_CH + 2) * sizeof(int);
+}
+
 #ifdef MFX_ALS_STAMPS
 extern "C" int mfx_debug_als_stamps(unsigned long long *out)
 {
@@ -998,6 +1258,58 @@ struct DevBuf {
 
 constexpr int kGramBlocks = 512;
 
+constexpr int kBigSlabs = 64;
+double *g_big_scratch = nullptr;       // per-workgroup bordered matrices of the k > 128 path (one call at a time)
+size_t g_big_scratch_bytes = 0;
+
+// the k > 128 half-epoch: k_gram_big + k_als_rows_big (persistent over rows, global scratch)
+int als_half_big(int k, int KP, const double *dY, int ny, double *dX, const int64_t *d_off, int64_t n_active,
+                 const int32_t *d_col, int c_pos, double lambda, double *d_partial, double *dG, int *d_status,
+                 int rank, int world, bool gather)
+{
+    hipStream_t s = mfx::stream();
+    const int NT = KP / 16;
+    {
+        int slabs = ny < kBigSlabs * 64 ? ceil_div(ny, 64) : kBigSlabs;
+        if (slabs < 1) slabs = 1;
+        const int rps = ceil_div(ny, slabs);
+        hipLaunchKernelGGL(k_gram_big, dim3(NT * NT, slabs), dim3(256), 0, s, dY, ny, k, KP, rps, d_partial);
+        hipLaunchKernelGGL(k_gram_reduce, dim3(ceil_div(KP * KP, 256)), dim3(256), 0, s, d_partial, slabs, KP * KP, dG);
+        MFX_HIP(hipGetLastError());
+    }
+    if (n_active <= 0) return MFX_OK;
+    const size_t lds = rows_big_lds_bytes(KP);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)k_als_rows_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int64_t B = ceil_div(n_active, (int64_t)world);
+    const int r_first = rank < 0 ? 0 : rank, r_last = rank < 0 ? world - 1 : rank;
+    for (int rr = r_first; rr <= r_last; ++rr) {
+        const int64_t lo = (int64_t)rr * B < n_active ? (int64_t)rr * B : n_active;
+        const int64_t hi = lo + B < n_active ? lo + B : n_active;
+        if (hi <= lo) continue;
+        const int n = (int)(hi - lo);
+        const int grid = n < 512 ? n : 512;
+        const size_t need = (size_t)grid * (size_t)(KP + 1) * (KP + 2) * sizeof(double);
+        if (need > g_big_scratch_bytes) {
+            if (g_big_scratch) (void)hipFree(g_big_scratch);
+            g_big_scratch = nullptr;
+            g_big_scratch_bytes = 0;
+            if (hipMalloc((void **)&g_big_scratch, need) != hipSuccess)
+                return mfx::fail(MFX_E_NOMEM, "mfx_als_wrmf: %zu bytes of scratch for k = %d", need, k);
+            g_big_scratch_bytes = need;
+        }
+        hipLaunchKernelGGL(k_als_rows_big, dim3(grid), dim3(64 * BIG_NW), lds, s, dY, k, KP, (const double *)dG,
+                           d_off + lo, d_col, (double)c_pos, (double)(1 + c_pos), lambda, dX + (size_t)lo * k, d_status,
+                           g_big_scratch, n);
+        MFX_HIP(hipGetLastError());
+    }
+    if (gather) {
+        int rc = mfx::comm_allgather_f64(dX, (size_t)B * k);
+        if (rc) return rc;
+    }
+    return MFX_OK;
+}
+
 // one half-epoch: solve X (n_active rows) from Y
 // rank/world: this process solves rows [rank*B, (rank+1)*B) with B = ceil(n_active / world) and
 // the slices are all-gathered in place (dX has room for world*B rows); world == 1: all rows.
@@ -1008,6 +1320,8 @@ int als_half(int k, int NT, const AlsKernels &K, const double *dY, int ny, doubl
 {
     mfx::TraceRange trace_("mfx:als_half (Gramian + row solves)");
     const int KP = NT * 16;
+    if (NT > 8) return als_half_big(k, KP, dY, ny, dX, d_off, n_active, d_col, c_pos, lambda, d_partial, dG, d_status,
+                                    rank, world, gather);
     hipStream_t s = mfx::stream();
     {   // Gramian over ALL rows of Y (als_implicit.pyx:257-262)
         int blocks = ny < kGramBlocks * CH ? ceil_div(ny, CH) : kGramBlocks;
@@ -1097,9 +1411,9 @@ static int als_wrmf_impl(int nbr_epochs, int dim, double *u, double *v, const in
                          int64_t n_urow, const int32_t *ucol, const int32_t *irow, int64_t n_irow,
                          const int32_t *icol, int nu, int ni, int c_pos, double lambda, bool sharded)
 {
-    if (!u || !v || !urow || !irow || dim < 1 || dim > 128 || nu <= 0 || ni <= 0 || n_urow < 1 ||
+    if (!u || !v || !urow || !irow || dim < 1 || dim > kBigMaxK || nu <= 0 || ni <= 0 || n_urow < 1 ||
         n_irow < 1)
-        return mfx::fail(MFX_E_ARG, "mfx_als_wrmf: bad argument (1 <= k <= 128)");
+        return mfx::fail(MFX_E_ARG, "mfx_als_wrmf: bad argument (1 <= k <= %d)", kBigMaxK);
     int rc = mfx::ensure_init();
     if (rc) return rc;
     if (nbr_epochs <= 0) return MFX_OK;
@@ -1116,7 +1430,7 @@ static int als_wrmf_impl(int nbr_epochs, int dim, double *u, double *v, const in
     if ((nnz_u > 0 && !ucol) || (nnz_i > 0 && !icol)) return mfx::fail(MFX_E_ARG, "mfx_als_wrmf: NULL column array");
 
     const int NT = ceil_div(dim, 16), KP = NT * 16;
-    const AlsKernels K = als_kernels(NT);
+    const AlsKernels K = als_kernels(NT > 8 ? 8 : NT);      // NT > 8: als_half_big, K unused
     const size_t su = (size_t)dim * ni * sizeof(double), sv = (size_t)dim * nu * sizeof(double);
     // sharded: every rank holds full replicas, solves a contiguous slice of the rows of each
     // half-epoch and all-gathers the slices (row solves are independent: same result as 1 GPU)
@@ -1133,7 +1447,7 @@ static int als_wrmf_impl(int nbr_epochs, int dim, double *u, double *v, const in
     if ((rc = dUkm.alloc(su)) || (rc = dVkm.alloc(sv)) || (rc = dU.alloc(su + pad)) || (rc = dV.alloc(sv + pad)) ||
         (rc = dUoff.alloc((nau + 1) * 8)) || (rc = dIoff.alloc((nai + 1) * 8)) ||
         (rc = dUcol.alloc((size_t)nnz_u * 4)) || (rc = dIcol.alloc((size_t)nnz_i * 4)) ||
-        (rc = dPart.alloc((size_t)kGramBlocks * KP * KP * 8)) || (rc = dG.alloc((size_t)KP * KP * 8)) ||
+        (rc = dPart.alloc((size_t)(NT > 8 ? kBigSlabs : kGramBlocks) * KP * KP * 8)) || (rc = dG.alloc((size_t)KP * KP * 8)) ||
         (rc = dStatus.alloc(4)))
         return rc;
     hipStream_t s = mfx::stream();

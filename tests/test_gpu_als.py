@@ -65,6 +65,44 @@ def test_als_vs_oracle(k):
     assert np.abs(u.T @ v - u2.T @ v2).max() < 1e-9
 
 
+# k > 128 (als_implicit.pyx:211-225 takes any dim): the global-scratch kernel k_als_rows_big, NT = 9..32,
+# ragged k, several accumulation rounds (k >= 176 needs more than one round of 64 tiles)
+@pytest.mark.parametrize("k", [129, 144, 176, 200, 256, 300, 512])
+def test_als_big_k_vs_oracle(k):
+    from mfrec_amd.lib.als_implicit import als_wrmf
+    from oracle import oracle as O
+    nu, ni = 70, 50
+    urow, ucol, irow, icol = _problem(nu, ni, 1200, 10 + k)
+    rs = np.random.RandomState(k)
+    u0, v0 = rs.normal(0, 0.1, (k, ni)), rs.normal(0, 0.1, (k, nu))
+    u, v = u0.copy(), v0.copy()
+    als_wrmf(2, k, u, v, None, None, urow, ucol, irow, icol, nu, ni, 1, 0.015)
+    u2, v2 = u0.copy(), v0.copy()
+    O.als_wrmf(2, k, u2, v2, None, None, urow, ucol, irow, icol, nu, ni, 1, 0.015)
+    np.testing.assert_allclose(u, u2, rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(v, v2, rtol=1e-7, atol=1e-10)
+    assert np.abs(u.T @ v - u2.T @ v2).max() < 1e-8
+
+
+def test_als_big_k_slices_singular_and_limit(monkeypatch):
+    from mfrec_amd.lib.als_implicit import als_wrmf
+    nu, ni, k = 90, 60, 160
+    urow, ucol, irow, icol = _problem(nu, ni, 1500, 7)
+    rs = np.random.RandomState(1)
+    u0, v0 = rs.normal(0, 0.1, (k, ni)), rs.normal(0, 0.1, (k, nu))
+    u, v = u0.copy(), v0.copy()
+    als_wrmf(1, k, u, v, None, None, urow, ucol, irow, icol, nu, ni)
+    monkeypatch.setenv("MFX_ALS_FAKE_WORLD", "3")                 # the sharded row slices, one GPU
+    u2, v2 = u0.copy(), v0.copy()
+    als_wrmf(1, k, u2, v2, None, None, urow, ucol, irow, icol, nu, ni)
+    assert np.array_equal(u, u2) and np.array_equal(v, v2)
+    monkeypatch.delenv("MFX_ALS_FAKE_WORLD")
+    with pytest.raises(np.linalg.LinAlgError, match="not positive definite"):
+        als_wrmf(1, k, np.zeros((k, ni)), np.zeros((k, nu)), None, None, urow, ucol, irow, icol, nu, ni, 1, 0.0)
+    with pytest.raises(ValueError, match="1 <= k <= 512"):
+        als_wrmf(1, 513, np.zeros((513, ni)), np.zeros((513, nu)), None, None, urow, ucol, irow, icol, nu, ni)
+
+
 def test_als_c_pos_and_lambda():
     from mfrec_amd.lib.als_implicit import als_wrmf
     from oracle import oracle as O

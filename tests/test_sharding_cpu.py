@@ -148,11 +148,28 @@ def test_file_rendezvous_delivers_the_unique_id(tmp_path):
         assert p.wait(timeout=120) == 0
     for rank in range(3):
         assert open(out % rank, "rb").read() == bytes(range(128))
+    # cleanup is keyed by (user, parent pid, port, run id, restart count): from this process the parent pid
+    # differs, so remove the workers' directory by pattern
+    import glob, shutil, tempfile
     from mfrec_amd import rendezvous
-    os.environ["MASTER_PORT"] = "47123"
-    try:
-        # cleanup is keyed by (parent pid, port): from this process the key differs, so emulate rank 0
-        import shutil, tempfile
-        shutil.rmtree(os.path.join(tempfile.gettempdir(), "mfx_rdzv_%d_47123" % os.getpid()), ignore_errors=True)
-    finally:
-        del os.environ["MASTER_PORT"]
+    hits = glob.glob(os.path.join(rendezvous._base(), "mfx_rdzv_u%d_p%d_47123_*" % (os.getuid(), os.getpid())))
+    assert len(hits) == 1
+    st = os.lstat(hits[0])
+    assert (st.st_mode & 0o077) == 0 and st.st_uid == os.getuid()          # private to the user
+    for h in hits:
+        shutil.rmtree(h, ignore_errors=True)
+
+
+def test_rendezvous_refuses_a_planted_directory(tmp_path, monkeypatch):
+    """A directory at the rendezvous path that is not a private directory of this user (here: group/world
+    accessible) is not trusted by the waiting ranks."""
+    import pytest
+    from mfrec_amd import rendezvous
+    monkeypatch.setenv("XDG_RUNTIME_DIR", str(tmp_path))
+    monkeypatch.setenv("MASTER_PORT", "47999")
+    d = rendezvous._dir()
+    os.mkdir(d, 0o755)
+    with open(os.path.join(d, "unique_id.bin"), "wb") as f:
+        f.write(b"x" * 128)
+    with pytest.raises(TimeoutError):
+        rendezvous.exchange_unique_id(1, 2, None, timeout_s=0.5)

@@ -417,6 +417,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--no-also", action="store_true", help="skip the `also` block (secondary kernels)")
     ap.add_argument("--no-extra", action="store_true", help=argparse.SUPPRESS)   # accepted, no-op
+    ap.add_argument("--also-only", default="", help="comma-separated subset of the `also` legs (profiling runs)")
     ap.add_argument("--storage", choices=["f64", "f32"], default="f64",
                     help="f32 = NOT the reference's precision: rows stored as f32 (measured option only)")
     ap.add_argument("--cpu-replica", type=int, default=0, help=argparse.SUPPRESS)
@@ -646,7 +647,13 @@ def main():
             and a.order == "shuffled":
         v0n = v0
 
+        only = set(x for x in a.also_only.split(",") if x)
+
         def leg(name, fn):
+            if only and name not in only:
+                return
+            if os.environ.get("MFX_BENCH_TRACE") == "1":
+                sys.stderr.write("[bench] leg %s\n" % name); sys.stderr.flush()
             t = time.perf_counter()
             try:
                 also[name] = fn()
@@ -662,7 +669,7 @@ def main():
         leg("k1_tolerance_mode_balanced", lambda: also_k1_tolerance(idx, r, nu, ni, k, u0, v0n, a.steps, a.warmup, "balanced"))
         leg("k2_funk", lambda: also_funk(idx, r, nu, ni, k, "shuffled"))
         leg("k2_funk_balanced", lambda: also_funk(idx, r, nu, ni, k, "balanced"))
-        if not a.no_cpu and "error" not in also["k2_funk"]:
+        if not a.no_cpu and "k2_funk" in also and "error" not in also["k2_funk"]:
             try:
                 also["k2_funk"]["cpu_baseline"] = cpu_baseline_funk(idx, r, nu, ni)
             except Exception as e:
@@ -690,11 +697,13 @@ def main():
                 out["k3_als_cfg4"] = {"error": repr(e)}
             return out
 
-        t = time.perf_counter()
-        try:
-            also.update(cfg3_and_als())
-        except Exception as e:
-            also["k1_cfg3_whole_1gpu"] = {"error": repr(e)}
+        if not only or (only & {"k1_cfg3_whole_1gpu", "k3_als_cfg4"}):
+            if os.environ.get("MFX_BENCH_TRACE") == "1":
+                sys.stderr.write("[bench] leg cfg3 + als\n"); sys.stderr.flush()
+            try:
+                also.update(cfg3_and_als())
+            except Exception as e:
+                also["k1_cfg3_whole_1gpu"] = {"error": repr(e)}
         if not a.no_cpu and "k3_als_cfg4" in also and "error" not in also["k3_als_cfg4"]:
             try:
                 cb = cpu_baseline_als(128)

@@ -1,7 +1,9 @@
 """Build mfrec_amd/libmfx.so in-tree with hipcc for gfx950 (python -m mfrec_amd.build).
 
-Every source is compiled to its own object (in parallel, cached by mtime under build/obj) and the
-objects are linked into the shared library."""
+Every source is compiled to its own object (in parallel, cached by mtime under build/obj) with
+-save-temps, the gfx950 assembly of exactly those objects is linted for the hazards the compiler cannot
+see inside inline asm (mfrec_amd/isa_lint.py) -- a hazard FAILS the build -- and the objects are linked
+into the shared library."""
 import glob
 import os
 import subprocess
@@ -21,6 +23,25 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
 
 
+def lint(srcs, isa_of, verbose=True):
+    """ISA hazard lint of what is about to be linked; raises on any hazard."""
+    from . import isa_lint
+    total = {"dpp": 0, "dpp_hazards": 0, "wide_asm_stores": 0, "store_hazards": 0}
+    for src in srcs:
+        path = isa_of(src)
+        if not os.path.exists(path):
+            raise RuntimeError("no device assembly for %s (expected %s)" % (src, path))
+        r = isa_lint.lint_file(path, verbose=True)
+        for k in total:
+            total[k] += r[k]
+    if verbose:
+        print("[mfrec_amd.build] ISA lint: %(dpp)d DPP instructions, %(dpp_hazards)d hazards; "
+              "%(wide_asm_stores)d wide asm stores, %(store_hazards)d without s_nop >= 1" % total, flush=True)
+    if total["dpp_hazards"] or total["store_hazards"]:
+        raise RuntimeError("ISA hazard lint failed: %r" % (total,))
+    return total
+
+
 def build(force=False, verbose=True):
     srcs = sources()
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(ROOT, "include", "mfx.h")]
@@ -34,19 +55,25 @@ def build(force=False, verbose=True):
     os.makedirs(objdir, exist_ok=True)
     hdr_time = max(os.path.getmtime(h) for h in hdrs)
 
+    def isa_of(src):
+        stem = os.path.splitext(os.path.basename(src))[0]
+        return os.path.join(objdir, stem + "-hip-amdgcn-amd-amdhsa-gfx950.s")
+
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
-        if (not force and os.path.exists(obj)
+        if (not force and os.path.exists(obj) and os.path.exists(isa_of(src))
                 and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_time)):
             return obj
-        cmd = [hipcc] + CFLAGS + extra + ["-c", src, "-o", obj]
+        # -save-temps=obj: the device assembly of THIS object, with THESE flags, lands next to it
+        cmd = [hipcc] + CFLAGS + extra + ["-save-temps=obj", "-c", src, "-o", obj]
         if verbose:
             print("[mfrec_amd.build]", " ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+        subprocess.check_call(cmd, cwd=objdir)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1, 8)) as ex:
         objs = list(ex.map(compile_one, srcs))
+    lint(srcs, isa_of, verbose)
     cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950"] + objs + ["-o", out, "-ldl", "-lpthread"]
     if verbose:
         print("[mfrec_amd.build]", " ".join(cmd), flush=True)

@@ -1,7 +1,10 @@
 """The slice of mfrec/recommendation/base.py the training path needs: the ratings
-container, parameter handling, ratings -> kernel-input marshalling, model snapshots.
-Persistence backends, similarity search and KNN predictors are out of scope."""
+container, parameter handling, ratings -> kernel-input marshalling, model snapshots and the
+save_state / load_state file set (so that factors trained here load into the original tooling
+and vice versa).  Database backends, similarity search and KNN predictors are out of scope
+(SURVEY 8)."""
 import logging
+import pickle
 
 import numpy as np
 from scipy.sparse import lil_matrix
@@ -25,6 +28,9 @@ class BaseRecommender(object):
         self.relationship_matrix_csr = None
         self.svd_u = self.svd_v = self.svd_s = None
         self.users_bias = self.items_bias = self.overall_bias = None
+        # label <-> index maps of the reference's container (base.py:96-101); carried through save_state
+        self.users_label, self.users_index = {}, {}
+        self.items_label, self.items_index, self.items_index_map = {}, {}, {}
 
     @property
     def nbr_users(self):
@@ -73,15 +79,18 @@ class BaseRecommender(object):
             # global numpy RNG the reference's shuffle uses); falls back to the plain shuffle
             from ..lib.datasets import balanced_order, balanced_order_gpu
             from .._shim import MfxError
+            # what a builder's refusal looks like after _shim.check(): MFX_E_STATE -> MfxError (too many
+            # levels), MFX_E_NOMEM -> MemoryError (colour bitsets / scratch), never a wrong order
+            refusal = (MfxError, MemoryError)
             np.random.shuffle(order)               # the random part, from the RNG the reference uses
             try:
                 try:                               # GPU builder: milliseconds (recolours the shuffled order)
                     perm, _ = balanced_order_gpu(ratings_index[order], self.nbr_users, self.nbr_items)
                     order = order[perm]
-                except MfxError:                   # > 2^20 levels etc.: the host builder
+                except refusal:                    # > 2^20 levels, bitsets too large: the host builder
                     order, _ = balanced_order(ratings_index, self.nbr_users, self.nbr_items,
                                               seed=int(np.random.randint(0, 2 ** 31 - 1)))
-            except MfxError:
+            except refusal:
                 pass                               # keep the plain shuffle
         elif randomize_order:
             np.random.shuffle(order)
@@ -90,6 +99,44 @@ class BaseRecommender(object):
     def compute_overall_avg(self):
         data = self.relationship_matrix.tocoo().data                         # base.py:504-508
         self.overall_bias = float(data[data != 0].astype(float).mean())
+
+    # ---- save_state / load_state: the file set of base.py:557-596 ----------------------
+    _STATE_DICTS = (("_userslabel.dat", "users_label"), ("_usersindex.dat", "users_index"),
+                    ("_itemslabel.dat", "items_label"), ("_itemsindex.dat", "items_index"),
+                    ("_itemsindexmap.dat", "items_index_map"))
+
+    def save_state(self, filename):
+        """`filename`_relations.mtx (MatrixMarket), `filename`_svd.npz with keys svd_s / svd_u / svd_v
+        ([k, n] f64; svd_s is None for the SGD / ALS families and is stored the way np.savez stores None,
+        exactly what the reference writes), and the five label / index dictionaries as pickles --
+        protocol 0, which the reference's Python 2 reads (base.py:557-575)."""
+        import scipy.io
+        scipy.io.mmwrite(filename + "_relations.mtx", self.relationship_matrix)
+        np.savez(filename + "_svd.npz", svd_s=self.svd_s, svd_u=self.svd_u, svd_v=self.svd_v)
+        for suffix, attr in self._STATE_DICTS:
+            with open(filename + suffix, "wb") as f:
+                pickle.dump(getattr(self, attr), f, protocol=0)
+        self.logger.info("The state of the recommendation engine has been saved.")
+
+    def load_state(self, filename):
+        """Inverse of save_state; also reads a file set written by the reference itself (its pickles are
+        Python 2 text pickles, its svd_s an object array): base.py:578-596.  The ratings come back as a
+        lil_matrix (the reference keeps mmread's coo_matrix; every consumer here indexes the matrix)."""
+        import scipy.io
+        z = np.load(filename + "_svd.npz", allow_pickle=True)
+        self.svd_u, self.svd_v = z["svd_u"], z["svd_v"]
+        s = z["svd_s"]
+        self.svd_s = s.item() if (s.dtype == object and s.shape == ()) else s
+        for name in ("svd_u", "svd_v"):
+            a = getattr(self, name)
+            if a.dtype == object and a.shape == ():
+                setattr(self, name, a.item())
+        self.relationship_matrix = lil_matrix(scipy.io.mmread(filename + "_relations.mtx"))
+        self._nbr_users, self._nbr_items = self.relationship_matrix.shape
+        for suffix, attr in self._STATE_DICTS:
+            with open(filename + suffix, "rb") as f:
+                setattr(self, attr, pickle.load(f, encoding="latin1"))
+        self.logger.info("The state of the recommendation engine has been loaded")
 
     # ---- model snapshots (npz keys as base.py:805-812) -------------------------------
     def save_model_snapshot(self, filename):

@@ -144,3 +144,89 @@ def test_folding_in_and_top_n():
     new_item = R.add_item("thing", np.array([1, 2, 3], dtype=np.int32), np.array([4.0, 4.0, 5.0]))
     assert new_item == ni and R.svd_u.shape == (k, ni + 1)
     assert np.array_equal(R.svd_v[:, :nu], v_before)
+
+
+def test_gd_learned_bias_trainer_matches_oracle():
+    """GDRecommender.feature_training_bias (gradient_descent.py:472-503) at recommender level: replay the RNG,
+    rebuild the bias pre-computes, run the oracle's estimator_loop_with_learned_bias -- bit for bit."""
+    from mfrec_amd.recommendation import GDRecommender
+    from oracle import oracle as O
+    nu, ni, k = 150, 100, 5
+    params = {"min_epochs": 3, "max_epochs": 3, "min_improvement": 1e9, "nbr_features": k}
+    R = _fill(GDRecommender(nu, ni, params), nu, ni, 4000, 4)
+    np.random.seed(6)
+    R.feature_training_bias()
+    Q = _fill(GDRecommender(nu, ni, params), nu, ni, 4000, 4)
+    np.random.seed(6)
+    idx, r = Q.get_ratings(randomize_order=True)
+    Q.compute_overall_avg(); Q.compute_items_bias_bk(); Q.compute_users_bias_bk()
+    u, v = synth.init_const(k, ni), synth.init_const(k, nu)
+    ib, ub = Q.items_bias.copy(), Q.users_bias.copy()
+    O.estimator_loop_with_learned_bias(3, 3, 1e9, k, 0.1, 0.001, 0.001, 0.001, 0.05, 0.01, Q.overall_bias,
+                                       u, v, idx, r, ib, ub, nu, ni)
+    assert np.array_equal(R.svd_u, u) and np.array_equal(R.svd_v, v)
+    assert np.array_equal(R.items_bias, ib) and np.array_equal(R.users_bias, ub)
+
+
+def test_folding_in_matches_oracle_and_empty_fold_in_is_a_noop():
+    """retrain_user / retrain_item (gradient_descent.py:879-905, kmf.py:120-146) against the oracle with the
+    same update gates; a fold-in WITHOUT ratings runs the reference's empty epochs and changes nothing but the
+    re-initialised row (it used to raise after the row had been re-initialised)."""
+    from mfrec_amd.recommendation import GDRecommender, KMFRecommender
+    from oracle import oracle as O
+    nu, ni, k = 120, 90, 6
+    # --- GD family ---------------------------------------------------------------------------
+    params = {"min_epochs": 3, "max_epochs": 3, "min_improvement": 1e9, "nbr_features": k}
+    R = _fill(GDRecommender(nu, ni, params), nu, ni, 3000, 2)
+    np.random.seed(2)
+    R.train(handle_bias=True)
+    idx, r = R.get_ratings(randomize_order=False)
+    user = int(idx[7, 0])
+    u0, v0 = R.svd_u.copy(), R.svd_v.copy()
+    np.random.seed(9)
+    R.retrain_user(user, idx, r)
+    np.random.seed(9)
+    v0[:, user] = np.random.normal(0.0, 0.1, k)                      # init_user_features (mf.py:136-137)
+    sel = np.where(idx[:, 0] == user)[0]
+    O.estimator_loop_with_bias_dev(3, 3, 1e9, k, 0.1, 0.001, 0.001, 0.001, 0.05, R.overall_bias, u0, v0,
+                                   np.ascontiguousarray(idx[sel]), np.ascontiguousarray(r[sel]), R.items_bias,
+                                   R.users_bias, nu, ni, 1, 0)
+    assert np.array_equal(R.svd_u, u0) and np.array_equal(R.svd_v, v0)
+    item = int(idx[11, 1])
+    np.random.seed(10)
+    R.retrain_item(item, idx, r)
+    np.random.seed(10)
+    u0[:, item] = np.random.normal(0.0, 0.1, k)
+    sel = np.where(idx[:, 1] == item)[0]
+    O.estimator_loop_with_bias_dev(3, 3, 1e9, k, 0.1, 0.001, 0.001, 0.001, 0.05, R.overall_bias, u0, v0,
+                                   np.ascontiguousarray(idx[sel]), np.ascontiguousarray(r[sel]), R.items_bias,
+                                   R.users_bias, nu, ni, 0, 1)
+    assert np.array_equal(R.svd_u, u0) and np.array_equal(R.svd_v, v0)
+    # a user nobody rated for: no ratings selected -> only the re-initialised row differs
+    lonely = [x for x in range(nu) if x not in set(idx[:, 0].tolist())]
+    if not lonely:
+        idx2 = idx[idx[:, 0] != 0]; r2 = r[idx[:, 0] != 0]; lonely = [0]
+    else:
+        idx2, r2 = idx, r
+    before_u, before_v = R.svd_u.copy(), R.svd_v.copy()
+    np.random.seed(11)
+    R.retrain_user(lonely[0], idx2, r2)                                # must not raise
+    np.random.seed(11)
+    before_v[:, lonely[0]] = np.random.normal(0.0, 0.1, k)
+    assert np.array_equal(R.svd_u, before_u) and np.array_equal(R.svd_v, before_v)
+    # --- KMF family --------------------------------------------------------------------------
+    K = _fill(KMFRecommender(nu, ni, {"nbr_epochs": 4, "nbr_features": k}), nu, ni, 3000, 2)
+    np.random.seed(1)
+    K.train(kernel="train_linear_kernel")
+    idx, r = K.get_ratings(randomize_order=False)
+    user = int(idx[5, 0])
+    u0, v0, ib0, ub0 = K.svd_u.copy(), K.svd_v.copy(), K.items_bias.copy(), K.users_bias.copy()
+    np.random.seed(3)
+    K.retrain_user(user, idx, r, kernel="train_linear_kernel")
+    np.random.seed(3)
+    v0[:, user] = np.random.normal(0.0, 0.1, k)
+    sel = np.where(idx[:, 0] == user)[0]
+    O.train_linear_kernel(4, k, 0.1, 0.01, 0.01, 0.01, 0.1, 0.1, 0.007, K.overall_bias, u0, v0,
+                          np.ascontiguousarray(idx[sel]), np.ascontiguousarray(r[sel]), ib0, ub0, 1, 0)
+    assert np.array_equal(K.svd_u, u0) and np.array_equal(K.svd_v, v0)
+    assert np.array_equal(K.items_bias, ib0) and np.array_equal(K.users_bias, ub0)

@@ -83,3 +83,69 @@ def test_snapshot_roundtrip(tmp_path):
     assert np.array_equal(Q.svd_u, R.svd_u) and np.array_equal(Q.svd_v, R.svd_v)
     z = np.load(str(tmp_path / "m") + "_model_snapshot.npz")
     assert sorted(z.files) == ["svd_u", "svd_v"]          # keys of base.py:805-806
+
+
+def test_save_state_load_state_file_set(tmp_path):
+    """base.py:557-596: `_relations.mtx`, `_svd.npz` (svd_s / svd_u / svd_v), five pickled dictionaries."""
+    import pickle
+    import scipy.io
+    from mfrec_amd.recommendation.base import BaseRecommender
+    R = BaseRecommender(5, 7)
+    R.set_ratings(np.array([[0, 1], [4, 6], [2, 2]]), [3.0, 5.0, 1.0])
+    R.svd_u, R.svd_v = np.arange(14.0).reshape(2, 7), np.arange(10.0).reshape(2, 5)
+    R.users_label, R.users_index = {0: "ann", 4: "bob"}, {"ann": 0, "bob": 4}
+    R.items_label, R.items_index, R.items_index_map = {1: "x"}, {"x": 1}, {1: 1}
+    base = str(tmp_path / "state")
+    R.save_state(base)
+    for suffix in ("_relations.mtx", "_svd.npz", "_userslabel.dat", "_usersindex.dat", "_itemslabel.dat",
+                   "_itemsindex.dat", "_itemsindexmap.dat"):
+        assert (tmp_path / ("state" + suffix)).exists()
+    z = np.load(base + "_svd.npz", allow_pickle=True)
+    assert sorted(z.files) == ["svd_s", "svd_u", "svd_v"]
+    assert z["svd_s"].shape == () and z["svd_s"].item() is None           # None as numpy stores it
+    assert pickle.load(open(base + "_userslabel.dat", "rb")) == R.users_label
+    assert open(base + "_usersindex.dat", "rb").read(1) not in (b"\x80",)    # protocol 0: Python 2 reads it
+    Q = BaseRecommender(1, 1)
+    Q.load_state(base)
+    assert (Q.nbr_users, Q.nbr_items) == (5, 7) and Q.svd_s is None
+    assert np.array_equal(Q.svd_u, R.svd_u) and np.array_equal(Q.svd_v, R.svd_v)
+    assert (Q.relationship_matrix != R.relationship_matrix).nnz == 0
+    assert Q.users_index == R.users_index and Q.items_index_map == R.items_index_map
+    a, b = Q.get_ratings()
+    assert a.tolist() == [[0, 1], [2, 2], [4, 6]] and b.tolist() == [3.0, 1.0, 5.0]
+
+    # a file set as the REFERENCE writes it: text-mode protocol-0 pickles, svd_s a real array
+    scipy.io.mmwrite(base + "2_relations.mtx", R.relationship_matrix)
+    np.savez(base + "2_svd.npz", svd_s=np.array([2.0, 1.0]), svd_u=R.svd_u, svd_v=R.svd_v)
+    for suffix, obj in (("_userslabel.dat", {0: "ann"}), ("_usersindex.dat", {"ann": 0}), ("_itemslabel.dat", {}),
+                        ("_itemsindex.dat", {}), ("_itemsindexmap.dat", {})):
+        with open(base + "2" + suffix, "w") as f:
+            f.write(pickle.dumps(obj, protocol=0).decode("latin1"))
+    Q.load_state(base + "2")
+    assert Q.svd_s.tolist() == [2.0, 1.0] and Q.users_label == {0: "ann"}
+
+
+def test_balanced_order_falls_back_when_a_builder_refuses(monkeypatch):
+    """get_ratings('balanced') promises GPU builder -> host builder -> plain shuffle; a builder's refusal
+    arrives as MfxError (MFX_E_STATE) or MemoryError (MFX_E_NOMEM) after _shim.check()."""
+    from mfrec_amd import _shim as S
+    from mfrec_amd.lib import datasets as D
+    from mfrec_amd.recommendation.base import BaseRecommender
+    R = BaseRecommender(6, 5)
+    R.set_ratings(np.array([[0, 1], [1, 1], [2, 3], [5, 4], [3, 0]]), [1.0, 2.0, 3.0, 4.0, 5.0])
+    calls = []
+
+    def gpu_refuses(*a, **k):
+        calls.append("gpu")
+        raise MemoryError("libmfx error -3: colour bitsets")
+
+    def host_refuses(*a, **k):
+        calls.append("host")
+        raise S.MfxError("libmfx error -7: too many levels")
+
+    monkeypatch.setattr(D, "balanced_order_gpu", gpu_refuses)
+    monkeypatch.setattr(D, "balanced_order", host_refuses)
+    np.random.seed(3)
+    idx, r = R.get_ratings(randomize_order="balanced")
+    assert calls == ["gpu", "host"]
+    assert sorted(r.tolist()) == [1.0, 2.0, 3.0, 4.0, 5.0] and idx.shape == (5, 2)     # the plain shuffle

@@ -47,3 +47,29 @@ def test_lint_detects_a_wide_asm_store_without_nop():
     assert L.scan_asm_stores(bad) == (1, 1)
     ok = [";;#ASMSTART", "global_store_dwordx4 v[0:1], v[2:5], off sc0 sc1", "s_nop 1", ";;#ASMEND"]
     assert L.scan_asm_stores(ok) == (1, 0)
+
+
+def test_lint_is_conservative_at_labels_and_rejects_s_nop_0():
+    """(2) control flow -- a hand-written DPP instruction right behind a label or a branch cannot
+    rely on what the linear scan saw before it; (3) `s_nop 0` is ONE wait state, a wide store needs two."""
+    from mfrec_amd import isa_lint as L
+    dpp = "v_fmac_f64_dpp v[0:1], -v[2:3], v[4:5] row_newbcast:3 row_mask:0xf bank_mask:0xf"
+    at_label = ["v_add_f64 v[8:9], v[8:9], v[4:5]", ".LBB0_3:", ";;#ASMSTART", dpp, ";;#ASMEND"]
+    assert L.scan(at_label, verbose=False) == (1, 1)
+    after_branch = ["s_cbranch_vccnz .LBB0_7", ";;#ASMSTART", dpp, ";;#ASMEND"]
+    assert L.scan(after_branch, verbose=False) == (1, 1)
+    padded = [".LBB0_3:", ";;#ASMSTART", "s_nop 1", dpp, ";;#ASMEND"]
+    assert L.scan(padded, verbose=False) == (1, 0)
+    compiler_dpp = [".LBB0_3:", "v_mov_b32_dpp v1, v2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"]
+    assert L.scan(compiler_dpp, verbose=False) == (1, 0)          # the hazard recogniser's own business
+    nop0 = [";;#ASMSTART", "global_store_dwordx4 v[0:1], v[2:5], off sc0 sc1", "s_nop 0", ";;#ASMEND"]
+    assert L.scan_asm_stores(nop0) == (1, 1)
+
+
+def test_the_build_lints_what_it_links():
+    """the lint is part of mfrec_amd.build -- same flags, the objects that are linked."""
+    import inspect
+    from mfrec_amd import build as B
+    src = inspect.getsource(B.build)
+    assert "-save-temps=obj" in src and "lint(srcs, isa_of" in src
+    assert "ISA hazard lint failed" in inspect.getsource(B.lint)

@@ -885,7 +885,7 @@ static int ensure_k2x(mfx_sgd_plan *p)
     if (per_group > cap_doubles) return MFX_OK;
     p->x_lds_doubles = (int)(2 * per_group <= cap_doubles ? 2 * per_group : per_group);
     const int64_t nseg = p->n_levels * kXGroups;
-    p->k2x_slots = p->nnz / 64 + nseg + 2;
+    p->k2x_slots = (int64_t)kXGroups * kXWorkers * 64;
     if (dev_alloc(p, &p->d_seg_off, (size_t)nseg + 1) || dev_alloc(p, &p->d_xctl, 4096) ||
         dev_alloc(p, &p->d_se_x, (size_t)p->k2x_slots))
         return last_code();

@@ -651,7 +651,7 @@ struct K2XParams {
     const double *ib;          // nullable (without_bias)
     const double *ub;
     const int32_t *seg_off;    // [n_levels * kXGroups + 1]
-    double *se_partial;        // slot of a chunk starting at position tb of segment q: (tb >> 6) + q
+    double *se_partial;        // [kXGroups][kXWorkers][64]: one accumulator per (group, worker, lane)
     unsigned *ctl;             // [x*32] registrations of XCD x, [512] status, [1024 + slot*32] flags
     int n_levels, nu;
     int lds_doubles;
@@ -702,9 +702,9 @@ __global__ __launch_bounds__((kXWorkers + 1) * 64) void k2_xcd_pass(K2XParams P)
     // (group(u) = u * NG / nu  <=>  u in [ceil(nu * g / NG), ceil(nu * (g+1) / NG)))
 
     // my groups' user slices -> LDS (groups slot, slot + nx, ...)
-    int need = 0;
-    for (int g = slot; g < NG; g += nx) need += glo(g + 1) - glo(g);
-    if (need > P.lds_doubles) {                          // uniform over the workgroup
+    int need = 0, ngroups = 0;
+    for (int g = slot; g < NG; g += nx, ++ngroups) need += glo(g + 1) - glo(g);
+    if (need > P.lds_doubles || ngroups > 2) {           // uniform over the workgroup
         if (threadIdx.x == 0) atomicExch(P.ctl + 512, 2u);
         return;
     }
@@ -738,27 +738,45 @@ __global__ __launch_bounds__((kXWorkers + 1) * 64) void k2_xcd_pass(K2XParams P)
     if (!barrier(P.gen_base, kXSpinSetup)) return;      // nothing has been modified yet
 
     // records and cache words do not depend on the updates: the first chunk of the NEXT level is requested
-    // before the barrier
-    Rec nrec; nrec.user = 0; nrec.item = 0; nrec.r = 0.0;
-    double ncache = 0.0;
-    if (worker >= 0 && P.n_levels > 0 && (int)slot < NG) {
-        const int tb = P.seg_off[slot] + worker * 64, s1 = P.seg_off[slot + 1];
-        if (tb + lane < s1) { nrec = P.recs[tb + lane]; ncache = P.cache[tb + lane]; }
-    }
+    // before the barrier.  (Also requesting U[f, item] one level ahead for the ratings whose item was not
+    // touched in the level in between -- two thirds of them at cfg 2 -- was built and measured: no gain, every
+    // wave still waits for its remaining third; dropped.)
+    struct Pre {
+        Rec rec;
+        double cache;
+    };
+    auto stage1 = [&](int l, Pre &x) {
+        x.cache = 0.0;
+        x.rec.user = 0; x.rec.item = 0; x.rec.r = 0.0;
+        if (l < P.n_levels && (int)slot < NG) {
+            const int q = l * NG + (int)slot;
+            const int t = P.seg_off[q] + worker * 64 + lane;
+            if (t < P.seg_off[q + 1]) {
+                x.rec = P.recs[t];
+                x.cache = P.cache[t];
+            }
+        }
+    };
+    Pre cur;
+    if (worker >= 0) stage1(0, cur);
+    // squared errors: one accumulator per (user group, worker, lane), summed over the levels in level order and
+    // written once at the end of the pass -- a layout fixed by the schedule alone (a group's segment of a level
+    // is cut into 64-rating chunks dealt to the workers in turn), so the epoch RMSE has the same bits whatever
+    // the placement; and no wave reduction + store sits on every level's critical path (stamps: ~10 % of it)
+    double se_acc[2] = {0.0, 0.0};                       // a workgroup holds at most two groups (LDS, above)
     for (int l = 0; l < P.n_levels; ++l) {
         if (worker >= 0) {
-            int base = 0;
+            int base = 0, gi = 0;
             bool first = true;
-            for (int g = slot; g < NG; g += nx) {
+            for (int g = slot; g < NG; g += nx, ++gi) {
                 const int lo = glo(g);
                 const int q = l * NG + g;
                 const int s0 = P.seg_off[q], s1 = P.seg_off[q + 1];
                 for (int tb = s0 + worker * 64; tb < s1; tb += kXWorkers * 64) {      // wave-uniform
                     const int t = tb + lane;
-                    double e2 = 0.0;
                     if (t < s1) {
-                        const Rec rec = first ? nrec : P.recs[t];
-                        const double c = first ? ncache : P.cache[t];
+                        const Rec rec = first ? cur.rec : P.recs[t];
+                        const double c = first ? cur.cache : P.cache[t];
                         double bs;
                         if (P.ib) bs = P.mu + P.ib[rec.item] + P.ub[rec.user];
                         else bs = P.mu + 0.0 + 0.0;
@@ -766,25 +784,25 @@ __global__ __launch_bounds__((kXWorkers + 1) * 64) void k2_xcd_pass(K2XParams P)
                         const double cf = vlds[base + rec.user - lo];
                         const double p = funk_estimate(mf, cf, c, bs, trail, true);
                         const double err = rec.r - p;
-                        e2 = err * err;
                         if (P.upd_i) uf[rec.item] = mf + lr * (err * cf - K * mf);
                         if (P.upd_u) vlds[base + rec.user - lo] = cf + lr * (err * mf - K * cf);
+                        if (gi == 0) se_acc[0] += err * err;
+                        else se_acc[1] += err * err;
                     }
                     first = false;
-                    const double ws = wave_sum_fixed(e2);
-                    if (lane == 0) P.se_partial[(tb >> 6) + q] = ws;
                 }
                 first = false;
                 base += glo(g + 1) - lo;
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my stores are in L2
-            if (l + 1 < P.n_levels && (int)slot < NG) {
-                const int q = (l + 1) * NG + (int)slot;
-                const int tb = P.seg_off[q] + worker * 64, s1 = P.seg_off[q + 1];
-                if (tb + lane < s1) { nrec = P.recs[tb + lane]; ncache = P.cache[tb + lane]; }
-            }
+            stage1(l + 1, cur);
         }
         if (!barrier(P.gen_base + (unsigned)l + 1u, kXSpinRun)) return;
+    }
+    if (worker >= 0) {
+        int gi = 0;
+        for (int g = slot; g < NG; g += nx, ++gi)
+            P.se_partial[((size_t)g * kXWorkers + worker) * 64 + lane] = gi == 0 ? se_acc[0] : se_acc[1];
     }
     // LDS slices back to V[f,:]
     if (P.upd_u) {

@@ -29,7 +29,7 @@ using namespace mfx;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
-__device__ __forceinline__ unsigned ld_sc1_u32(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// (ld_sc1_u32: mfx_sgd_kernels.h)
 __device__ __forceinline__ double ld_sc1_f64(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 #ifndef WORKERS
@@ -50,7 +50,13 @@ struct XParams {
     int n_levels;
     int lds_doubles;           // variant 3: capacity of the dynamic LDS
     double lr, K, mu, trail;
+    unsigned long long *stamps;   // -DSTAMPS: [n_levels][8] s_memtime of workgroup slot 0
 };
+#ifdef STAMPS
+#define STAMP(i) do { if (slot == 0 && lane == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); P.stamps[(size_t)l * 8 + (i)] = t_; } } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
 // ctl layout (unsigned): [x*32] registrations of XCD x (own line), [512] error, [1024 + slot*32] flag of workgroup slot
 template <int VARIANT>
@@ -140,6 +146,7 @@ __global__ __launch_bounds__((W + 1) * 64) void k2_xcd_pass(XParams P)
         return err * err;
     };
     for (int l = 0; l < P.n_levels; ++l) {
+        if (worker == 0) STAMP(0);
         if (worker >= 0) {
             if constexpr (VARIANT == 3) {
                 int base = 0;
@@ -189,7 +196,9 @@ __global__ __launch_bounds__((W + 1) * 64) void k2_xcd_pass(XParams P)
                     if (lane == 0) P.se_partial[t0 >> 6] = ws;
                 }
             }
+            if (worker == 0) STAMP(1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my stores are in L2
+            if (worker == 0) STAMP(2);
 #ifdef PREFETCH
             if (l + 1 < P.n_levels) {
                 int tb, s1, lo, base;
@@ -200,6 +209,7 @@ __global__ __launch_bounds__((W + 1) * 64) void k2_xcd_pass(XParams P)
         }
         __syncthreads();                                          // A: every worker's stores are in L2
         if (worker < 0) {
+            STAMP(3);
             const unsigned gen = (unsigned)(l + 1);
             if (lane == 0) flags[slot * 32] = gen;               // plain store: stays in this XCD's L2
             unsigned spins = 0;
@@ -208,8 +218,13 @@ __global__ __launch_bounds__((W + 1) * 64) void k2_xcd_pass(XParams P)
                 if (__all(ok)) break;
                 if (++spins > SPIN_LIMIT || ld_sc1_u32(P.ctl + 512)) { if (lane == 0) atomicExch(P.ctl + 512, 1u); break; }
             }
+            STAMP(4);
+#ifdef STAMPS
+            if (slot == 0 && lane == 0) P.stamps[(size_t)l * 8 + 6] = spins;
+#endif
         }
         __syncthreads();                                          // B: the level is complete everywhere
+        if (worker == 0) STAMP(5);
     }
     if constexpr (VARIANT == 3) {
         int base = 0;
@@ -453,6 +468,9 @@ int main(int argc, char **argv)
     }
     XParams X{}; X.recs = dX; X.cache = dcX; X.uf = duf[1]; X.vf = dvf[1]; X.seg_off = d_seg; X.group_lo = d_glo; X.se_partial = d_se; X.ctl = d_ctl;
     X.n_levels = (int)n_levels; X.lr = lr; X.K = K; X.mu = mu; X.trail = trail;
+    unsigned long long *d_stamps = nullptr;
+    CK(hipMalloc(&d_stamps, (size_t)(n_levels + 1) * 8 * 8)); CK(hipMemset(d_stamps, 0, (size_t)(n_levels + 1) * 8 * 8));
+    X.stamps = d_stamps;
     const size_t lds = variant == 3 ? (size_t)((nu + NG - 1) / NG + 8) * 8 * 2 : 0;      // up to two groups per workgroup (nx >= 16)
     X.lds_doubles = (int)(lds / 8);
     void *fn = variant == 3 ? (void *)k2_xcd_pass<3> : (void *)k2_xcd_pass<1>;
@@ -475,6 +493,25 @@ int main(int argc, char **argv)
     size_t du = 0, dv = 0;
     for (int i = 0; i < ni; ++i) du += memcmp(&a[i], &b[i], 8) != 0;
     for (int i = 0; i < nu; ++i) dv += memcmp(&c[i], &d[i], 8) != 0;
+#ifdef STAMPS
+    {
+        std::vector<unsigned long long> st((size_t)n_levels * 8);
+        CK(hipMemcpy(st.data(), d_stamps, st.size() * 8, hipMemcpyDeviceToHost));
+        double d[6] = {0, 0, 0, 0, 0, 0}, sp = 0; int n = 0;
+        for (int64_t l = 20; l + 1 < n_levels - 20; ++l, ++n) {
+            const unsigned long long *a = &st[(size_t)l * 8], *b = &st[(size_t)(l + 1) * 8];
+            d[0] += (double)(a[1] - a[0]);      // level open -> updates issued (sc1 load + compute + store issue)
+            d[1] += (double)(a[2] - a[1]);      // store drain (vmcnt(0))
+            d[2] += (double)(a[3] - a[2]);      // barrier A (+ prefetch issue)
+            d[3] += (double)(a[4] - a[3]);      // flag store -> all flags seen
+            d[4] += (double)(a[5] - a[4]);      // barrier B
+            d[5] += (double)(b[0] - a[0]);      // whole level
+            sp += (double)a[6];
+        }
+        printf("stamps (s_memtime ticks, workgroup slot 0, mean over %d levels): load+compute+issue %.0f | store drain %.0f | barrier A %.0f | flag->all flags %.0f (%.1f poll rounds) | barrier B %.0f | level %.0f\n",
+               n, d[0] / n, d[1] / n, d[2] / n, d[3] / n, sp / n, d[4] / n, d[5] / n);
+    }
+#endif
     printf("workgroups per XCD: %u %u %u %u %u %u %u %u\n", reg[0], reg[1], reg[2], reg[3], reg[4], reg[5], reg[6], reg[7]);
     printf("K2 pass: level-per-launch %.3f ms = %.2f G scalar-updates/s | single-XCD persistent (variant %d): %.3f ms = %.2f G/s = %.2f us per level | error %u | differing uf %zu vf %zu\n",
            ms_ref, nnz / ms_ref / 1e6, variant, ms_x, nnz / ms_x / 1e6, ms_x * 1e3 / n_levels, err, du, dv);

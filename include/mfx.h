@@ -280,28 +280,38 @@ int mfx_als_wrmf_sharded(int nbr_epochs, int dim, double *u, double *v,
                          double lambda);
 
 /* ------------------------------------------------ exact multi-GPU mode (DSGD block rotation)
- * Users are cut into `world` blocks (one per GPU), items into `world` blocks.  In sub-epoch s GPU g
- * trains the ratings of block (g, (g+s) mod world) and then passes that item block (rows + biases) to
- * GPU g-1 over xGMI (ncclSend/ncclRecv ring) while it receives the next one from GPU g+1.  The blocks of
- * a sub-epoch share no user and no item, so the epoch IS the reference's sequential loop
- * (kmf_train.pyx:243-270) on the rating order
- *     for s: for g: ratings of block (g, (g+s) mod world), in the order given
+ * Users are cut into `world` blocks (one per GPU), items into n_item_blocks = world or 2 * world blocks
+ * (stride = n_item_blocks / world).  In step h GPU g trains the ratings of block
+ * (g, (stride * g + h) mod n_item_blocks) and then passes that item block (rows + biases) to GPU g-1 over xGMI
+ * (ncclSend/ncclRecv), which trains it `stride` steps later: with 2 * world blocks a block rests one whole
+ * step in transit, the transfer runs on a second stream under the next step's levels.  The blocks of a step
+ * share no user and no item, so the epoch IS the reference's sequential loop (kmf_train.pyx:243-270) on the
+ * rating order
+ *     for h: for g: ratings of block (g, (stride * g + h) mod n_item_blocks), in block order
  * and the result is bit-identical to it -- the multi-GPU mode that keeps "RMSE within 1e-5 of the
- * reference" (parameter averaging, above, does not).  The reference's only multi-machine precedent is
- * the averaging prototype gradient_descent.py:124-211.
+ * reference" (parameter averaging, above, does not).  "Block order" is the given order, or with
+ * MFX_DSGD_BALANCED the block's own minimum-level order (first-fit recolouring, as
+ * mfx_schedule_balanced_order_gpu); mfx_dsgd_get_order returns the whole order.  The reference's only
+ * multi-machine precedent is the averaging prototype gradient_descent.py:124-211; its rating order is an
+ * unseeded shuffle (base.py:1127-1129), so any order is a legitimate one.
  * ratings_index holds GLOBAL ids; a rank keeps the ratings of its own user block (so passing all ratings
  * or only the rank's own is the same).  rank = -1: all `world` ranks live in this process on this GPU
- * (rotation = device copy), for tests and rehearsals.  mfx_comm_init first when world > 1 and rank >= 0.
+ * (hand-off = device copy), for tests and rehearsals.  mfx_comm_init first when world > 1 and rank >= 0.
  * v / users_bias are this rank's users ([k, nu_local] / [nu_local]; fake world: all users); u /
  * items_bias are always the full item side.  mfx_dsgd_get_factors is collective. */
 typedef struct mfx_dsgd mfx_dsgd;
+enum { MFX_DSGD_BALANCED = 1 };
 mfx_dsgd *mfx_dsgd_create(const int32_t *ratings_index, const double *ratings, int64_t nnz, int nu,
                           int ni, int dim, const int64_t *user_bounds /* world+1 */,
-                          const int64_t *item_bounds /* world+1 */, int rank, int world);
+                          const int64_t *item_bounds /* n_item_blocks+1 */, int n_item_blocks, int rank,
+                          int world, int flags);
 void mfx_dsgd_destroy(mfx_dsgd *d);
 /* info[0] = ratings held by this process, [1] = dependency levels summed over its blocks,
- * [2] / [3] = largest / smallest block (ratings), [4] = kernel launches per epoch */
+ * [2] / [3] = largest / smallest block (ratings), [4] = kernel launches per epoch, [5] = item blocks */
 int mfx_dsgd_info(const mfx_dsgd *d, int64_t info[8]);
+/* perm_out[p] = index (into the arrays given to mfx_dsgd_create) of the p-th rating of the sequential order
+ * this object's epoch equals, restricted to the ratings this process holds (info[0] entries). */
+int mfx_dsgd_get_order(const mfx_dsgd *d, int64_t *perm_out);
 int mfx_dsgd_set_factors(mfx_dsgd *d, const double *u, const double *v, const double *items_bias,
                          const double *users_bias);
 /* se_out: nullable f64[nbr_epochs], squared-error sum of every epoch over all ratings of the job */

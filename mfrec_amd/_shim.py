@@ -93,8 +93,9 @@ SIGNATURES = {
                                           C.c_double, C.c_double, C.c_double, _dp, _dp]),
     "mfx_sgd_run_kmf_fake_world": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_double,
                                              C.c_double, C.c_double, C.c_double, C.c_double, _dp]),
-    "mfx_dsgd_create": (C.c_void_p, [_ip, _dp, C.c_int64, C.c_int, C.c_int, C.c_int, _lp, _lp, C.c_int,
-                                     C.c_int]),
+    "mfx_dsgd_create": (C.c_void_p, [_ip, _dp, C.c_int64, C.c_int, C.c_int, C.c_int, _lp, _lp, C.c_int, C.c_int,
+                                     C.c_int, C.c_int]),
+    "mfx_dsgd_get_order": (C.c_int, [C.c_void_p, _lp]),
     "mfx_dsgd_destroy": (None, [C.c_void_p]),
     "mfx_dsgd_info": (C.c_int, [C.c_void_p, _lp]),
     "mfx_dsgd_set_factors": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp]),

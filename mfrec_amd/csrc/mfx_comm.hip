@@ -155,14 +155,15 @@ int comm_broadcast_f64(double *buf, size_t count, int root)
     MFX_NCCL(R.Broadcast(buf, buf, count, ncclFloat64, root, g_comm, mfx::stream()));
     return MFX_OK;
 }
-int comm_sendrecv_f64(const CommSeg *out, int n_out, int to, const CommSeg *in, int n_in, int from)
+int comm_sendrecv_f64(const CommSeg *out, int n_out, int to, const CommSeg *in, int n_in, int from, hipStream_t st)
 {
     if (!g_comm) return fail(MFX_E_STATE, "comm_sendrecv_f64: no communicator");
+    if (!st) st = mfx::stream();
     MFX_NCCL(R.GroupStart());
     for (int i = 0; i < n_out; ++i)
-        if (out[i].count) MFX_NCCL(R.Send(out[i].ptr, out[i].count, ncclFloat64, to, g_comm, mfx::stream()));
+        if (out[i].count) MFX_NCCL(R.Send(out[i].ptr, out[i].count, ncclFloat64, to, g_comm, st));
     for (int i = 0; i < n_in; ++i)
-        if (in[i].count) MFX_NCCL(R.Recv(in[i].ptr, in[i].count, ncclFloat64, from, g_comm, mfx::stream()));
+        if (in[i].count) MFX_NCCL(R.Recv(in[i].ptr, in[i].count, ncclFloat64, from, g_comm, st));
     MFX_NCCL(R.GroupEnd());
     return MFX_OK;
 }

@@ -2,19 +2,24 @@
 //
 // Sequential SGD is order dependent, and the user-sharded averaging scheme of mfx_comm.hip (the
 // reference's own two-"machine" prototype, gradient_descent.py:124-211) changes the trajectory.  This
-// mode does not: users are cut into G blocks (one per GPU) and items into G blocks; in sub-epoch s
-// GPU g trains the ratings of block (g, (g+s) mod G) -- the G blocks of a sub-epoch share neither a
-// user nor an item, so running them at the same time IS running them one after the other -- and then
-// hands its item block (rows + biases) to GPU g-1 while it receives the next one from GPU g+1
-// (ncclSend/ncclRecv ring over xGMI).  After G sub-epochs every rating has been applied once and every
-// item block is home again.  The result is bit-identical to the reference's sequential loop
-// (kmf_train.pyx:243-270) run on the rating order
-//     for s in 0..G-1: for g in 0..G-1: ratings of block (g, (g+s) mod G) in their given order
-// which is as legitimate an order as the reference's unseeded shuffle (base.py:1127-1129).
+// mode does not: users are cut into G blocks (one per GPU) and items into B blocks, B = G or B = 2 G.
+// In step h (0 <= h < B) GPU g trains the ratings of block (g, (stride * g + h) mod B), stride = B / G
+// -- the G blocks of a step share neither a user nor an item, so running them at the same time IS
+// running them one after the other -- and then hands that item block (rows + biases) to GPU g - 1, which
+// needs it `stride` steps later.  With B = 2 G every block rests one whole step in transit: the
+// ncclSend/ncclRecv pair of a step rides a second HIP stream under the next step's levels (events order
+// the two streams per block); with B = G the hand-off sits between two steps.  After B steps every
+// rating has been applied once and every item block is home again.  The result is bit-identical to the
+// reference's sequential loop (kmf_train.pyx:243-270) run on the rating order
+//     for h in 0..B-1: for g in 0..G-1: ratings of block (g, (stride * g + h) mod B), in block order
+// where "block order" is the given order, or (MFX_DSGD_BALANCED) the block's first-fit recolouring with
+// the fewest dependency levels -- as legitimate an order as the reference's unseeded shuffle
+// (base.py:1127-1129).  mfx_dsgd_get_order returns that order for the tests to feed the oracle with.
 //
-// One DSGD rank = G sub-plans (one per item block) that share the rank's user rows.  rank = -1 keeps
-// all G ranks in this process on this GPU ("fake world": the rotation is a device copy); it runs the
-// same code path except for the transport and is what the single-GPU tests drive.
+// One DSGD rank = B sub-plans (one per item block) that share the rank's user rows.  rank = -1 keeps
+// all G ranks in this process on this GPU ("fake world": the hand-off is a device copy on the second
+// stream, same events); it runs the same code path except for the transport and is what the single-GPU
+// tests drive.
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -27,7 +32,11 @@ namespace {
 struct DsgdRank {
     int g = 0;                              // this rank's user block
     int user_lo = 0, nu_local = 0;
-    std::vector<mfx_sgd_plan *> plans;      // [G]: block (g, j); plans[0] owns the user-side buffers
+    std::vector<mfx_sgd_plan *> plans;      // [B]: block (g, j); plans[0] owns the user-side buffers
+    std::vector<hipEvent_t> trained;        // [B]: recorded on the compute stream after block j's levels
+    std::vector<hipEvent_t> arrived;        // [B]: recorded on the transfer stream after block j has landed
+    std::vector<char> in_flight;            // [B]: block j has a pending arrival to wait for
+    std::vector<std::vector<int64_t>> orig; // [B]: original rating index of every position of block j
 };
 
 int block_of(const std::vector<int64_t> &bounds, int64_t x)
@@ -45,11 +54,13 @@ int block_of(const std::vector<int64_t> &bounds, int64_t x)
 
 struct mfx_dsgd {
     int world = 1, rank = 0;                // rank < 0: fake world
+    int B = 1, stride = 1;                  // item blocks, B / world
     int nu = 0, ni = 0, k = 0;
-    std::vector<int64_t> ub, ib;            // user / item block bounds [world + 1]
+    std::vector<int64_t> ub, ib;            // user [world + 1] / item [B + 1] block bounds
     std::vector<DsgdRank> ranks;            // 1 (a real rank) or world (fake world)
     bool have_factors = false;
     int64_t nnz_local = 0;
+    hipStream_t xfer = nullptr;             // transfer stream
 };
 
 extern "C" {
@@ -57,29 +68,44 @@ extern "C" {
 void mfx_dsgd_destroy(mfx_dsgd *d)
 {
     if (!d) return;
+    if (ready()) {
+        (void)hipStreamSynchronize(stream());
+        if (d->xfer) (void)hipStreamSynchronize(d->xfer);
+    }
     for (DsgdRank &r : d->ranks) {
+        for (hipEvent_t e : r.trained) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : r.arrived) if (e) (void)hipEventDestroy(e);
         // sub-plans that alias the user side first, their owner (plans[0]) last
         for (size_t j = r.plans.size(); j-- > 0;)
             if (r.plans[j]) mfx_sgd_plan_destroy(r.plans[j]);
     }
+    if (d->xfer) (void)hipStreamDestroy(d->xfer);
     delete d;
 }
 
 mfx_dsgd *mfx_dsgd_create(const int32_t *idx, const double *r, int64_t nnz, int nu, int ni, int dim,
-                          const int64_t *user_bounds, const int64_t *item_bounds, int rank, int world)
+                          const int64_t *user_bounds, const int64_t *item_bounds, int n_item_blocks, int rank,
+                          int world, int flags)
 {
     TraceRange trace_("mfx:dsgd_create (block split + schedules)");
     if ((nnz > 0 && (!idx || !r)) || nnz < 0 || nu <= 0 || ni <= 0 || dim < 1 || !user_bounds || !item_bounds ||
-        world < 1 || rank < -1 || rank >= world) {
-        fail(MFX_E_ARG, "mfx_dsgd_create: bad argument");
+        world < 1 || rank < -1 || rank >= world || (n_item_blocks != world && n_item_blocks != 2 * world) ||
+        (flags & ~MFX_DSGD_BALANCED)) {
+        fail(MFX_E_ARG, "mfx_dsgd_create: bad argument (item blocks must be world or 2 * world)");
         return nullptr;
     }
-    if (user_bounds[0] != 0 || user_bounds[world] != nu || item_bounds[0] != 0 || item_bounds[world] != ni) {
+    const int B = n_item_blocks;
+    if (user_bounds[0] != 0 || user_bounds[world] != nu || item_bounds[0] != 0 || item_bounds[B] != ni) {
         fail(MFX_E_ARG, "mfx_dsgd_create: bounds must run from 0 to nu / ni");
         return nullptr;
     }
     for (int g = 0; g < world; ++g)
-        if (user_bounds[g + 1] < user_bounds[g] || item_bounds[g + 1] < item_bounds[g]) {
+        if (user_bounds[g + 1] < user_bounds[g]) {
+            fail(MFX_E_ARG, "mfx_dsgd_create: bounds must be ascending");
+            return nullptr;
+        }
+    for (int j = 0; j < B; ++j)
+        if (item_bounds[j + 1] < item_bounds[j]) {
             fail(MFX_E_ARG, "mfx_dsgd_create: bounds must be ascending");
             return nullptr;
         }
@@ -96,15 +122,22 @@ mfx_dsgd *mfx_dsgd_create(const int32_t *idx, const double *r, int64_t nnz, int 
     try {
         d->world = world;
         d->rank = rank;
+        d->B = B;
+        d->stride = B / world;
         d->nu = nu;
         d->ni = ni;
         d->k = dim;
         d->ub.assign(user_bounds, user_bounds + world + 1);
-        d->ib.assign(item_bounds, item_bounds + world + 1);
+        d->ib.assign(item_bounds, item_bounds + B + 1);
+        if (hipStreamCreateWithFlags(&d->xfer, hipStreamNonBlocking) != hipSuccess) {
+            fail(MFX_E_HIP, "mfx_dsgd_create: cannot create the transfer stream");
+            mfx_dsgd_destroy(d);
+            return nullptr;
+        }
         const int g0 = rank < 0 ? 0 : rank, g1 = rank < 0 ? world : rank + 1;
         const int nr = g1 - g0;
         // split the ratings (order preserved) into this process's blocks, ids made block-local
-        std::vector<int64_t> cnt((size_t)nr * world, 0);
+        std::vector<int64_t> cnt((size_t)nr * B, 0);
         std::vector<int32_t> blk((size_t)(nnz ? nnz : 1));       // block slot per rating, -1 = not ours
         for (int64_t t = 0; t < nnz; ++t) {
             const int32_t u = idx[2 * t], i = idx[2 * t + 1];
@@ -116,25 +149,28 @@ mfx_dsgd *mfx_dsgd_create(const int32_t *idx, const double *r, int64_t nnz, int 
             }
             const int g = block_of(d->ub, u);
             if (g < g0 || g >= g1) { blk[t] = -1; continue; }
-            const int b = (g - g0) * world + block_of(d->ib, i);
+            const int b = (g - g0) * B + block_of(d->ib, i);
             blk[t] = b;
             ++cnt[b];
         }
-        std::vector<std::vector<int32_t>> bidx((size_t)nr * world);
-        std::vector<std::vector<double>> br((size_t)nr * world);
+        std::vector<std::vector<int32_t>> bidx((size_t)nr * B);
+        std::vector<std::vector<double>> br((size_t)nr * B);
+        std::vector<std::vector<int64_t>> borig((size_t)nr * B);
         for (size_t b = 0; b < cnt.size(); ++b) {
             bidx[b].resize((size_t)cnt[b] * 2 + 2);
             br[b].resize((size_t)cnt[b] + 1);
+            borig[b].resize((size_t)cnt[b]);
             cnt[b] = 0;
         }
         for (int64_t t = 0; t < nnz; ++t) {
             const int b = blk[t];
             if (b < 0) continue;
-            const int g = g0 + b / world, j = b % world;
+            const int g = g0 + b / B, j = b % B;
             const int64_t c = cnt[b]++;
             bidx[b][2 * c] = idx[2 * t] - (int32_t)d->ub[g];
             bidx[b][2 * c + 1] = idx[2 * t + 1] - (int32_t)d->ib[j];
             br[b][c] = r[t];
+            borig[b][c] = t;
             ++d->nnz_local;
         }
         std::vector<int32_t>().swap(blk);
@@ -144,20 +180,45 @@ mfx_dsgd *mfx_dsgd_create(const int32_t *idx, const double *r, int64_t nnz, int 
             R.g = g0 + gi;
             R.user_lo = (int)d->ub[R.g];
             R.nu_local = (int)(d->ub[R.g + 1] - d->ub[R.g]);
-            R.plans.assign((size_t)world, nullptr);
-            for (int j = 0; j < world; ++j) {
-                const size_t b = (size_t)gi * world + j;
+            R.plans.assign((size_t)B, nullptr);
+            R.trained.assign((size_t)B, nullptr);
+            R.arrived.assign((size_t)B, nullptr);
+            R.in_flight.assign((size_t)B, 0);
+            R.orig.resize((size_t)B);
+            for (int j = 0; j < B; ++j) {
+                const size_t b = (size_t)gi * B + j;
                 const int nij = (int)(d->ib[j + 1] - d->ib[j]);
-                R.plans[j] = mfx_sgd_plan_create(bidx[b].data(), br[b].data(), cnt[b], R.nu_local > 0 ? R.nu_local : 1,
-                                                 nij > 0 ? nij : 1, dim);
-                if (!R.plans[j]) {
+                const int nul = R.nu_local > 0 ? R.nu_local : 1, nil = nij > 0 ? nij : 1;
+                if ((flags & MFX_DSGD_BALANCED) && cnt[b] >= 2) {
+                    // the block's own minimum-level order (first-fit recolouring of its dependency levels);
+                    // a refusal (too many levels, scratch) keeps the given order -- never a wrong one
+                    std::vector<int64_t> perm((size_t)cnt[b]);
+                    int64_t rounds = 0;
+                    if (mfx_schedule_balanced_order_gpu(bidx[b].data(), cnt[b], nul, nil, perm.data(), &rounds) == MFX_OK) {
+                        std::vector<int32_t> ni2((size_t)cnt[b] * 2 + 2);
+                        std::vector<double> nr2((size_t)cnt[b] + 1);
+                        std::vector<int64_t> no2((size_t)cnt[b]);
+                        for (int64_t c = 0; c < cnt[b]; ++c) {
+                            const int64_t s = perm[(size_t)c];
+                            ni2[2 * c] = bidx[b][2 * s];
+                            ni2[2 * c + 1] = bidx[b][2 * s + 1];
+                            nr2[c] = br[b][s];
+                            no2[c] = borig[b][s];
+                        }
+                        bidx[b].swap(ni2);
+                        br[b].swap(nr2);
+                        borig[b].swap(no2);
+                    }
+                }
+                R.plans[j] = mfx_sgd_plan_create(bidx[b].data(), br[b].data(), cnt[b], nul, nil, dim);
+                if (!R.plans[j] || (j > 0 && plan_alias_users(R.plans[j], R.plans[0])) ||
+                    hipEventCreateWithFlags(&R.trained[j], hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&R.arrived[j], hipEventDisableTiming) != hipSuccess) {
+                    if (R.plans[j]) fail(MFX_E_HIP, "mfx_dsgd_create: block (%d, %d) set-up failed", R.g, j);
                     mfx_dsgd_destroy(d);
                     return nullptr;
                 }
-                if (j > 0 && plan_alias_users(R.plans[j], R.plans[0])) {
-                    mfx_dsgd_destroy(d);
-                    return nullptr;
-                }
+                R.orig[j].swap(borig[b]);
                 std::vector<int32_t>().swap(bidx[b]);
                 std::vector<double>().swap(br[b]);
             }
@@ -170,14 +231,15 @@ mfx_dsgd *mfx_dsgd_create(const int32_t *idx, const double *r, int64_t nnz, int 
     return d;
 }
 
-/* info[0] = ratings held by this process, [1] = sum of dependency levels over its blocks,
- * [2] = largest block (ratings), [3] = smallest block, [4] = launches per epoch (all blocks) */
+/* info[0] = ratings held by this process, [1] = dependency levels summed over its blocks,
+ * [2] = largest block (ratings), [3] = smallest block, [4] = launches per epoch (all blocks), [5] = item blocks */
 int mfx_dsgd_info(const mfx_dsgd *d, int64_t info[8])
 {
     if (!d || !info) return fail(MFX_E_ARG, "mfx_dsgd_info: NULL");
     memset(info, 0, 8 * sizeof(int64_t));
     info[0] = d->nnz_local;
     info[3] = INT64_MAX;
+    info[5] = d->B;
     for (const DsgdRank &R : d->ranks)
         for (mfx_sgd_plan *p : R.plans) {
             int64_t pi[8];
@@ -191,8 +253,23 @@ int mfx_dsgd_info(const mfx_dsgd *d, int64_t info[8])
     return MFX_OK;
 }
 
+// The rating order this object's epoch is bit-identical to, restricted to the ratings this process holds:
+// for h: for its ranks g (ascending): block (g, (stride g + h) mod B) in block order.  perm_out[p] = index
+// (into the arrays given to mfx_dsgd_create) of the p-th rating; nnz_local entries.
+int mfx_dsgd_get_order(const mfx_dsgd *d, int64_t *perm_out)
+{
+    if (!d || !perm_out) return fail(MFX_E_ARG, "mfx_dsgd_get_order: NULL");
+    int64_t p = 0;
+    for (int h = 0; h < d->B; ++h)
+        for (const DsgdRank &R : d->ranks) {
+            const std::vector<int64_t> &o = R.orig[(size_t)((d->stride * R.g + h) % d->B)];
+            for (int64_t t : o) perm_out[p++] = t;
+        }
+    return MFX_OK;
+}
+
 // u [k, ni] / items_bias [ni]: the FULL item side (every rank passes the same arrays; a rank keeps the
-// block it starts with).  v [k, nu_local] / users_bias [nu_local]: this rank's users -- in the fake
+// blocks it starts with).  v [k, nu_local] / users_bias [nu_local]: this rank's users -- in the fake
 // world (rank -1) the full [k, nu] / [nu].
 int mfx_dsgd_set_factors(mfx_dsgd *d, const double *u, const double *v, const double *items_bias,
                          const double *users_bias)
@@ -201,6 +278,7 @@ int mfx_dsgd_set_factors(mfx_dsgd *d, const double *u, const double *v, const do
     if (!d || !u || !v) return fail(MFX_E_ARG, "mfx_dsgd_set_factors: NULL argument");
     const int k = d->k;
     const int64_t v_ld = d->rank < 0 ? d->nu : d->ranks[0].nu_local;      // row length of the v passed in
+    MFX_HIP(hipStreamSynchronize(d->xfer));
     std::vector<double> tmp;
     for (DsgdRank &R : d->ranks) {
         // users: the rank's column range of v
@@ -213,9 +291,9 @@ int mfx_dsgd_set_factors(mfx_dsgd *d, const double *u, const double *v, const do
         if (users_bias && R.nu_local > 0) memcpy(ubt.data(), users_bias + off, (size_t)R.nu_local * sizeof(double));
         int rc = plan_upload_users(R.plans[0], tmp.data(), ubt.data());
         if (rc) return rc;
-        // items: block j = g is the one this rank starts with; the other blocks arrive by rotation, but
-        // every sub-plan gets its block here so that a plan is never run on uninitialised rows
-        for (int j = 0; j < d->world; ++j) {
+        // items: every sub-plan gets its block here (a rank starts with its home blocks; the others are
+        // overwritten by the rotation before they are trained), so no plan ever runs on uninitialised rows
+        for (int j = 0; j < d->B; ++j) {
             const int nij = (int)(d->ib[j + 1] - d->ib[j]);
             const int m = nij > 0 ? nij : 1;
             tmp.assign((size_t)k * m, 0.0);
@@ -226,6 +304,7 @@ int mfx_dsgd_set_factors(mfx_dsgd *d, const double *u, const double *v, const do
             rc = plan_upload_items(R.plans[j], tmp.data(), ibt.data());
             if (rc) return rc;
             plan_mark_ready(R.plans[j]);
+            R.in_flight[j] = 0;
         }
     }
     d->have_factors = true;
@@ -233,7 +312,7 @@ int mfx_dsgd_set_factors(mfx_dsgd *d, const double *u, const double *v, const do
 }
 
 // se_out (nullable): f64[nbr_epochs], the squared-error sum of each epoch over ALL ratings of the job
-// (online, as the reference accumulates it, kmf_train.pyx:257); blocks are added in sub-epoch order,
+// (online, as the reference accumulates it, kmf_train.pyx:257); blocks are added in step order,
 // ranks in rank order.
 int mfx_dsgd_run_kmf(mfx_dsgd *d, int mode, int nbr_epochs, double lr, double Ku, double Ki, double Kb,
                      double *se_out)
@@ -243,57 +322,74 @@ int mfx_dsgd_run_kmf(mfx_dsgd *d, int mode, int nbr_epochs, double lr, double Ku
     if (!d->have_factors) return fail(MFX_E_STATE, "mfx_dsgd_run_kmf: mfx_dsgd_set_factors has not been called");
     if (mode != MFX_MODE_LINEAR && mode != MFX_MODE_LOGISTIC) return fail(MFX_E_ARG, "mfx_dsgd_run_kmf: mode %d", mode);
     if (nbr_epochs <= 0) return MFX_OK;
-    const int G = d->world;
-    hipStream_t s = stream();
+    const int G = d->world, B = d->B, stride = d->stride;
+    hipStream_t s = stream(), x = d->xfer;
     int rc;
     for (DsgdRank &R : d->ranks)
         for (mfx_sgd_plan *p : R.plans)
             if ((rc = sgd_reset_se(p, nbr_epochs))) return rc;
     for (int ep = 0; ep < nbr_epochs; ++ep) {
-        for (int sub = 0; sub < G; ++sub) {
+        for (int h = 0; h < B; ++h) {
+            // ---- compute: every rank of this process trains its block of the step -------------------
             for (DsgdRank &R : d->ranks) {
-                mfx_sgd_plan *p = R.plans[(R.g + sub) % G];
-                if ((rc = sgd_enqueue_k1(p, mode, lr, Ku, Ki, Kb))) return rc;
+                const int j = (stride * R.g + h) % B;
+                if (R.in_flight[j]) {                             // the block travelled here: wait for it
+                    MFX_HIP(hipStreamWaitEvent(s, R.arrived[j], 0));
+                    R.in_flight[j] = 0;
+                }
+                if ((rc = sgd_enqueue_k1(R.plans[j], mode, lr, Ku, Ki, Kb))) return rc;
+                if (G > 1) MFX_HIP(hipEventRecord(R.trained[j], s));
             }
             if (G == 1) continue;
-            // rotate: block j = (g + sub) % G leaves rank g for rank g - 1
+            // ---- hand-off on the transfer stream: block j leaves rank g for rank g - 1, which trains it
+            //      `stride` steps later; with stride 2 it travels under the next step's levels ---------
             if (d->rank < 0) {
                 for (DsgdRank &R : d->ranks) {
-                    const int j = (R.g + sub) % G;
-                    DsgdRank &dst = d->ranks[(R.g + G - 1) % G];
+                    const int j = (stride * R.g + h) % B;
+                    DsgdRank &dst = d->ranks[(size_t)((R.g + G - 1) % G)];
                     mfx_sgd_plan *from = R.plans[j], *to = dst.plans[j];
+                    MFX_HIP(hipStreamWaitEvent(x, R.trained[j], 0));
                     MFX_HIP(hipMemcpyAsync(plan_U(to), plan_U(from), (size_t)plan_ni(from) * d->k * sizeof(double),
-                                           hipMemcpyDeviceToDevice, s));
+                                           hipMemcpyDeviceToDevice, x));
                     MFX_HIP(hipMemcpyAsync(plan_ib(to), plan_ib(from), (size_t)plan_ni(from) * sizeof(double),
-                                           hipMemcpyDeviceToDevice, s));
+                                           hipMemcpyDeviceToDevice, x));
+                    MFX_HIP(hipEventRecord(dst.arrived[j], x));
+                    dst.in_flight[j] = 1;
                 }
             } else {
                 DsgdRank &R = d->ranks[0];
-                const int j_out = (R.g + sub) % G, j_in = (R.g + sub + 1) % G;
+                const int j_out = (stride * R.g + h) % B, j_in = (stride * (R.g + 1) + h) % B;
                 mfx_sgd_plan *po = R.plans[j_out], *pi = R.plans[j_in];
                 // empty item blocks are stored as one padding row: nothing travels for them
                 const size_t n_out = (size_t)(d->ib[j_out + 1] - d->ib[j_out]), n_in = (size_t)(d->ib[j_in + 1] - d->ib[j_in]);
                 const CommSeg out[2] = {{plan_U(po), n_out * d->k}, {plan_ib(po), n_out}};
                 const CommSeg in[2] = {{plan_U(pi), n_in * d->k}, {plan_ib(pi), n_in}};
-                if ((rc = comm_sendrecv_f64(out, 2, (R.g + G - 1) % G, in, 2, (R.g + 1) % G))) return rc;
+                MFX_HIP(hipStreamWaitEvent(x, R.trained[j_out], 0));
+                if ((rc = comm_sendrecv_f64(out, 2, (R.g + G - 1) % G, in, 2, (R.g + 1) % G, x))) return rc;
+                MFX_HIP(hipEventRecord(R.arrived[j_in], x));
+                R.in_flight[j_in] = 1;
             }
         }
     }
+    // the epoch ends with every block home again; join the transfer stream
+    MFX_HIP(hipStreamSynchronize(x));
     MFX_HIP(hipStreamSynchronize(s));
+    for (DsgdRank &R : d->ranks)
+        for (int j = 0; j < B; ++j) R.in_flight[j] = 0;
     if (se_out) {
-        std::vector<double> se((size_t)nbr_epochs, 0.0), tmp((size_t)nbr_epochs);
-        // per epoch: blocks in sub-epoch order, ranks in rank order (fake world: exactly the order of the
+        std::vector<double> se((size_t)nbr_epochs, 0.0);
+        // per epoch: blocks in step order, ranks in rank order (fake world: exactly the order of the
         // equivalent sequential run; real ranks: each rank's partial, then a rank-ordered sum)
-        std::vector<std::vector<double>> per((size_t)d->ranks.size() * G);
+        std::vector<std::vector<double>> per((size_t)d->ranks.size() * B);
         for (size_t gi = 0; gi < d->ranks.size(); ++gi)
-            for (int j = 0; j < G; ++j) {
-                per[gi * G + j].resize((size_t)nbr_epochs);
-                if ((rc = sgd_fetch_se(d->ranks[gi].plans[j], nbr_epochs, per[gi * G + j].data()))) return rc;
+            for (int j = 0; j < B; ++j) {
+                per[gi * B + j].resize((size_t)nbr_epochs);
+                if ((rc = sgd_fetch_se(d->ranks[gi].plans[j], nbr_epochs, per[gi * B + j].data()))) return rc;
             }
         for (int ep = 0; ep < nbr_epochs; ++ep)
-            for (int sub = 0; sub < G; ++sub)
+            for (int h = 0; h < B; ++h)
                 for (size_t gi = 0; gi < d->ranks.size(); ++gi)
-                    se[ep] += per[gi * G + (d->ranks[gi].g + sub) % G][ep];
+                    se[ep] += per[gi * B + (size_t)((stride * d->ranks[gi].g + h) % B)][ep];
         if (d->rank >= 0 && G > 1) {
             // all-gather the per-rank partials and add them in rank order (deterministic)
             double *dbuf = nullptr;
@@ -325,8 +421,9 @@ int mfx_dsgd_get_factors(mfx_dsgd *d, double *u, double *v, double *items_bias, 
     TraceRange trace_("mfx:dsgd_get_factors");
     if (!d) return fail(MFX_E_ARG, "mfx_dsgd_get_factors: NULL");
     if (!d->have_factors) return fail(MFX_E_STATE, "mfx_dsgd_get_factors: no factors");
-    const int k = d->k, G = d->world;
+    const int k = d->k, G = d->world, B = d->B;
     const int64_t v_ld = d->rank < 0 ? d->nu : d->ranks[0].nu_local;
+    MFX_HIP(hipStreamSynchronize(d->xfer));
     std::vector<double> tmp, bt;
     int rc;
     for (DsgdRank &R : d->ranks) {
@@ -342,17 +439,18 @@ int mfx_dsgd_get_factors(mfx_dsgd *d, double *u, double *v, double *items_bias, 
         }
     }
     if (!u && !items_bias) return MFX_OK;
-    // between epochs block j is at rank j (plan (j, j)); a real rank broadcasts its block to the others
-    for (int j = 0; j < G; ++j) {
+    // between epochs block j is at its home rank j / stride; a real rank broadcasts its blocks to the others
+    for (int j = 0; j < B; ++j) {
         const int nij = (int)(d->ib[j + 1] - d->ib[j]);
         if (nij <= 0) continue;
+        const int home = j / d->stride;
         mfx_sgd_plan *p = nullptr;
-        if (d->rank < 0) p = d->ranks[j].plans[j];
+        if (d->rank < 0) p = d->ranks[(size_t)home].plans[j];
         else {
             p = d->ranks[0].plans[j];
             if (G > 1) {
-                if ((rc = comm_broadcast_f64(plan_U(p), (size_t)nij * k, j))) return rc;
-                if ((rc = comm_broadcast_f64(plan_ib(p), (size_t)nij, j))) return rc;
+                if ((rc = comm_broadcast_f64(plan_U(p), (size_t)nij * k, home))) return rc;
+                if ((rc = comm_broadcast_f64(plan_ib(p), (size_t)nij, home))) return rc;
             }
         }
         tmp.resize((size_t)k * nij);

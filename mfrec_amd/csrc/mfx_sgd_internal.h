@@ -60,9 +60,10 @@ int comm_world();
 int comm_allgather_f64(double *buf, size_t count);          // in place: rank g's part at buf + g*count
 int comm_allreduce_sum_f64(double *buf, size_t count);      // in place, library stream
 int comm_broadcast_f64(double *buf, size_t count, int root);
-// one fused group on the library stream: send every (ptr, count) of `out` to `to`, receive every
-// (ptr, count) of `in` from `from`
+// one fused group on stream `st` (nullptr: the library stream): send every (ptr, count) of `out` to `to`,
+// receive every (ptr, count) of `in` from `from`
 struct CommSeg { double *ptr; size_t count; };
-int comm_sendrecv_f64(const CommSeg *out, int n_out, int to, const CommSeg *in, int n_in, int from);
+int comm_sendrecv_f64(const CommSeg *out, int n_out, int to, const CommSeg *in, int n_in, int from,
+                      hipStream_t st = nullptr);
 
 }  // namespace mfx

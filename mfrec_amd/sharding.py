@@ -110,46 +110,58 @@ def item_blocks(ratings_index, nbr_items, world):
 
 
 def dsgd_block_order(ratings_index, user_bounds, item_bounds):
-    """The sequential rating order a DSGD epoch is bit-identical to: sub-epoch s = 0..G-1, inside it
-    GPU g = 0..G-1 with its block (g, (g+s) mod G), inside a block the given order.  -> int64 perm."""
-    G = len(user_bounds) - 1
+    """The sequential rating order a DSGD epoch is bit-identical to (given order inside the blocks): step
+    h = 0..B-1, inside it GPU g = 0..G-1 with its block (g, (stride g + h) mod B), stride = B / G, inside a
+    block the given order.  B = len(item_bounds) - 1 is G or 2 G.  -> int64 perm."""
+    G, B = len(user_bounds) - 1, len(item_bounds) - 1
+    stride = B // G
     ub = np.searchsorted(user_bounds, ratings_index[:, 0], side="right") - 1
     jb = np.searchsorted(item_bounds, ratings_index[:, 1], side="right") - 1
     # empty blocks repeat a bound: searchsorted(right) lands on the LAST block starting at that id,
     # which is the non-empty one -- the same choice as the library's binary search
-    sub = (jb - ub) % G
-    return np.lexsort((np.arange(ratings_index.shape[0]), ub, sub)).astype(np.int64)
+    step = (jb - stride * ub) % B
+    return np.lexsort((np.arange(ratings_index.shape[0]), ub, step)).astype(np.int64)
 
 
-def dsgd_epoch_loop(nbr_epochs, rank, world, train_block, rotate):
-    """Generic DSGD driver (what mfx_dsgd_run_kmf does inside libmfx): train_block(j) runs this rank's
-    ratings of item block j in place; rotate(j_out, j_in) sends block j_out to rank-1 and receives block
-    j_in from rank+1."""
+def dsgd_epoch_loop(nbr_epochs, rank, world, n_item_blocks, train_block, post_transfer, wait_block):
+    """Generic DSGD driver (what mfx_dsgd_run_kmf does inside libmfx).  In step h this rank trains item block
+    j = (stride rank + h) mod B (after wait_block(j), which blocks until a transfer into j has landed), then
+    post_transfer(j_out, j_in) starts sending j_out to rank-1 and receiving j_in = (stride (rank+1) + h) mod B
+    from rank+1 -- asynchronously: with B = 2 world the received block is needed only two steps later."""
+    B = n_item_blocks
+    stride = B // world
     for _ in range(nbr_epochs):
-        for s in range(world):
-            j = (rank + s) % world
+        for h in range(B):
+            j = (stride * rank + h) % B
+            wait_block(j)
             train_block(j)
             if world > 1:
-                rotate(j, (j + 1) % world)
+                post_transfer(j, (stride * (rank + 1) + h) % B)
 
 
 class DsgdKMF(object):
     """Exact multi-GPU full-k SGD (mfx_dsgd_*).  rank = -1: every rank in this process on this GPU."""
 
     def __init__(self, ratings_index, ratings, nbr_users, nbr_items, dim, rank, world,
-                 user_bounds=None, item_bounds=None):
+                 user_bounds=None, item_bounds=None, overlap=True, balanced=False):
+        """overlap: 2 * world item blocks (a block rests one step in transit: hand-offs under the next step's
+        levels) instead of world; balanced: every block in its own minimum-level order.  Explicit item_bounds
+        decide the block count themselves (world + 1 or 2 * world + 1 entries)."""
         import ctypes as C
         from . import _shim as S
         self.rank, self.world, self.k = int(rank), int(world), int(dim)
         self.nu, self.ni = int(nbr_users), int(nbr_items)
         self.user_bounds = np.ascontiguousarray(
             user_blocks(ratings_index, nbr_users, world) if user_bounds is None else user_bounds, dtype=np.int64)
+        nb = (2 * self.world if (overlap and self.world > 1) else self.world)
         self.item_bounds = np.ascontiguousarray(
-            item_blocks(ratings_index, nbr_items, world) if item_bounds is None else item_bounds, dtype=np.int64)
+            item_blocks(ratings_index, nbr_items, nb) if item_bounds is None else item_bounds, dtype=np.int64)
+        self.n_item_blocks = len(self.item_bounds) - 1
         pi, pr, nnz = S.ratings_args(ratings_index, ratings)
         self._h = S.lib().mfx_dsgd_create(pi, pr, nnz, self.nu, self.ni, self.k,
                                           self.user_bounds.ctypes.data_as(S._lp),
-                                          self.item_bounds.ctypes.data_as(S._lp), self.rank, self.world)
+                                          self.item_bounds.ctypes.data_as(S._lp), self.n_item_blocks,
+                                          self.rank, self.world, 1 if balanced else 0)
         if not self._h:
             msg = S.last_error()
             raise (ValueError if ("outside" in msg or "bad argument" in msg or "bounds" in msg) else S.MfxError)(msg)
@@ -162,8 +174,16 @@ class DsgdKMF(object):
         from . import _shim as S
         a = (C.c_int64 * 8)()
         S.check(S.lib().mfx_dsgd_info(self._h, a))
-        return dict(zip(("nnz_local", "levels_total", "max_block", "min_block", "launches_per_epoch"),
-                        [int(x) for x in a][:5]))
+        return dict(zip(("nnz_local", "levels_total", "max_block", "min_block", "launches_per_epoch", "item_blocks"),
+                        [int(x) for x in a][:6]))
+
+    def order(self):
+        """int64 perm: the sequential rating order this object's epoch is bit-identical to (the ratings this
+        process holds; indices into the arrays given to the constructor)."""
+        from . import _shim as S
+        perm = np.empty(self.info()["nnz_local"], dtype=np.int64)
+        S.check(S.lib().mfx_dsgd_get_order(self._h, perm.ctypes.data_as(S._lp)))
+        return perm
 
     def _args(self, u, v, items_bias, users_bias):
         from . import _shim as S

@@ -9,9 +9,11 @@ from oracle import oracle as O
 
 
 def simulate(mode, nbr_epochs, k, lr, Ku, Ki, Kb, u0, v0, ib0, ub0, ratings_index, ratings,
-             user_bounds, item_bounds):
-    """-> (u, v, ib, ub, rmse[nbr_epochs]) of the sequential oracle on the DSGD block order."""
-    perm = SH.dsgd_block_order(ratings_index, user_bounds, item_bounds)
+             user_bounds, item_bounds, perm=None):
+    """-> (u, v, ib, ub, rmse[nbr_epochs]) of the sequential oracle on the DSGD block order (or on the
+    explicit order `perm`, e.g. DsgdKMF.order() of a balanced run)."""
+    if perm is None:
+        perm = SH.dsgd_block_order(ratings_index, user_bounds, item_bounds)
     idx = np.ascontiguousarray(ratings_index[perm])
     r = np.ascontiguousarray(ratings[perm])
     u, v, ib, ub = u0.copy(), v0.copy(), ib0.copy(), ub0.copy()

@@ -1,7 +1,9 @@
 """CPU: host logic of the exact multi-GPU mode (DSGD block rotation, mfrec_amd/sharding.py).
-  * the block order is a permutation, sub-epoch major, and its sub-epochs are conflict free;
-  * world_size-2 gloo run (two real processes, item blocks travelling by send/recv) of
-    sharding.dsgd_epoch_loop == the sequential oracle on that block order, bit for bit."""
+  * the block order is a permutation, step major, and its steps are conflict free -- for B = G item
+    blocks and for B = 2 G (a block rests one step in transit);
+  * world_size-2 gloo run (two real processes, item blocks travelling by ASYNCHRONOUS isend/irecv that are
+    only waited for when the block is needed) of sharding.dsgd_epoch_loop == the sequential oracle on that
+    block order, bit for bit, for both block counts."""
 import os
 import socket
 import subprocess
@@ -27,25 +29,30 @@ def _problem():
 def test_block_order_is_a_conflict_free_stratification():
     idx, r, _, _ = _problem()
     for G in (1, 2, 3, 8):
-        ub, jb = SH.user_blocks(idx, NU, G), SH.item_blocks(idx, NI, G)
-        assert jb[0] == 0 and jb[-1] == NI and np.all(np.diff(jb) >= 0)
-        perm = SH.dsgd_block_order(idx, ub, jb)
-        assert np.array_equal(np.sort(perm), np.arange(NNZ))
-        o = idx[perm]
-        g = np.searchsorted(ub, o[:, 0], side="right") - 1
-        j = np.searchsorted(jb, o[:, 1], side="right") - 1
-        sub = (j - g) % G
-        assert np.all(np.diff(sub) >= 0)                       # sub-epoch major
-        for s in range(G):
-            gs = g[sub == s]
-            assert np.all(np.diff(gs) >= 0)                    # then by GPU
-            # inside a sub-epoch GPU g owns item block (g+s)%G only: no two GPUs share a user or an item
-            assert np.array_equal(j[sub == s], (gs + s) % G)
-        # inside a block the given order is kept
-        for gg in range(G):
-            for jj in range(G):
-                sel = (g == gg) & (j == jj)
-                assert np.all(np.diff(perm[sel]) > 0)
+        for mult in (1, 2):
+            B = G * mult
+            ub, jb = SH.user_blocks(idx, NU, G), SH.item_blocks(idx, NI, B)
+            assert jb[0] == 0 and jb[-1] == NI and np.all(np.diff(jb) >= 0) and len(jb) == B + 1
+            perm = SH.dsgd_block_order(idx, ub, jb)
+            assert np.array_equal(np.sort(perm), np.arange(NNZ))
+            o = idx[perm]
+            g = np.searchsorted(ub, o[:, 0], side="right") - 1
+            j = np.searchsorted(jb, o[:, 1], side="right") - 1
+            step = (j - mult * g) % B
+            assert np.all(np.diff(step) >= 0)                      # step major
+            for h in range(B):
+                gs = g[step == h]
+                assert np.all(np.diff(gs) >= 0)                    # then by GPU
+                # inside a step GPU g owns item block (mult g + h) % B only: no two GPUs share a user or an item
+                assert np.array_equal(j[step == h], (mult * gs + h) % B)
+                owners = {}
+                for gg, jj in zip(gs.tolist(), j[step == h].tolist()):
+                    assert owners.setdefault(jj, gg) == gg
+            # inside a block the given order is kept
+            for gg in range(G):
+                for jj in range(B):
+                    sel = (g == gg) & (j == jj)
+                    assert np.all(np.diff(perm[sel]) > 0)
 
 
 def test_empty_blocks_and_degenerate_bounds():
@@ -65,45 +72,62 @@ from oracle import oracle as O
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 NU, NI, NNZ, K, E = %(dims)s
+B = %(blocks)d
 idx, r = synth.make_ratings(NU, NI, NNZ, seed=77)
 u = synth.init_normal(K, NI, 1); v0 = synth.init_normal(K, NU, 2)
-ub_ = SH.user_blocks(idx, NU, world); jb_ = SH.item_blocks(idx, NI, world)
+ub_ = SH.user_blocks(idx, NU, world); jb_ = SH.item_blocks(idx, NI, B)
 lo, hi = int(ub_[rank]), int(ub_[rank + 1])
 v = np.ascontiguousarray(v0[:, lo:hi]); ubias = np.zeros(hi - lo)
 # per item block: this rank's ratings (local ids) and the block's item state; a rank starts with all
-# blocks' INITIAL values but only ever trains a block after having received it (or, for its own, at s=0)
+# blocks' INITIAL values but only ever trains a block it holds (its home blocks, or one that has arrived)
 blocks = []
-for j in range(world):
+for j in range(B):
     a, b = int(jb_[j]), int(jb_[j + 1])
     sel = (idx[:, 0] >= lo) & (idx[:, 0] < hi) & (idx[:, 1] >= a) & (idx[:, 1] < b)
     bi = np.ascontiguousarray(idx[sel]).copy(); bi[:, 0] -= lo; bi[:, 1] -= a
     blocks.append(dict(idx=bi, r=np.ascontiguousarray(r[sel]), u=np.ascontiguousarray(u[:, a:b]), ib=np.zeros(b - a)))
+pending = {}                     # block -> requests of a transfer into it that has not been waited for
+sends = []
 def train_block(j):
-    B = blocks[j]
-    if B["r"].shape[0]:
-        O.train_linear_kernel(1, K, 0.1, 0.01, 0, 0, 0.1, 0.1, 0.007, 0.0, B["u"], v, B["idx"], B["r"], B["ib"], ubias)
-def rotate(j_out, j_in):
-    prev, nxt = (rank - 1) %% world, (rank + 1) %% world
-    so = [torch.from_numpy(blocks[j_out]["u"]), torch.from_numpy(blocks[j_out]["ib"])]
-    si = [torch.from_numpy(blocks[j_in]["u"]), torch.from_numpy(blocks[j_in]["ib"])]
-    reqs = [dist.isend(t, prev) for t in so] + [dist.irecv(t, nxt) for t in si]
-    for q in reqs:
+    Bk = blocks[j]
+    if Bk["r"].shape[0]:
+        O.train_linear_kernel(1, K, 0.1, 0.01, 0, 0, 0.1, 0.1, 0.007, 0.0, Bk["u"], v, Bk["idx"], Bk["r"], Bk["ib"], ubias)
+def wait_block(j):
+    for q in pending.pop(j, []):
         q.wait()
-SH.dsgd_epoch_loop(E, rank, world, train_block, rotate)
-np.savez(%(out)r %% rank, u=blocks[rank]["u"], ib=blocks[rank]["ib"], v=v, ub=ubias, lo=lo, hi=hi,
-         a=int(jb_[rank]), b=int(jb_[rank + 1]))
+def post_transfer(j_out, j_in):
+    prev, nxt = (rank - 1) %% world, (rank + 1) %% world
+    # the outgoing block is final (its training has returned); snapshot it so that the buffer may be reused
+    so = [torch.from_numpy(blocks[j_out]["u"].copy()), torch.from_numpy(blocks[j_out]["ib"].copy())]
+    sends.extend(dist.isend(t, prev) for t in so)
+    pending[j_in] = [dist.irecv(torch.from_numpy(blocks[j_in]["u"]), nxt), dist.irecv(torch.from_numpy(blocks[j_in]["ib"]), nxt)]
+SH.dsgd_epoch_loop(E, rank, world, B, train_block, post_transfer, wait_block)
+for q in sends:
+    q.wait()
+for j in list(pending):
+    wait_block(j)
+stride = B // world
+home = [j for j in range(B) if j // stride == rank]
+np.savez(%(out)r %% rank, lo=lo, hi=hi, v=v, ub=ubias, home=np.array(home),
+         **{"u%%d" %% j: blocks[j]["u"] for j in home}, **{"ib%%d" %% j: blocks[j]["ib"] for j in home},
+         **{"a%%d" %% j: int(jb_[j]) for j in home}, **{"b%%d" %% j: int(jb_[j + 1]) for j in home})
 dist.destroy_process_group()
 """
 
 
-def test_two_process_gloo_rotation_equals_sequential_oracle(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("mult", [1, 2])
+def test_two_process_gloo_rotation_equals_sequential_oracle(tmp_path, mult):
     idx, r, u0, v0 = _problem()
-    ub, jb = SH.user_blocks(idx, NU, 2), SH.item_blocks(idx, NI, 2)
+    B = 2 * mult
+    ub, jb = SH.user_blocks(idx, NU, 2), SH.item_blocks(idx, NI, B)
     su, sv, sib, sub, _ = DS.simulate(0, E, K, *HP, u0, v0, np.zeros(NI), np.zeros(NU), idx, r, ub, jb)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "rank%d.npz")
     script = tmp_path / "worker.py"
-    script.write_text(WORKER % {"root": ROOT, "dims": (NU, NI, NNZ, K, E), "out": out})
+    script.write_text(WORKER % {"root": ROOT, "dims": (NU, NI, NNZ, K, E), "out": out, "blocks": B})
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
@@ -111,11 +135,16 @@ def test_two_process_gloo_rotation_equals_sequential_oracle(tmp_path):
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env))
     for p in procs:
         assert p.wait(timeout=240) == 0
+    seen = []
     for rank in range(2):
         z = np.load(out % rank)
-        a, b, lo, hi = int(z["a"]), int(z["b"]), int(z["lo"]), int(z["hi"])
-        assert np.array_equal(z["u"], su[:, a:b]) and np.array_equal(z["ib"], sib[a:b])
+        lo, hi = int(z["lo"]), int(z["hi"])
         assert np.array_equal(z["v"], sv[:, lo:hi]) and np.array_equal(z["ub"], sub[lo:hi])
+        for j in z["home"].tolist():                       # every block is home again after whole epochs
+            a, b = int(z["a%d" % j]), int(z["b%d" % j])
+            assert np.array_equal(z["u%d" % j], su[:, a:b]) and np.array_equal(z["ib%d" % j], sib[a:b])
+            seen.append(j)
+    assert sorted(seen) == list(range(B))
     # and the block order is a genuinely different trajectory from the given order (exact, not equal)
     u2, v2, ib2, ub2 = u0.copy(), v0.copy(), np.zeros(NI), np.zeros(NU)
     O.train_linear_kernel(E, K, 0.1, HP[0], 0, 0, HP[1], HP[2], HP[3], 0.0, u2, v2, idx, r, ib2, ub2)

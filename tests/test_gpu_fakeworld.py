@@ -52,22 +52,33 @@ def test_averaging_fake_world_equals_simulation(world, scale):
     assert se.shape == (world, E) and np.all(np.isfinite(se)) and np.all(se > 0)
 
 
-@pytest.mark.parametrize("world,k,mode", [(1, 16, 0), (2, 64, 0), (3, 10, 0), (8, 64, 0), (4, 32, 1)])
-def test_dsgd_fake_world_equals_sequential_oracle_on_block_order(world, k, mode):
+@pytest.mark.parametrize("world,k,mode,overlap,balanced",
+                         [(1, 16, 0, True, False), (2, 64, 0, True, False), (2, 64, 0, False, False),
+                          (3, 10, 0, True, False), (8, 64, 0, True, False), (8, 64, 0, False, False),
+                          (4, 32, 1, True, False), (4, 64, 0, True, True), (3, 24, 0, False, True)])
+def test_dsgd_fake_world_equals_sequential_oracle_on_block_order(world, k, mode, overlap, balanced):
+    """overlap = 2 * world item blocks (transfers on the second stream, one step of slack) vs world blocks;
+    balanced = every block in its own minimum-level order (the library reports the order it used)."""
+    from mfrec_amd import sharding as SH
     from mfrec_amd.sharding import DsgdKMF
     from oracle import dsgd_sim as DS
     nu, ni, nnz, E = 900, 400, 40000, 3
     idx, r = synth.make_ratings(nu, ni, nnz, seed=5)
     u0, v0 = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
     ib0, ub0 = 0.01 * synth.init_normal(1, ni, 3)[0], 0.01 * synth.init_normal(1, nu, 4)[0]
-    T = DsgdKMF(idx, r, nu, ni, k, -1, world)
+    T = DsgdKMF(idx, r, nu, ni, k, -1, world, overlap=overlap, balanced=balanced)
+    assert T.n_item_blocks == (2 * world if (overlap and world > 1) else world)
     T.set_factors(u0, v0, ib0, ub0)
     se = T.train(mode, E, *HP)
     u, v, ib, ub = np.zeros((k, ni)), np.zeros((k, nu)), np.zeros(ni), np.zeros(nu)
     T.get_factors(u, v, ib, ub)
     info = T.info()
+    perm = T.order()
     T.close()
-    su, sv, sib, sub, rm = DS.simulate(mode, E, k, *HP, u0, v0, ib0, ub0, idx, r, T.user_bounds, T.item_bounds)
+    assert np.array_equal(np.sort(perm), np.arange(nnz))
+    if not balanced:                                   # the library's order IS the host-side block order
+        assert np.array_equal(perm, SH.dsgd_block_order(idx, T.user_bounds, T.item_bounds))
+    su, sv, sib, sub, rm = DS.simulate(mode, E, k, *HP, u0, v0, ib0, ub0, idx, r, T.user_bounds, T.item_bounds, perm=perm)
     if mode == 0:
         assert np.array_equal(u, su) and np.array_equal(v, sv)
         assert np.array_equal(ib, sib) and np.array_equal(ub, sub)
@@ -76,6 +87,11 @@ def test_dsgd_fake_world_equals_sequential_oracle_on_block_order(world, k, mode)
         np.testing.assert_allclose(v, sv, rtol=1e-11, atol=1e-14)
     np.testing.assert_allclose(np.sqrt(se / nnz), rm, rtol=1e-12)
     assert info["nnz_local"] == nnz and info["max_block"] >= info["min_block"] >= 0
+    if balanced:
+        # fewer dependency levels than the same blocks in the given order
+        T2 = DsgdKMF(idx, r, nu, ni, k, -1, world, overlap=overlap, balanced=False)
+        assert info["levels_total"] < T2.info()["levels_total"]
+        T2.close()
 
 
 def test_dsgd_empty_blocks_and_real_single_rank():
@@ -89,6 +105,14 @@ def test_dsgd_empty_blocks_and_real_single_rank():
     u0, v0 = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
     ub = np.array([0, 100, 100, 300], dtype=np.int64)
     jb = np.array([0, 0, 120, 200], dtype=np.int64)
+    T6 = DsgdKMF(idx, r, nu, ni, k, -1, 3, user_bounds=ub, item_bounds=np.array([0, 0, 50, 50, 120, 199, 200], dtype=np.int64))
+    T6.set_factors(u0, v0, np.zeros(ni), np.zeros(nu))
+    T6.train(0, E, *HP)
+    u6, v6, ib6, ub6 = np.zeros((k, ni)), np.zeros((k, nu)), np.zeros(ni), np.zeros(nu)
+    T6.get_factors(u6, v6, ib6, ub6)
+    s6 = DS.simulate(0, E, k, *HP, u0, v0, np.zeros(ni), np.zeros(nu), idx, r, ub, T6.item_bounds)
+    T6.close()
+    assert np.array_equal(u6, s6[0]) and np.array_equal(v6, s6[1]) and np.array_equal(ib6, s6[2]) and np.array_equal(ub6, s6[3])
     T = DsgdKMF(idx, r, nu, ni, k, -1, 3, user_bounds=ub, item_bounds=jb)
     T.set_factors(u0, v0, np.zeros(ni), np.zeros(nu))
     T.train(0, E, *HP)
@@ -113,6 +137,8 @@ def test_dsgd_argument_errors():
     idx, r = synth.make_ratings(50, 40, 500, seed=1)
     with pytest.raises(ValueError):
         DsgdKMF(idx, r, 50, 40, 8, -1, 2, user_bounds=np.array([0, 30, 49]), item_bounds=np.array([0, 20, 40]))
+    with pytest.raises(ValueError):                     # 3 item blocks for 2 GPUs: neither world nor 2 * world
+        DsgdKMF(idx, r, 50, 40, 8, -1, 2, item_bounds=np.array([0, 10, 20, 40]))
     bad = idx.copy(); bad[3, 1] = 40
     with pytest.raises(ValueError, match="outside"):
         DsgdKMF(bad, r, 50, 40, 8, -1, 2)

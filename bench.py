@@ -586,7 +586,7 @@ def main():
             from mfrec_amd import sharding as SH
             plan.close()
             plan = None
-            d = SH.DsgdKMF(idx, r, nu, ni, k, rank, world, user_bounds=bounds)
+            d = SH.DsgdKMF(idx, r, nu, ni, k, rank, world, user_bounds=bounds, balanced=True)
             d.set_factors(u0, v0, np.zeros(ni), np.zeros(max(nu_local, 1)))
             d.train(LINEAR, max(a.warmup, 1), LR, KU, KI, KB)
             barrier()
@@ -598,9 +598,10 @@ def main():
             also["dsgd_exact"] = {"value": job_nnz * a.steps / w2, "unit": "rating-updates/s",
                                   "ms_per_step": w2 * 1e3 / a.steps, "rmse_online_last": float(np.sqrt(se[-1] / job_nnz)),
                                   "launches_per_epoch_per_gpu": di["launches_per_epoch"],
-                                  "workload": "%s: the same ratings, %d x %d user/item blocks, block rotation over a "
-                                              "ncclSend/Recv ring; bit-identical to the sequential loop on the block "
-                                              "order (tests/test_gpu_fakeworld.py)" % (cfg_name, world, world)}
+                                  "workload": "%s: the same ratings, %d x %d user/item blocks, every block in its own "
+                                              "minimum-level (balanced) order, block rotation over a ncclSend/Recv ring; "
+                                              "bit-identical to the sequential loop on that order "
+                                              "(tests/test_gpu_fakeworld.py)" % (cfg_name, world, world)}
             d.close()
         except Exception as e:
             fail_line(rank, world, "dsgd leg", e)

@@ -143,10 +143,12 @@ class DsgdKMF(object):
     """Exact multi-GPU full-k SGD (mfx_dsgd_*).  rank = -1: every rank in this process on this GPU."""
 
     def __init__(self, ratings_index, ratings, nbr_users, nbr_items, dim, rank, world,
-                 user_bounds=None, item_bounds=None, overlap=True, balanced=False):
+                 user_bounds=None, item_bounds=None, overlap=False, balanced=False):
         """overlap: 2 * world item blocks (a block rests one step in transit: hand-offs under the next step's
-        levels) instead of world; balanced: every block in its own minimum-level order.  Explicit item_bounds
-        decide the block count themselves (world + 1 or 2 * world + 1 entries)."""
+        levels) instead of world -- twice as many, half as large dependency levels, which at BASELINE cfg 3 costs
+        more than the hidden hand-offs save, hence off by default; balanced: every block in
+        its own minimum-level order.  Explicit item_bounds decide the block count themselves (world + 1 or
+        2 * world + 1 entries)."""
         import ctypes as C
         from . import _shim as S
         self.rank, self.world, self.k = int(rank), int(world), int(dim)

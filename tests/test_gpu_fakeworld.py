@@ -105,7 +105,7 @@ def test_dsgd_empty_blocks_and_real_single_rank():
     u0, v0 = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
     ub = np.array([0, 100, 100, 300], dtype=np.int64)
     jb = np.array([0, 0, 120, 200], dtype=np.int64)
-    T6 = DsgdKMF(idx, r, nu, ni, k, -1, 3, user_bounds=ub, item_bounds=np.array([0, 0, 50, 50, 120, 199, 200], dtype=np.int64))
+    T6 = DsgdKMF(idx, r, nu, ni, k, -1, 3, user_bounds=ub, item_bounds=np.array([0, 0, 50, 50, 120, 199, 200], dtype=np.int64))   # 2 * world blocks
     T6.set_factors(u0, v0, np.zeros(ni), np.zeros(nu))
     T6.train(0, E, *HP)
     u6, v6, ib6, ub6 = np.zeros((k, ni)), np.zeros((k, nu)), np.zeros(ni), np.zeros(nu)

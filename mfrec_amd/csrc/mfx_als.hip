@@ -325,14 +325,18 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 ? 2 : (NT >= 5 ? 2 : 3))) void k_
 #pragma unroll
             for (int n = 0; n < CH2; ++n) bsum += ych[n * S + tid] * one_plus_c;
         }
+        // a ragged last chunk (span = 100: 4 valid rows of 32) skips its all-zero 4-row steps
+        const int nv = span - c * CH2, nv4 = nv >= CH2 ? CH2 : ((nv + 3) & ~3);
 #pragma unroll
         for (int n0 = 0; n0 < CH2; n0 += 4) {
-            const double *base = ych + (n0 + (lane >> 4)) * S + (lane & 15);
+            if (n0 < nv4) {                                       // wave-uniform
+                const double *base = ych + (n0 + (lane >> 4)) * S + (lane & 15);
 #pragma unroll
-            for (int t = 0; t < TPW; ++t)
-                if (t * NW + wid < NTT)
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(base[tI[t] * 16], base[tJ[t] * 16],
-                                                                  acc[t], 0, 0, 0);
+                for (int t = 0; t < TPW; ++t)
+                    if (t * NW + wid < NTT)
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(base[tI[t] * 16], base[tJ[t] * 16],
+                                                                      acc[t], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
@@ -661,12 +665,16 @@ __device__ __forceinline__ void als_rows3_body(const double *__restrict__ Y, int
 #pragma unroll
             for (int n = 0; n < CH2; ++n) bsum += ych[n * S + tid] * one_plus_c;
         }
+        // a ragged last chunk (span = 100: 4 valid rows of 32) skips its all-zero 4-row steps
+        const int nv = span - c * CH2, nv4 = nv >= CH2 ? CH2 : ((nv + 3) & ~3);
 #pragma unroll
         for (int n0 = 0; n0 < CH2; n0 += 4) {
-            const double *base = ych + (n0 + (lane >> 4)) * S + (lane & 15);
+            if (n0 < nv4) {                                       // wave-uniform
+                const double *base = ych + (n0 + (lane >> 4)) * S + (lane & 15);
 #pragma unroll
-            for (int s = 0; s < TS; ++s)
-                                    acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(base[sI(s) * 16], base[sJ(s) * 16], acc[s], 0, 0, 0);
+                for (int s = 0; s < TS; ++s)
+                    acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(base[sI(s) * 16], base[sJ(s) * 16], acc[s], 0, 0, 0);
+            }
         }
         __syncthreads();
     }

@@ -341,16 +341,32 @@ int schedule_device(const int32_t *h_idx, const double *h_r, int64_t nnz, int nu
 }  // namespace mfx
 
 // ---------------------------------------------------------------------------------------------
-// Re-order the ratings INSIDE every dependency level by (user group, item) and return the segment
-// table seg_off[l * n_groups + g] = first position of (level l, group g), seg_off[n_levels * n_groups]
-// = nnz.  The order inside a level is free (its ratings share no user and no item), so every kernel
-// keeps its exact result; the XCD-resident Funk pass (mfx_sgd.hip: k2_xcd_pass) wants it this way:
-// a workgroup owns a user group (its slice of V[f,:] lives in LDS) and walks ascending items.
-// User groups are equal contiguous id ranges: group(u) = u * n_groups / nu.
+// Re-order the ratings INSIDE every dependency level by (user group, late / early, item) and return the
+// segment tables: seg_off[l * n_groups + g] = first position of (level l, group g), seg_mid[...] = first
+// EARLY position of that segment, seg_off[n_levels * n_groups] = nnz.  A rating is LATE when its item was
+// updated in the level just before its own (it can only run once that level is complete everywhere) and
+// EARLY otherwise (its item value has been final for a whole level already).  The order inside a level is
+// free (its ratings share no user and no item), so every kernel keeps its exact result; the XCD-resident
+// Funk pass (mfx_sgd.hip: k2_xcd_pass) wants it this way: a workgroup owns a user group (its slice of
+// V[f,:] lives in LDS), runs the late ratings of a level right after the barrier and the early ratings of
+// the NEXT level while the barrier is in flight.  User groups are equal contiguous id ranges:
+// group(u) = u * n_groups / nu.
 namespace mfx {
 namespace {
-__global__ void k_group_keys(const Rec *__restrict__ recs, int64_t nnz, const int64_t *__restrict__ level_off,
-                             int n_levels, int nu, int n_groups, unsigned long long *keys)
+// one level of the late flags (host loop over the levels: they must be walked in order; inside a level
+// every item occurs once)
+__global__ __launch_bounds__(256) void k_late_level(const Rec *__restrict__ recs, int64_t start, int count, int32_t level,
+                                                    int32_t *last_level, uint8_t *late)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= count) return;
+    const int item = recs[start + t].item;
+    late[start + t] = (level > 0 && last_level[item] == level - 1) ? 1 : 0;
+    last_level[item] = level;
+}
+__global__ void k_group_keys(const Rec *__restrict__ recs, const uint8_t *__restrict__ late, int64_t nnz,
+                             const int64_t *__restrict__ level_off, int n_levels, int nu, int n_groups,
+                             unsigned long long *keys)
 {
     for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < nnz; p += (int64_t)gridDim.x * blockDim.x) {
         int lo = 0, hi = n_levels;                       // level_off[lo] <= p < level_off[hi]
@@ -360,27 +376,32 @@ __global__ void k_group_keys(const Rec *__restrict__ recs, int64_t nnz, const in
         }
         const Rec q = recs[p];
         const unsigned long long g = (unsigned long long)((int64_t)q.user * n_groups / nu);
-        keys[p] = ((unsigned long long)lo << 36) | (g << 31) | (unsigned long long)(unsigned)q.item;
+        const unsigned long long early = late[p] ? 0ull : 1ull;
+        keys[p] = ((unsigned long long)lo << 37) | (g << 32) | (early << 31) | (unsigned long long)(unsigned)q.item;
     }
 }
 __global__ void k_seg_bounds(const unsigned long long *__restrict__ keys, int64_t nnz, int n_levels, int n_groups,
-                             int32_t *seg_off)
+                             int32_t *seg_off, int32_t *seg_mid)
 {
     const int64_t nseg = (int64_t)n_levels * n_groups;
     for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q <= nseg; q += (int64_t)gridDim.x * blockDim.x) {
-        const unsigned long long want = ((unsigned long long)(q / n_groups) << 36) | ((unsigned long long)(q % n_groups) << 31);
-        int64_t lo = 0, hi = nnz;                        // first position with key >= want
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (keys[mid] < want) lo = mid + 1; else hi = mid;
+        const unsigned long long base = ((unsigned long long)(q / n_groups) << 37) | ((unsigned long long)(q % n_groups) << 32);
+        for (int half = 0; half < 2; ++half) {
+            const unsigned long long want = base | ((unsigned long long)half << 31);
+            int64_t lo = 0, hi = nnz;                    // first position with key >= want
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (keys[mid] < want) lo = mid + 1; else hi = mid;
+            }
+            if (half == 0) seg_off[q] = (int32_t)lo;
+            else if (q < nseg) seg_mid[q] = (int32_t)lo;
         }
-        seg_off[q] = (int32_t)lo;
     }
 }
 }  // namespace
 
-int levels_group_sort(Rec *d_recs, int64_t nnz, const int64_t *d_level_off, int64_t n_levels, int nu,
-                      int n_groups, int32_t *d_seg_off)
+int levels_group_sort(Rec *d_recs, int64_t nnz, const std::vector<int64_t> &level_off, const int64_t *d_level_off,
+                      int64_t n_levels, int nu, int ni, int n_groups, int32_t *d_seg_off, int32_t *d_seg_mid)
 {
     mfx::TraceRange trace_("mfx:levels_group_sort");
     if (nnz <= 0 || nnz >= ((int64_t)1 << 31) - 1 || n_levels >= ((int64_t)1 << 24) || n_groups < 1 || n_groups > 32)
@@ -389,19 +410,26 @@ int levels_group_sort(Rec *d_recs, int64_t nnz, const int64_t *d_level_off, int6
     Scratch S;
     unsigned long long *k0, *k1;
     Rec *r1;
+    uint8_t *late;
+    int32_t *last;
     const size_t n = (size_t)nnz;
-    if (S.get(&k0, n) || S.get(&k1, n) || S.get(&r1, n)) return last_code();
+    if (S.get(&k0, n) || S.get(&k1, n) || S.get(&r1, n) || S.get(&late, n) || S.get(&last, (size_t)ni)) return last_code();
+    MFX_HIP(hipMemsetAsync(last, 0xff, (size_t)ni * sizeof(int32_t), st));       // -1
+    for (int64_t l = 0; l < n_levels; ++l) {
+        const int cnt = (int)(level_off[(size_t)l + 1] - level_off[(size_t)l]);
+        if (cnt > 0) k_late_level<<<ceil_div(cnt, 256), 256, 0, st>>>(d_recs, level_off[(size_t)l], cnt, (int32_t)l, last, late);
+    }
     const int blocks = (int)std::min<int64_t>(ceil_div<int64_t>(nnz, 256), 8192);
-    k_group_keys<<<blocks, 256, 0, st>>>(d_recs, nnz, d_level_off, (int)n_levels, nu, n_groups, k0);
+    k_group_keys<<<blocks, 256, 0, st>>>(d_recs, late, nnz, d_level_off, (int)n_levels, nu, n_groups, k0);
     size_t tmp_bytes = 0;
-    const int key_bits = 36 + bits_for(n_levels + 1);
+    const int key_bits = 37 + bits_for(n_levels + 1);
     MFX_HIP(sort_pairs(nullptr, tmp_bytes, k0, k1, d_recs, r1, nnz, key_bits, st));
     char *tmp = nullptr;
     if (S.get(&tmp, tmp_bytes)) return last_code();
     MFX_HIP(sort_pairs(tmp, tmp_bytes, k0, k1, d_recs, r1, nnz, key_bits, st));
     MFX_HIP(hipMemcpyAsync(d_recs, r1, n * sizeof(Rec), hipMemcpyDeviceToDevice, st));
     k_seg_bounds<<<(int)std::min<int64_t>(ceil_div<int64_t>(n_levels * n_groups + 1, 256), 4096), 256, 0, st>>>(
-        k1, nnz, (int)n_levels, n_groups, d_seg_off);
+        k1, nnz, (int)n_levels, n_groups, d_seg_off, d_seg_mid);
     MFX_HIP(hipGetLastError());
     MFX_HIP(hipStreamSynchronize(st));
     return MFX_OK;

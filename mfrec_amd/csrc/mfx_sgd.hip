@@ -12,8 +12,9 @@
 using namespace mfx;
 
 namespace mfx {
-int levels_group_sort(Rec *d_recs, int64_t nnz, const int64_t *d_level_off, int64_t n_levels, int nu,
-                      int n_groups, int32_t *d_seg_off);                                          // mfx_schedule_dev.hip
+int levels_group_sort(Rec *d_recs, int64_t nnz, const std::vector<int64_t> &level_off, const int64_t *d_level_off,
+                      int64_t n_levels, int nu, int ni, int n_groups, int32_t *d_seg_off,
+                      int32_t *d_seg_mid);                                                        // mfx_schedule_dev.hip
 int schedule_device(const int32_t *h_idx, const double *h_r, int64_t nnz, int nu, int ni, Rec *d_recs,
                     int32_t *h_level, std::vector<int64_t> &level_off, int64_t *n_levels,
                     int64_t level_budget, bool *over_budget, bool compact, int64_t *h_order);   // mfx_schedule_dev.hip
@@ -62,6 +63,7 @@ struct mfx_sgd_plan {
     // XCD-resident Funk pass (k2_xcd_pass): 0 = not decided, 1 = ready, -1 = not applicable / disabled
     int k2x_state = 0;
     int32_t *d_seg_off = nullptr;        // [n_levels * kXGroups + 1] after levels_group_sort
+    int32_t *d_seg_mid = nullptr;        // [n_levels * kXGroups]: first EARLY rating of every segment
     unsigned *d_xctl = nullptr;          // registration counters, status, barrier flags
     double *d_se_x = nullptr;            // its squared-error partials (sparse slots, zero elsewhere)
     int64_t k2x_slots = 0;
@@ -689,7 +691,7 @@ void mfx_sgd_plan_destroy(mfx_sgd_plan *p)
     drop_graph(p);
     if (!p->owns_users) p->d_V_km = p->d_V_nk = p->d_ub = nullptr;
     void *ptrs[] = {p->d_recs, p->d_U_km, p->d_V_km, p->d_U_nk, p->d_V_nk, p->d_ib, p->d_ub,
-                    p->d_cache, p->d_k2dyn, p->d_seg_off, p->d_xctl, p->d_se_x, p->d_level_off, p->d_k1_wave_off, p->d_k2_wave_off, p->d_se_partial, p->d_se_tmp, p->d_se_epoch, p->d_counter, p->d_U_start,
+                    p->d_cache, p->d_k2dyn, p->d_seg_off, p->d_seg_mid, p->d_xctl, p->d_se_x, p->d_level_off, p->d_k1_wave_off, p->d_k2_wave_off, p->d_se_partial, p->d_se_tmp, p->d_se_epoch, p->d_counter, p->d_U_start,
                     p->d_ib_start};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -886,12 +888,13 @@ static int ensure_k2x(mfx_sgd_plan *p)
     p->x_lds_doubles = (int)(2 * per_group <= cap_doubles ? 2 * per_group : per_group);
     const int64_t nseg = p->n_levels * kXGroups;
     p->k2x_slots = (int64_t)kXGroups * kXWorkers * 64;
-    if (dev_alloc(p, &p->d_seg_off, (size_t)nseg + 1) || dev_alloc(p, &p->d_xctl, 4096) ||
+    if (dev_alloc(p, &p->d_seg_off, (size_t)nseg + 1) || dev_alloc(p, &p->d_seg_mid, (size_t)nseg + 1) || dev_alloc(p, &p->d_xctl, 4096) ||
         dev_alloc(p, &p->d_se_x, (size_t)p->k2x_slots))
         return last_code();
     MFX_HIP(hipMemsetAsync(p->d_xctl, 0, 4096 * sizeof(unsigned), stream()));
     MFX_HIP(hipMemsetAsync(p->d_se_x, 0, (size_t)p->k2x_slots * sizeof(double), stream()));
-    int rc = levels_group_sort(p->d_recs, p->nnz, p->d_level_off, p->n_levels, p->nu, kXGroups, p->d_seg_off);
+    int rc = levels_group_sort(p->d_recs, p->nnz, p->level_off, p->d_level_off, p->n_levels, p->nu, p->ni, kXGroups,
+                               p->d_seg_off, p->d_seg_mid);
     if (rc) return rc;
     const size_t lds = (size_t)p->x_lds_doubles * sizeof(double);
     if (lds > 64 * 1024)
@@ -905,7 +908,7 @@ static int enqueue_k2x_pass(mfx_sgd_plan *p, const K2Params &P)
     K2XParams X;
     memset(&X, 0, sizeof(X));
     X.recs = P.recs; X.dyn = P.dyn; X.cache = P.cache; X.ib = P.ib; X.ub = P.ub;
-    X.seg_off = p->d_seg_off; X.se_partial = p->d_se_x; X.ctl = p->d_xctl;
+    X.seg_off = p->d_seg_off; X.seg_mid = p->d_seg_mid; X.se_partial = p->d_se_x; X.ctl = p->d_xctl;
     X.n_levels = (int)p->n_levels; X.nu = p->nu; X.lds_doubles = p->x_lds_doubles;
     X.gen_base = p->x_gen;
     X.lr = P.lr; X.K = P.K; X.mu = P.mu; X.upd_u = P.upd_u; X.upd_i = P.upd_i;

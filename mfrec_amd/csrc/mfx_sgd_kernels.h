@@ -650,7 +650,8 @@ struct K2XParams {
     const double *cache;
     const double *ib;          // nullable (without_bias)
     const double *ub;
-    const int32_t *seg_off;    // [n_levels * kXGroups + 1]
+    const int32_t *seg_off;    // [n_levels * kXGroups + 1]: segment (level, group) = [seg_off[q], seg_off[q+1])
+    const int32_t *seg_mid;    // [n_levels * kXGroups]: its LATE ratings [seg_off[q], seg_mid[q]), EARLY the rest
     double *se_partial;        // [kXGroups][kXWorkers][64]: one accumulator per (group, worker, lane)
     unsigned *ctl;             // [x*32] registrations of XCD x, [512] status, [1024 + slot*32] flags
     int n_levels, nu;
@@ -737,67 +738,91 @@ __global__ __launch_bounds__((kXWorkers + 1) * 64) void k2_xcd_pass(K2XParams P)
     };
     if (!barrier(P.gen_base, kXSpinSetup)) return;      // nothing has been modified yet
 
-    // records and cache words do not depend on the updates: the first chunk of the NEXT level is requested
-    // before the barrier.  (Also requesting U[f, item] one level ahead for the ratings whose item was not
-    // touched in the level in between -- two thirds of them at cfg 2 -- was built and measured: no gain, every
-    // wave still waits for its remaining third; dropped.)
+    // squared errors: one accumulator per (user group, worker, lane), summed in processing order and written
+    // once at the end of the pass -- a layout fixed by the schedule alone (a segment's late / early part is cut
+    // into 64-rating chunks dealt to the workers in turn), so the epoch RMSE has the same bits whatever the
+    // placement; and no wave reduction + store sits on a level's critical path
+    double se_acc[2] = {0.0, 0.0};                       // a workgroup holds at most two groups (LDS, above)
+    // One part (late or early) of level l for my groups.  LATE ratings (item updated in level l - 1) can only
+    // run once level l - 1 is complete everywhere; EARLY ones (item final since level l - 2 or before) run one
+    // barrier earlier, while that barrier is still in flight.  Records and cache words never change: the first
+    // late chunk of the next level is requested before the barrier (pre).
     struct Pre {
         Rec rec;
         double cache;
     };
-    auto stage1 = [&](int l, Pre &x) {
+    auto fetch_first_late = [&](int l, Pre &x) {
         x.cache = 0.0;
         x.rec.user = 0; x.rec.item = 0; x.rec.r = 0.0;
         if (l < P.n_levels && (int)slot < NG) {
             const int q = l * NG + (int)slot;
             const int t = P.seg_off[q] + worker * 64 + lane;
-            if (t < P.seg_off[q + 1]) {
+            if (t < P.seg_mid[q]) {
                 x.rec = P.recs[t];
                 x.cache = P.cache[t];
             }
         }
     };
-    Pre cur;
-    if (worker >= 0) stage1(0, cur);
-    // squared errors: one accumulator per (user group, worker, lane), summed over the levels in level order and
-    // written once at the end of the pass -- a layout fixed by the schedule alone (a group's segment of a level
-    // is cut into 64-rating chunks dealt to the workers in turn), so the epoch RMSE has the same bits whatever
-    // the placement; and no wave reduction + store sits on every level's critical path (stamps: ~10 % of it)
-    double se_acc[2] = {0.0, 0.0};                       // a workgroup holds at most two groups (LDS, above)
-    for (int l = 0; l < P.n_levels; ++l) {
-        if (worker >= 0) {
-            int base = 0, gi = 0;
-            bool first = true;
-            for (int g = slot; g < NG; g += nx, ++gi) {
-                const int lo = glo(g);
-                const int q = l * NG + g;
-                const int s0 = P.seg_off[q], s1 = P.seg_off[q + 1];
-                for (int tb = s0 + worker * 64; tb < s1; tb += kXWorkers * 64) {      // wave-uniform
-                    const int t = tb + lane;
-                    if (t < s1) {
-                        const Rec rec = first ? cur.rec : P.recs[t];
-                        const double c = first ? cur.cache : P.cache[t];
-                        double bs;
-                        if (P.ib) bs = P.mu + P.ib[rec.item] + P.ub[rec.user];
-                        else bs = P.mu + 0.0 + 0.0;
-                        const double mf = __hip_atomic_load(uf + rec.item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const double cf = vlds[base + rec.user - lo];
-                        const double p = funk_estimate(mf, cf, c, bs, trail, true);
-                        const double err = rec.r - p;
-                        if (P.upd_i) uf[rec.item] = mf + lr * (err * cf - K * mf);
-                        if (P.upd_u) vlds[base + rec.user - lo] = cf + lr * (err * mf - K * cf);
-                        if (gi == 0) se_acc[0] += err * err;
-                        else se_acc[1] += err * err;
-                    }
-                    first = false;
+    auto run_part = [&](int l, bool late, const Pre *pre) {
+        int base = 0, gi = 0;
+        bool first = pre != nullptr;
+        for (int g = slot; g < NG; g += nx, ++gi) {
+            const int lo = glo(g);
+            const int q = l * NG + g;
+            const int s0 = late ? P.seg_off[q] : P.seg_mid[q], s1 = late ? P.seg_mid[q] : P.seg_off[q + 1];
+            for (int tb = s0 + worker * 64; tb < s1; tb += kXWorkers * 64) {      // wave-uniform
+                const int t = tb + lane;
+                if (t < s1) {
+                    const Rec rec = first ? pre->rec : P.recs[t];
+                    const double c = first ? pre->cache : P.cache[t];
+                    double bs;
+                    if (P.ib) bs = P.mu + P.ib[rec.item] + P.ub[rec.user];
+                    else bs = P.mu + 0.0 + 0.0;
+                    const double mf = __hip_atomic_load(uf + rec.item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const double cf = vlds[base + rec.user - lo];
+                    const double p = funk_estimate(mf, cf, c, bs, trail, true);
+                    const double err = rec.r - p;
+                    if (P.upd_i) uf[rec.item] = mf + lr * (err * cf - K * mf);
+                    if (P.upd_u) vlds[base + rec.user - lo] = cf + lr * (err * mf - K * cf);
+                    if (gi == 0) se_acc[0] += err * err;
+                    else se_acc[1] += err * err;
                 }
                 first = false;
-                base += glo(g + 1) - lo;
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my stores are in L2
-            stage1(l + 1, cur);
+            first = false;
+            base += glo(g + 1) - lo;
         }
-        if (!barrier(P.gen_base + (unsigned)l + 1u, kXSpinRun)) return;
+    };
+    Pre cur;
+    if (worker >= 0) {
+        run_part(0, false, nullptr);                     // level 0 has no late ratings: all of it is early
+        fetch_first_late(0, cur);                        // (empty; keeps the loop uniform)
+    }
+    for (int l = 0; l < P.n_levels; ++l) {
+        if (worker >= 0) {
+            run_part(l, true, &cur);                              // late(l): needs barrier l - 1, which has passed
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my stores of level l (late and early) are in L2
+            fetch_first_late(l + 1, cur);
+        }
+        // level l is complete in this workgroup: signal; while the flags travel, the workers run early(l + 1)
+        __syncthreads();                                          // A
+        if (worker < 0) {
+            const unsigned gen = P.gen_base + (unsigned)l + 1u;
+            if (lane == 0) flags[slot * 32] = gen;               // plain store: stays in this XCD's L2
+            unsigned spins = 0;
+            for (;;) {
+                const bool ok = lane >= (int)nx || (int)(ld_sc1_u32(flags + lane * 32) - gen) >= 0;
+                if (__all(ok)) break;
+                if (++spins > kXSpinRun || ld_sc1_u32(P.ctl + 512)) {
+                    if (lane == 0) atomicExch(P.ctl + 512, 3u);
+                    break;
+                }
+            }
+        } else if (l + 1 < P.n_levels) {
+            run_part(l + 1, false, nullptr);                      // early(l + 1): items final since level l - 1
+        }
+        __syncthreads();                                          // B
+        if (ld_sc1_u32(P.ctl + 512)) return;
     }
     if (worker >= 0) {
         int gi = 0;

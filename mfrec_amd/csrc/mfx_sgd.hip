@@ -911,6 +911,7 @@ static int enqueue_k2x_pass(mfx_sgd_plan *p, const K2Params &P)
     X.seg_off = p->d_seg_off; X.seg_mid = p->d_seg_mid; X.se_partial = p->d_se_x; X.ctl = p->d_xctl;
     X.n_levels = (int)p->n_levels; X.nu = p->nu; X.lds_doubles = p->x_lds_doubles;
     X.gen_base = p->x_gen;
+    X.tune = env_int("MFX_K2_TUNE", 0);
     X.lr = P.lr; X.K = P.K; X.mu = P.mu; X.upd_u = P.upd_u; X.upd_i = P.upd_i;
     p->x_gen += (unsigned)p->n_levels + 1u;
     // the registration counters are cleared per pass (the status word per batch, by the caller); the flags

@@ -656,6 +656,8 @@ struct K2XParams {
     unsigned *ctl;             // [x*32] registrations of XCD x, [512] status, [1024 + slot*32] flags
     int n_levels, nu;
     int lds_doubles;
+    int tune;                  // bit 1: no early phase -- every rating runs behind its own level's barrier (A/B hook,
+                               // MFX_K2_TUNE=2; same-process measurement: tools/k2_tune.py)
     unsigned gen_base;         // flags count up across passes: gen = gen_base + level + 1
     double lr, K, mu;
     int upd_u, upd_i;
@@ -793,6 +795,7 @@ __global__ __launch_bounds__((kXWorkers + 1) * 64) void k2_xcd_pass(K2XParams P)
             base += glo(g + 1) - lo;
         }
     };
+    // (requesting it two levels ahead instead of one: measured neutral)
     Pre cur;
     if (worker >= 0) {
         run_part(0, false, nullptr);                     // level 0 has no late ratings: all of it is early
@@ -801,6 +804,7 @@ __global__ __launch_bounds__((kXWorkers + 1) * 64) void k2_xcd_pass(K2XParams P)
     for (int l = 0; l < P.n_levels; ++l) {
         if (worker >= 0) {
             run_part(l, true, &cur);                              // late(l): needs barrier l - 1, which has passed
+            if ((P.tune & 2) && l > 0) run_part(l, false, nullptr);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my stores of level l (late and early) are in L2
             fetch_first_late(l + 1, cur);
         }
@@ -818,7 +822,7 @@ __global__ __launch_bounds__((kXWorkers + 1) * 64) void k2_xcd_pass(K2XParams P)
                     break;
                 }
             }
-        } else if (l + 1 < P.n_levels) {
+        } else if (l + 1 < P.n_levels && !(P.tune & 2)) {
             run_part(l + 1, false, nullptr);                      // early(l + 1): items final since level l - 1
         }
         __syncthreads();                                          // B

@@ -132,8 +132,14 @@ __global__ __launch_bounds__((W + 1) * 64) void k2_xcd_pass(XParams P)
         if (tb + lane < s1) { nrec = P.recs[tb + lane]; ncache = P.cache[tb + lane]; }
     }
 #endif
-    auto one = [&](const Rec &rec, double c, int lo, int base) -> double {
+    auto one = [&](const Rec &rec, double c, int lo, int base, int l = -1) -> double {
+#ifdef STAMPS
+        if (l >= 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (worker == 0) STAMP(6); }
+#endif
         const double mf = ld_sc1_f64(uf + rec.item);
+#ifdef STAMPS
+        if (l >= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (worker == 0) STAMP(7); }
+#endif
         double cf;
         if constexpr (VARIANT == 3) cf = vlds[base + rec.user - lo];
         else cf = ld_sc1_f64(vf + rec.user);
@@ -165,7 +171,7 @@ __global__ __launch_bounds__((W + 1) * 64) void k2_xcd_pass(XParams P)
                             const Rec rec = P.recs[t];
                             const double c = P.cache[t];
 #endif
-                            e2 = one(rec, c, lo, base);
+                            e2 = one(rec, c, lo, base, first ? l : -1);
                         }
                         first = false;
                         const double ws = wave_sum_fixed(e2);
@@ -220,7 +226,7 @@ __global__ __launch_bounds__((W + 1) * 64) void k2_xcd_pass(XParams P)
             }
             STAMP(4);
 #ifdef STAMPS
-            if (slot == 0 && lane == 0) P.stamps[(size_t)l * 8 + 6] = spins;
+            (void)spins;
 #endif
         }
         __syncthreads();                                          // B: the level is complete everywhere
@@ -497,7 +503,7 @@ int main(int argc, char **argv)
     {
         std::vector<unsigned long long> st((size_t)n_levels * 8);
         CK(hipMemcpy(st.data(), d_stamps, st.size() * 8, hipMemcpyDeviceToHost));
-        double d[6] = {0, 0, 0, 0, 0, 0}, sp = 0; int n = 0;
+        double d[6] = {0, 0, 0, 0, 0, 0}, sp = 0, e6 = 0, e7 = 0; int n = 0;
         for (int64_t l = 20; l + 1 < n_levels - 20; ++l, ++n) {
             const unsigned long long *a = &st[(size_t)l * 8], *b = &st[(size_t)(l + 1) * 8];
             d[0] += (double)(a[1] - a[0]);      // level open -> updates issued (sc1 load + compute + store issue)
@@ -506,8 +512,10 @@ int main(int argc, char **argv)
             d[3] += (double)(a[4] - a[3]);      // flag store -> all flags seen
             d[4] += (double)(a[5] - a[4]);      // barrier B
             d[5] += (double)(b[0] - a[0]);      // whole level
-            sp += (double)a[6];
+            if (a[6] && a[7]) { e6 += (double)(a[6] - a[0]); e7 += (double)(a[7] - a[6]); }
         }
+        printf("  inside load+compute+issue: level open -> record/cache in registers %.0f | sc1 load of U[f,item] %.0f | rest (LDS, compute, wave sum, store issue) %.0f\n",
+               e6 / n, e7 / n, (d[0] - e6 - e7) / n);
         printf("stamps (s_memtime ticks, workgroup slot 0, mean over %d levels): load+compute+issue %.0f | store drain %.0f | barrier A %.0f | flag->all flags %.0f (%.1f poll rounds) | barrier B %.0f | level %.0f\n",
                n, d[0] / n, d[1] / n, d[2] / n, d[3] / n, sp / n, d[4] / n, d[5] / n);
     }

@@ -719,11 +719,13 @@ __global__ __launch_bounds__((kXWorkers + 1) * 64) void k2_xcd_pass(K2XParams P)
             base += n;
         }
     }
+    // (measured with run-time hooks, same process: 8 or 12 worker waves instead of 15: +1 %; 4: +16 %; raising the
+    // sync wave's priority: nothing -- the level is a latency chain, not a throughput problem)
     const int worker = wid - 1;                          // -1 = the sync wave
     // barrier(gen): A = my workgroup is done, flag, poll everybody's flag, B
     auto barrier = [&](unsigned gen, unsigned limit) -> bool {
         __syncthreads();
-        if (worker < 0) {
+        if (worker == -1) {
             if (lane == 0) flags[slot * 32] = gen;       // plain store: stays in this XCD's L2
             unsigned spins = 0;
             for (;;) {
@@ -759,7 +761,7 @@ __global__ __launch_bounds__((kXWorkers + 1) * 64) void k2_xcd_pass(K2XParams P)
         if (l < P.n_levels && (int)slot < NG) {
             const int q = l * NG + (int)slot;
             const int t = P.seg_off[q] + worker * 64 + lane;
-            if (t < P.seg_mid[q]) {
+            if (worker >= 0 && t < P.seg_mid[q]) {
                 x.rec = P.recs[t];
                 x.cache = P.cache[t];
             }
@@ -810,7 +812,7 @@ __global__ __launch_bounds__((kXWorkers + 1) * 64) void k2_xcd_pass(K2XParams P)
         }
         // level l is complete in this workgroup: signal; while the flags travel, the workers run early(l + 1)
         __syncthreads();                                          // A
-        if (worker < 0) {
+        if (worker == -1) {
             const unsigned gen = P.gen_base + (unsigned)l + 1u;
             if (lane == 0) flags[slot * 32] = gen;               // plain store: stays in this XCD's L2
             unsigned spins = 0;
@@ -822,16 +824,16 @@ __global__ __launch_bounds__((kXWorkers + 1) * 64) void k2_xcd_pass(K2XParams P)
                     break;
                 }
             }
-        } else if (l + 1 < P.n_levels && !(P.tune & 2)) {
+        } else if (worker >= 0 && l + 1 < P.n_levels && !(P.tune & 2)) {
             run_part(l + 1, false, nullptr);                      // early(l + 1): items final since level l - 1
         }
         __syncthreads();                                          // B
         if (ld_sc1_u32(P.ctl + 512)) return;
     }
-    if (worker >= 0) {
+    if (wid >= 1) {                                      // every worker slot is written every pass (idle ones: 0)
         int gi = 0;
         for (int g = slot; g < NG; g += nx, ++gi)
-            P.se_partial[((size_t)g * kXWorkers + worker) * 64 + lane] = gi == 0 ? se_acc[0] : se_acc[1];
+            P.se_partial[((size_t)g * kXWorkers + (wid - 1)) * 64 + lane] = gi == 0 ? se_acc[0] : se_acc[1];
     }
     // LDS slices back to V[f,:]
     if (P.upd_u) {

@@ -149,6 +149,21 @@ int mfx_learned_bias(int min_epochs, double min_improvement, int dim, double f_i
                      double *users_bias, int64_t nnz, int nu, int ni, int epoch_cap,
                      double *rmse_hist, int64_t hist_cap, int64_t *n_hist);
 
+/* estimator_loop_with_implicit_feedback (gd_estimator.pyx:785-806): the SVD++-like prototype, reproduced as
+ * written (feedback_sum overwritten at :873, cache commit without the implicit term).  y f64[k, ni] is the
+ * implicit item factor; rated int32[n_rated, 2] = (user, item) pairs sorted by user, pairs distinct;
+ * rated_hash int32[nu, 2] = (first row of the user in `rated`, count) -- gradient_descent.py:261-296.
+ * Every rating rewrites y[f, j] for all items j of its user, so the loop has no exact parallel schedule over
+ * ratings: ONE workgroup walks them in order (the parallelism is inside a rating).  Bit-identical to the
+ * reference; about its speed with the three feature vectors in LDS (2 ni + nu doubles <= 150 KB), slower
+ * beyond -- served for completeness, not for throughput. */
+int mfx_funk_implicit(int min_epochs, double min_improvement, int dim, double f_init, double learning_rate,
+                      double K, double overall_avg, double *u, double *v, double *y,
+                      const int32_t *ratings_index, const double *ratings, const int32_t *rated,
+                      int64_t n_rated, const int32_t *rated_hash, const double *items_bias,
+                      const double *users_bias, int64_t nnz, int nu, int ni, int epoch_cap,
+                      double *rmse_hist, int64_t hist_cap, int64_t *n_hist);
+
 /* als_wrmf (als_implicit.pyx:211-225).  *_row are the run-length arrays of
  * mfrec/lib/datasets.py:13-32 ([0, count_0, count_1, ...], n_*row entries). */
 int mfx_als_wrmf(int nbr_epochs, int dim, double *u, double *v, const int32_t *ratings_users_row,

@@ -55,6 +55,9 @@ SIGNATURES = {
                                    C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _dp,
                                    _dp, _ip, _dp, _dp, _dp, C.c_int64, C.c_int, C.c_int, C.c_int,
                                    _dp, C.c_int64, _lp]),
+    "mfx_funk_implicit": (C.c_int, [C.c_int, C.c_double, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                                    _dp, _dp, _dp, _ip, _dp, _ip, C.c_int64, _ip, _dp, _dp, C.c_int64, C.c_int,
+                                    C.c_int, C.c_int, _dp, C.c_int64, _lp]),
     "mfx_als_wrmf": (C.c_int, [C.c_int, C.c_int, _dp, _dp, _ip, C.c_int64, _ip, _ip, C.c_int64,
                                _ip, C.c_int, C.c_int, C.c_int, C.c_double]),
     "mfx_als_wrmf_sharded": (C.c_int, [C.c_int, C.c_int, _dp, _dp, _ip, C.c_int64, _ip, _ip,

@@ -138,3 +138,30 @@ def predictor_subloop(f, epochs, dim, f_init, u, v, ratings_index, ratings, rati
     pc = S.f64(rating_cache, "rating_cache", 1, (nu * ni,))
     S.check(S.lib().mfx_funk_predictor_subloop(int(f), int(dim), float(f_init), pu, pv, pi, pr, pc,
                                                nnz, nu, ni))
+
+
+def estimator_loop_with_implicit_feedback(min_epochs, max_epochs, min_improvement, dim, f_init, learning_rate,
+                                          learning_rate_users, learning_rate_items, K, overall_avg, u, v, y,
+                                          ratings_index, ratings, rated, rated_hash, items_bias, users_bias,
+                                          nbr_users, nbr_items, verbose=0):
+    """gd_estimator.pyx:785-898: the SVD++-like prototype, as written.  `rated` int32[n, 2] (user, item) sorted by
+    user with distinct pairs, `rated_hash` int32[nu, 2] (first row, count) -- gradient_descent.py:261-296.  The
+    loop is sequential by nature (every rating rewrites y[f, :] for all items of its user): one workgroup walks the
+    ratings in order; exact, not fast."""
+    pu, pv, nu, ni = S.factor_args(u, v, int(dim))
+    py = S.f64(y, "y", 2, (int(dim), ni))
+    pi, pr, nnz = S.ratings_args(ratings_index, ratings)
+    prated = S.i32(rated, "rated", 2)
+    if rated.shape[1] != 2:
+        raise ValueError("rated must have shape [n, 2]")
+    phash = S.i32(rated_hash, "rated_hash", 2, (nu, 2))
+    pib = S.f64(items_bias, "items_bias", 1, (ni,))
+    pub = S.f64(users_bias, "users_bias", 1, (nu,))
+    hist = _hist(min_epochs, dim)
+    n = C.c_int64(0)
+    S.check(S.lib().mfx_funk_implicit(int(min_epochs), float(min_improvement), int(dim), float(f_init),
+                                      float(learning_rate), float(K), float(overall_avg), pu, pv, py, pi, pr,
+                                      prated, rated.shape[0], phash, pib, pub, nnz, nu, ni, int(EPOCH_CAP),
+                                      S.f64(hist, "hist", 1), hist.shape[0], C.byref(n)))
+    _print_hist(verbose, dim, hist, min(n.value, hist.shape[0]))
+    return hist[:min(n.value, hist.shape[0])]

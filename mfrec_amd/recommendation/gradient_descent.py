@@ -66,6 +66,37 @@ class GDRecommender(MFRecommender):
             ratings_index, ratings, self.items_bias, self.users_bias, self.nbr_users,
             self.nbr_items, int(verbose))
 
+    def get_feedback(self):
+        """gradient_descent.py:269-296: the rated (user, item) pairs in COO order of the boolean ratings matrix
+        (users ascending, items ascending) and, per user, (first row, count) -- (-1, -1) for a user without ratings."""
+        coo = self.relationship_matrix.tocoo()
+        keep = coo.data != 0
+        pairs = np.stack([coo.row[keep], coo.col[keep]], axis=1).astype(np.int32)
+        pairs = pairs[np.lexsort((pairs[:, 1], pairs[:, 0]))]
+        counts = np.bincount(pairs[:, 0], minlength=self.nbr_users).astype(np.int64)
+        first = np.concatenate([[0], np.cumsum(counts)[:-1]])
+        rated_hash = np.stack([np.where(counts > 0, first, -1), np.where(counts > 0, counts, -1)], axis=1).astype(np.int32)
+        return np.ascontiguousarray(pairs), np.ascontiguousarray(rated_hash)
+
+    def initialize_rated_feedback(self):                                      # :261-263
+        self.feedback_rated, self.feedback_hash = self.get_feedback()
+
+    def feature_training_implicit(self, initialize_model=True, verbose=False):
+        """gradient_descent.py:547-574: the SVD++-like trainer (sequential by nature; see lib.gd_estimator)."""
+        if initialize_model:
+            self.init_feature_const()
+        ratings_index, ratings = self.get_ratings(randomize_order=True)
+        self.compute_overall_avg()
+        self.compute_items_bias_bk()
+        self.compute_users_bias_bk()
+        self.initialize_rated_feedback()
+        self.items_feedback = np.zeros([self.dimensionality, self.nbr_items])
+        _kernels.estimator_loop_with_implicit_feedback(
+            self.min_epochs, self.max_epochs, self.min_improvement, self.dimensionality, self.feature_init,
+            self.learning_rate, self.learning_rate_users, self.learning_rate_items, self.K, self.overall_bias,
+            self.svd_u, self.svd_v, self.items_feedback, ratings_index, ratings, self.feedback_rated,
+            self.feedback_hash, self.items_bias, self.users_bias, self.nbr_users, self.nbr_items, int(verbose))
+
     def predict_rating(self, item_index, user_index):                         # :621-631
         return np.dot(self.svd_u[:, item_index], self.svd_v[:, user_index]) + 1.0
 

@@ -148,6 +148,76 @@ void mfxo_funk(int min_epochs, double min_improvement, int dim, double f_init, d
 }
 
 /* ------------------------------------------------------------------------
+ * a9: estimator_loop_with_implicit_feedback, gd_estimator.pyx:785-898 (the
+ * SVD++-like prototype), restated AS WRITTEN, quirks included:
+ *   - feedback_sum is summed over the user's rated items (:869-871) and then
+ *     overwritten by y[f, item] (:873), so the item update only sees that one
+ *     term;
+ *   - the inner loops reuse the loop variable `i` (:869, :879); Cython's range
+ *     loops iterate over a temporary, so the outer loop is unaffected, and
+ *     rating_cache[i] is read before `i` is clobbered (:860-861);
+ *   - every rating rewrites y[f, j] for ALL items j its user rated (:879-881);
+ *   - the stopping rule is the Funk one (:844; max_epochs ignored), the cache
+ *     commit (:891-896) uses v[f, user] alone (no implicit term).
+ * rated int32[n_rated, 2] = (user, item) sorted by user; rated_hash
+ * int32[nu, 2] = (first row of the user in `rated`, count)
+ * (gradient_descent.py:261-296).
+ * ---------------------------------------------------------------------- */
+void mfxo_implicit_feedback(int min_epochs, double min_improvement, int dim, double f_init, double lr,
+                            double K, double mu, double *u, double *v, double *y, const int32_t *idx,
+                            const double *r, const int32_t *rated, const int32_t *rated_hash,
+                            const double *ib, const double *ub, int64_t nnz, int nu, int ni,
+                            int epoch_cap, double *rmse_hist, int64_t hist_cap, int64_t *n_hist)
+{
+#define Y(f, i) y[(size_t)(f) * (size_t)ni + (size_t)(i)]
+    double rmse = 2.0, rmse_last = 0.0;
+    int64_t nh = 0;
+    double *cache = (double *)calloc((size_t)(nnz > 0 ? nnz : 1), sizeof(double));
+    for (int f = 0; f < dim; ++f) {
+        int epoch = 0;
+        while (epoch < min_epochs || rmse <= rmse_last - min_improvement) {
+            if (epoch_cap > 0 && epoch >= epoch_cap) break;
+            double se = 0.0;
+            rmse_last = rmse;
+            for (int64_t t = 0; t < nnz; ++t) {
+                const int user = idx[2 * t], item = idx[2 * t + 1];
+                const long nbr_rated = rated_hash[2 * user + 1];
+                const double feedback_norm = 1.0 / sqrt((double)nbr_rated);              /* :853-854 */
+                const double v_implicit = V(f, user) + (feedback_norm * Y(f, item));     /* :855 */
+                const double p = funk_estimate(U(f, item), v_implicit, dim, f, f_init, cache[t], 1, mu,
+                                               ib[item], ub[user]);                      /* :857-858 */
+                const double err = 1.0 * r[t] - p;
+                se += err * err;
+                const double cf = V(f, user);
+                double feedback_sum = 0.0;
+                for (long j = 0; j < nbr_rated; ++j)                                     /* :869-871 */
+                    feedback_sum += Y(f, rated[2 * (rated_hash[2 * user] + j) + 1]);
+                feedback_sum = Y(f, item);                                               /* :873 */
+                const double mf = U(f, item);
+                U(f, item) += lr * (err * (cf + feedback_norm * feedback_sum) - K * mf); /* :876 */
+                V(f, user) += lr * (err * mf - K * cf);                                  /* :877 */
+                for (long j = 0; j < nbr_rated; ++j) {                                   /* :879-881 */
+                    const int sum_j = rated[2 * (rated_hash[2 * user] + j) + 1];
+                    Y(f, sum_j) += lr * (err * feedback_norm * mf - K * Y(f, sum_j));
+                }
+            }
+            rmse = sqrt(se / (double)nnz);
+            if (rmse_hist && nh < hist_cap) rmse_hist[nh] = rmse;
+            ++nh;
+            ++epoch;
+        }
+        for (int64_t t = 0; t < nnz; ++t) {                                              /* :891-896 */
+            const int user = idx[2 * t], item = idx[2 * t + 1];
+            cache[t] = funk_estimate(U(f, item), V(f, user), dim, f, f_init, cache[t], 0, mu, ib[item],
+                                     ub[user]);
+        }
+    }
+    free(cache);
+    if (n_hist) *n_hist = nh;
+#undef Y
+}
+
+/* ------------------------------------------------------------------------
  * a5: estimator_loop_with_learned_bias, gd_estimator.pyx:401-483, with
  * full_estimator (:118-148): full k-dot per rating, but only feature f and
  * both biases are updated.

@@ -137,6 +137,24 @@ def estimator_loop_with_learned_bias(min_epochs, max_epochs, min_improvement, di
     return n.value
 
 
+def estimator_loop_with_implicit_feedback(min_epochs, max_epochs, min_improvement, dim, f_init,
+                                          learning_rate, learning_rate_users, learning_rate_items, K,
+                                          overall_avg, u, v, y, ratings_index, ratings, rated, rated_hash,
+                                          items_bias, users_bias, nbr_users, nbr_items, verbose=0,
+                                          rmse_hist=None, epoch_cap=0):
+    """gd_estimator.pyx:785-806 (the SVD++-like prototype, quirks included)."""
+    ni, nu = u.shape[1], v.shape[1]
+    n = C.c_int64(0)
+    cap = 0 if rmse_hist is None else rmse_hist.shape[0]
+    lib().mfxo_implicit_feedback(C.c_int(min_epochs), C.c_double(min_improvement), C.c_int(dim),
+                                 C.c_double(f_init), C.c_double(learning_rate), C.c_double(K),
+                                 C.c_double(overall_avg), _d(u), _d(v), _d(y), _i(ratings_index), _d(ratings),
+                                 _i(rated), _i(rated_hash), _d(items_bias), _d(users_bias),
+                                 C.c_int64(ratings.shape[0]), C.c_int(nu), C.c_int(ni), C.c_int(epoch_cap),
+                                 _d(rmse_hist), C.c_int64(cap), C.byref(n))
+    return n.value
+
+
 def estimator_subloop(f, epochs, min_improvement, dim, f_init, learning_rate, K, u, v,
                       ratings_index, ratings, rating_cache, nbr_users, nbr_features, verbose=0):
     """gd_estimator.pyx:903-917; returns the epoch's online RMSE."""

@@ -148,3 +148,27 @@ def test_edges(golden):
             fn(2, k, 0.1, 0.01, 0, 0, 0.1, 0.1, 0.007, 0.0, u, v, g["in_idx_b"], g["in_r_b"], ib, ub)
             eq(u, g["out_%s_u_k%d" % (nm, k)]); eq(v, g["out_%s_v_k%d" % (nm, k)])
             eq(ib, g["out_%s_ib_k%d" % (nm, k)]); eq(ub, g["out_%s_ub_k%d" % (nm, k)])
+
+
+def test_g11_implicit_feedback(golden):
+    """The SVD++-like prototype (gd_estimator.pyx:785-898) restated as written: fixed epochs and the live
+    stopping rule, against the reference's own outputs."""
+    g = golden("g11_implicit")
+    k, E = int(g["p_k"]), int(g["p_epochs"])
+    idx, r = g["in_idx"], g["in_r"]
+    u, v, y = synth.init_const(k, 40), synth.init_const(k, 60), np.zeros((k, 40))
+    hist = np.zeros(E * k)
+    n = O.estimator_loop_with_implicit_feedback(E, E, 1e9, k, float(g["p_init"]), float(g["p_lr"]), 0, 0, float(g["p_K"]),
+                                                float(g["p_mu"]), u, v, y, idx, r, g["in_rated"], g["in_rated_hash"],
+                                                g["in_ib"], g["in_ub"], 60, 40, 0, hist)
+    assert n == E * k
+    assert np.array_equal(u, g["out_u"]) and np.array_equal(v, g["out_v"]) and np.array_equal(y, g["out_y"])
+    assert np.array_equal(hist, g["out_rmse_hist"])
+    u, v, y = synth.init_const(k, 40), synth.init_const(k, 60), np.zeros((k, 40))
+    hist = np.zeros(4096)
+    n = O.estimator_loop_with_implicit_feedback(int(g["p_b_min_epochs"]), 0, float(g["p_b_min_improvement"]), k,
+                                                float(g["p_init"]), float(g["p_b_lr"]), 0, 0, float(g["p_K"]),
+                                                float(g["p_mu"]), u, v, y, idx, r, g["in_rated"], g["in_rated_hash"],
+                                                g["in_ib"], g["in_ub"], 60, 40, 0, hist)
+    assert np.array_equal(u, g["out_b_u"]) and np.array_equal(y, g["out_b_y"])
+    assert np.array_equal(hist[:n], g["out_b_rmse_hist"])

@@ -155,8 +155,8 @@ int mfx_learned_bias(int min_epochs, double min_improvement, int dim, double f_i
  * rated_hash int32[nu, 2] = (first row of the user in `rated`, count) -- gradient_descent.py:261-296.
  * Every rating rewrites y[f, j] for all items j of its user, so the loop has no exact parallel schedule over
  * ratings: ONE workgroup walks them in order (the parallelism is inside a rating).  Bit-identical to the
- * reference; about its speed with the three feature vectors in LDS (2 ni + nu doubles <= 150 KB), slower
- * beyond -- served for completeness, not for throughput. */
+ * reference and 7-10x SLOWER than its C loop on one host core (0.6 us per rating with the three feature
+ * vectors in LDS, 2 ni + nu doubles <= 150 KB; more beyond) -- served for completeness, not for throughput. */
 int mfx_funk_implicit(int min_epochs, double min_improvement, int dim, double f_init, double learning_rate,
                       double K, double overall_avg, double *u, double *v, double *y,
                       const int32_t *ratings_index, const double *ratings, const int32_t *rated,
@@ -208,9 +208,10 @@ int mfx_sgd_plan_info(const mfx_sgd_plan *p, int64_t info[8]);
  * kernel of the Funk pass ("k2_xcd_pass<...>", the single-XCD persistent pass chosen for large levels,
  * or "k2_level<...>", one launch per level). */
 int mfx_sgd_plan_kernel_name(const mfx_sgd_plan *p, int mode, char *buf, int buflen);
-/* Storage type of the factor rows inside the plan: 64 (default; exact) or 32 -- "f32 storage,
- * f64 arithmetic" fast mode of the full-k kernels: rows are widened on load and rounded once on
- * store.  NOT bit-exact (measured RMSE delta: DESIGN.md); single-GPU; call before set_factors. */
+/* Storage type of the factor rows inside the plan: 64 (default; exact), 32 or 16 (bf16) -- "narrow
+ * storage, f64 arithmetic" modes of the full-k kernels: rows are widened on load and rounded once on
+ * store.  NOT bit-exact (measured RMSE deltas: DESIGN.md -- f32 stays within the 1e-5 budget, bf16 does
+ * not); single-GPU; call before set_factors.  bf16: k a multiple of 8, k >= 16, linear / logistic. */
 int mfx_sgd_plan_set_storage(mfx_sgd_plan *p, int bits);
 /* How the full-k kernels (linear / logistic) form the k-term dot product ib + ub + sum_f U[f,i] V[f,u]:
  * MFX_DOT_ORDERED (default): summed strictly left to right by one lane, no FMA -- the reference's

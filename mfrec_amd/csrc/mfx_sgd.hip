@@ -35,7 +35,7 @@ struct mfx_sgd_plan {
     int nu = 0, ni = 0, k = 0;
     int64_t n_levels = 0, max_level = 0;
     int batch = 16;                      // full-k kernel: ratings per wave
-    int f32 = 0;                         // factor rows stored as f32 (fast mode, not exact)
+    int f32 = 0;                         // row storage: 0 = f64 (exact), 1 = f32, 2 = bf16 (measured options, not exact)
     int dot = 0;                         // 1: butterfly k-dot + FMA (tolerance mode, not bit-exact)
     std::vector<int64_t> level_off;      // n_levels + 1
     std::vector<int64_t> k1_wave_off;    // per level: first se_partial slot (full-k kernels)
@@ -133,7 +133,10 @@ int to_nk(mfx_sgd_plan *p)
 {
     if (p->nk_current) return MFX_OK;
     int rc;
-    if (p->f32) {
+    if (p->f32 == 2) {
+        rc = transpose(p->d_U_km, (__bf16 *)p->d_U_nk, p->k, p->ni);
+        if (!rc) rc = transpose(p->d_V_km, (__bf16 *)p->d_V_nk, p->k, p->nu);
+    } else if (p->f32) {
         rc = transpose(p->d_U_km, (float *)p->d_U_nk, p->k, p->ni);
         if (!rc) rc = transpose(p->d_V_km, (float *)p->d_V_nk, p->k, p->nu);
     } else {
@@ -148,7 +151,10 @@ int to_km(mfx_sgd_plan *p)
 {
     if (p->km_current) return MFX_OK;
     int rc;
-    if (p->f32) {
+    if (p->f32 == 2) {
+        rc = transpose((const __bf16 *)p->d_U_nk, p->d_U_km, p->ni, p->k);
+        if (!rc) rc = transpose((const __bf16 *)p->d_V_nk, p->d_V_km, p->nu, p->k);
+    } else if (p->f32) {
         rc = transpose((const float *)p->d_U_nk, p->d_U_km, p->ni, p->k);
         if (!rc) rc = transpose((const float *)p->d_V_nk, p->d_V_km, p->nu, p->k);
     } else {
@@ -228,6 +234,21 @@ K1Sel k1_pick(int k, int batch)
 #undef MFX_K1
 }
 
+// bf16 row storage: 16-byte chunks of EIGHT features, k a multiple of 8 and >= 16, linear / logistic only
+bool k1_bf16_eligible(int k) { return k % 8 == 0 && k >= 16 && k1_vec_mode() != 0; }
+template <int MODE, bool TAIL>
+K1Sel k1_pick_bf16(int k, int batch)
+{
+    const int vec = k1_vec_mode();
+#define MFX_K1B(KP, B) K1Sel{TAIL ? (void *)k1_tail<KP, 8, B, MODE, 0, __bf16, true> : (vec == 2 ? (void *)k1_level<KP, 8, B, MODE, 2, __bf16, true> : (void *)k1_level<KP, 8, B, MODE, 0, __bf16, true>), #KP ",8," #B ",vec16,bf16"}
+    if (k <= 64 && batch == 8) return MFX_K1B(8, 8);
+    if (k <= 64 && batch == 16) return MFX_K1B(8, 16);
+    if (k <= 128) return MFX_K1B(16, 8);
+    if (k <= 256) return MFX_K1B(32, 4);
+    return MFX_K1B(64, 2);
+#undef MFX_K1B
+}
+
 // the butterfly-dot (tolerance) mode exists for f64 rows, even k > 4, linear / logistic
 bool k1_dot_eligible(int k, int f32) { return !f32 && k % 2 == 0 && k > 4 && k1_vec_mode() != 0; }
 
@@ -237,6 +258,10 @@ K1Sel k1_select(int k, int mode, int batch, int f32, int dot = 0)
     if (dot && k1_dot_eligible(k, f32)) {
         if (mode == 0) return k1_pick<K1_LINEAR, double, TAIL, 1>(k, batch);
         if (mode == 1) return k1_pick<K1_LOGISTIC, double, TAIL, 1>(k, batch);
+    }
+    if (f32 == 2) {
+        if (mode == 1) return k1_pick_bf16<K1_LOGISTIC, TAIL>(k, batch);
+        return k1_pick_bf16<K1_LINEAR, TAIL>(k, batch);          // (learned bias: refused by its entry point)
     }
     switch (mode * 2 + (f32 ? 1 : 0)) {
     case 0: return k1_pick<K1_LINEAR, double, TAIL>(k, batch);
@@ -733,15 +758,17 @@ int mfx_sgd_plan_kernel_name(const mfx_sgd_plan *p, int mode, char *buf, int buf
     }
     static const char *const mode_name[] = {"linear", "logistic", "learned"};
     snprintf(buf, (size_t)buflen, "k1_level<%s,%s%s>", k1_select<false>(p->k, mode, p->batch, p->f32, p->dot).tag,
-             mode_name[mode], p->f32 ? ",f32" : "");
+             mode_name[mode], p->f32 == 1 ? ",f32" : "");
     return MFX_OK;
 }
 
 int mfx_sgd_plan_set_storage(mfx_sgd_plan *p, int bits)
 {
-    if (!p || (bits != 64 && bits != 32)) return fail(MFX_E_ARG, "mfx_sgd_plan_set_storage: bits must be 64 or 32");
+    if (!p || (bits != 64 && bits != 32 && bits != 16)) return fail(MFX_E_ARG, "mfx_sgd_plan_set_storage: bits must be 64, 32 or 16");
     if (p->have_factors) return fail(MFX_E_STATE, "mfx_sgd_plan_set_storage: call before mfx_sgd_set_factors");
-    p->f32 = (bits == 32);
+    if (bits == 16 && !k1_bf16_eligible(p->k))
+        return fail(MFX_E_ARG, "mfx_sgd_plan_set_storage: bf16 rows need k a multiple of 8, k >= 16 (k = %d)", p->k);
+    p->f32 = bits == 32 ? 1 : (bits == 16 ? 2 : 0);
     drop_graph(p);
     return MFX_OK;
 }
@@ -1072,6 +1099,7 @@ int mfx_sgd_run_learned_bias(mfx_sgd_plan *p, int min_epochs, double min_improve
     mfx::TraceRange trace_("mfx:run_learned_bias");
     int rc = check_plan(p, "mfx_sgd_run_learned_bias");
     if (rc) return rc;
+    if (p->f32 == 2) return fail(MFX_E_STATE, "mfx_sgd_run_learned_bias: bf16 row storage covers the linear / logistic kernels only");
     rc = to_nk(p);
     if (rc) return rc;
     p->km_current = false;

@@ -136,6 +136,13 @@ __device__ __forceinline__ double group_sum(double x)
 template <typename TS> struct Chunk16;
 template <> struct Chunk16<double> { typedef double type __attribute__((ext_vector_type(2), aligned(8))); };
 template <> struct Chunk16<float> { typedef float type __attribute__((ext_vector_type(4), aligned(4))); };
+// bf16 row storage (SURVEY 8(f)4's other storage option; a measured one: DESIGN.md): EIGHT features per chunk
+template <> struct Chunk16<__bf16> { typedef __bf16 type __attribute__((ext_vector_type(8), aligned(2))); };
+// f64 -> storage type, one rounding per step (f64 -> f32 -> bf16 for bf16: the mode is not exact anyway)
+template <typename TS> __host__ __device__ __forceinline__ TS narrow(double x) { return (TS)x; }
+template <> __host__ __device__ __forceinline__ __bf16 narrow<__bf16>(double x) { return (__bf16)(float)x; }
+template <typename TS> __host__ __device__ __forceinline__ double widen(TS x) { return (double)x; }
+template <> __host__ __device__ __forceinline__ double widen<__bf16>(__bf16 x) { return (double)(float)x; }
 template <typename TS>
 __device__ __forceinline__ void store16_sc1(TS *p, typename Chunk16<TS>::type c)
 {
@@ -217,8 +224,8 @@ __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cn
                         const chunk_t b = *reinterpret_cast<const chunk_t *>(vr[s] + f0);
 #pragma unroll
                         for (int e = 0; e < VW; ++e) {
-                            uval[s][VW * j + e] = (double)a[e];
-                            vval[s][VW * j + e] = (double)b[e];
+                            uval[s][VW * j + e] = widen<TS>(a[e]);
+                            vval[s][VW * j + e] = widen<TS>(b[e]);
                         }
                     }
                 }
@@ -382,11 +389,11 @@ __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cn
                         for (int e = 0; e < VW; ++e) {
                             const double mf = uval[s][VW * j + e], cf = vval[s][VW * j + e];
                             if constexpr (DOT == 1) {
-                                un[e] = (TS)__builtin_fma(P.lr, __builtin_fma(gr[s], cf, -(P.Ki * mf)), mf);
-                                vn[e] = (TS)__builtin_fma(P.lr, __builtin_fma(gr[s], mf, -(P.Ku * cf)), cf);
+                                un[e] = narrow<TS>(__builtin_fma(P.lr, __builtin_fma(gr[s], cf, -(P.Ki * mf)), mf));
+                                vn[e] = narrow<TS>(__builtin_fma(P.lr, __builtin_fma(gr[s], mf, -(P.Ku * cf)), cf));
                             } else {
-                                un[e] = (TS)(mf + P.lr * (gr[s] * cf - P.Ki * mf));       // kmf_train.pyx:267-270
-                                vn[e] = (TS)(cf + P.lr * (gr[s] * mf - P.Ku * cf));
+                                un[e] = narrow<TS>(mf + P.lr * (gr[s] * cf - P.Ki * mf));       // kmf_train.pyx:267-270
+                                vn[e] = narrow<TS>(cf + P.lr * (gr[s] * mf - P.Ku * cf));
                             }
                         }
                         TS *up = ur[s] + f0, *vp = vr[s] + f0;
@@ -919,12 +926,12 @@ __global__ __launch_bounds__(256) void k_transpose(const TI *in, TO *out, int ro
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     for (int i = ty; i < 32; i += 8) {
         const int r = by + i, c = bx + tx;
-        if (r < rows && c < cols) tile[i][tx] = (double)in[(size_t)r * cols + c];
+        if (r < rows && c < cols) tile[i][tx] = widen<TI>(in[(size_t)r * cols + c]);
     }
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
         const int c = bx + i, r = by + tx;
-        if (r < rows && c < cols) out[(size_t)c * rows + r] = (TO)tile[tx][i];
+        if (r < rows && c < cols) out[(size_t)c * rows + r] = narrow<TO>(tile[tx][i]);
     }
 }
 

@@ -10,8 +10,9 @@
 // scalar part, thread 0 applies the u / v updates, all threads share the y updates; two workgroup barriers per
 // rating.  The three feature vectors live in LDS when they fit (2 ni + nu doubles <= 150 KB: MovieLens-100K
 // does), else in global memory behind sc1 loads.  A legal call is served with the reference's exact bits;
-// it is not fast (about the reference's own speed with the vectors in LDS, several times slower without)
-// and is documented as such.
+// it is NOT fast and cannot be: 0.6 us per rating with the vectors in LDS against 0.06-0.09 us for the
+// reference's own C loop on one host core (tools/svdpp_timing.py: MovieLens-100K / -1M shapes) -- a chain of
+// two workgroup barriers per rating is what a GPU has to offer a sequential loop.  Documented as such.
 #include <math.h>
 #include <vector>
 #include "mfx_common.h"
@@ -54,7 +55,8 @@ __device__ __forceinline__ double ld_l2(const double *p)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // sc1: L2, never a stale L1 line
 }
 
-constexpr int kSThreads = 1024;
+constexpr int kSThreads = 256;          // one wave per SIMD: every wave evaluates the uniform scalar part (sqrt, division,
+                                       // estimate) without fighting for the VALU; 1 024 threads measured 1.1 us per rating
 
 template <bool LDS>
 __global__ __launch_bounds__(kSThreads) void k_svdpp_epoch(SParams P)
@@ -69,17 +71,40 @@ __global__ __launch_bounds__(kSThreads) void k_svdpp_epoch(SParams P)
         __syncthreads();
     }
     double se = 0.0;
+    // Everything a rating needs that no update touches (its record, cache word, biases, the user's slice of
+    // `rated`) is requested one rating ahead -- the record itself two ahead, because the rest hangs off its
+    // ids -- so that a step costs the two barriers and the LDS traffic, not a chain of three global loads;
+    // the user's 1 / sqrt(count) is formed there too (same bits, off the chain).
+    struct Step {
+        int2 ui, h;
+        double r, c, base, norm;
+        int jj;                                  // this thread's first item of the user's rated list (-1: none)
+    };
+    auto load_step = [&](int64_t t, int2 ui, Step &x) {
+        x.ui = ui; x.h = make_int2(0, 0); x.r = 0.0; x.c = 0.0; x.base = 0.0; x.norm = 0.0; x.jj = -1;
+        if (t < P.nnz) {
+            x.h = P.hash[ui.x];
+            x.r = P.r[t];
+            x.c = P.cache[t];
+            x.base = P.mu + P.ib[ui.y] + P.ub[ui.x];
+            x.norm = 1.0 / sqrt((double)x.h.y);                              // :853-854, off the chain
+            if (tid < x.h.y) x.jj = P.rated_item[x.h.x + tid];
+        }
+    };
+    Step cur, nxt;
+    int2 ui2 = make_int2(0, 0);                  // record of rating t + 2
+    load_step(0, P.nnz > 0 ? P.idx[0] : make_int2(0, 0), cur);
+    load_step(1, P.nnz > 1 ? P.idx[1] : make_int2(0, 0), nxt);
+    if (P.nnz > 2) ui2 = P.idx[2];
     for (int64_t t = 0; t < P.nnz; ++t) {
-        const int2 ui = P.idx[t];
-        const int2 h = P.hash[ui.x];
-        const double rt = P.r[t], ct = P.cache[t];
-        const double norm = 1.0 / sqrt((double)h.y);                         // :853-854
+        const int2 ui = cur.ui, h = cur.h;
+        const double norm = cur.norm;
         double cf, fb, mf;
         if constexpr (LDS) { cf = vf[ui.x]; fb = yf[ui.y]; mf = uf[ui.y]; }
         else { cf = ld_l2(vf + ui.x); fb = ld_l2(yf + ui.y); mf = ld_l2(uf + ui.y); }
         const double v_implicit = cf + (norm * fb);                          // :855
-        const double p = estimate(mf, v_implicit, ct, P.mu + P.ib[ui.y] + P.ub[ui.x], P.trail, true);
-        const double err = 1.0 * rt - p;                                     // :860
+        const double p = estimate(mf, v_implicit, cur.c, cur.base, P.trail, true);
+        const double err = 1.0 * cur.r - p;                                  // :860
         __syncthreads();                         // every thread has read y[f,item], u, v: now they may change
         if (tid == 0) {
             se += err * err;
@@ -87,12 +112,15 @@ __global__ __launch_bounds__(kSThreads) void k_svdpp_epoch(SParams P)
             vf[ui.x] = cf + P.lr * (err * mf - P.K * cf);                    // :877
         }
         for (int j = tid; j < h.y; j += kSThreads) {                         // :879-881, the items are distinct
-            const int jj = P.rated_item[h.x + j];
+            const int jj = (j == tid) ? cur.jj : P.rated_item[h.x + j];
             double yv;
             if constexpr (LDS) yv = yf[jj]; else yv = ld_l2(yf + jj);
             yf[jj] = yv + P.lr * (err * norm * mf - P.K * yv);
         }
         if constexpr (!LDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my stores are in L2
+        cur = nxt;
+        load_step(t + 2, ui2, nxt);
+        if (t + 3 < P.nnz) ui2 = P.idx[t + 3];
         __syncthreads();                         // the updates are visible to the next rating
     }
     if constexpr (LDS) {

@@ -27,11 +27,11 @@ class SgdPlan(object):
         if not self._h:
             msg = S.last_error()
             raise (ValueError if ("outside" in msg or "bad argument" in msg) else S.MfxError)(msg)
-        if storage not in ("f64", "f32"):
-            raise ValueError("storage must be 'f64' (exact) or 'f32' (fast mode)")
+        if storage not in ("f64", "f32", "bf16"):
+            raise ValueError("storage must be 'f64' (exact), 'f32' (fast mode) or 'bf16' (measured option)")
         self.storage = storage
-        if storage == "f32":
-            S.check(S.lib().mfx_sgd_plan_set_storage(self._h, 32))
+        if storage != "f64":
+            S.check(S.lib().mfx_sgd_plan_set_storage(self._h, 32 if storage == "f32" else 16))
         # dot: "ordered" = the reference's left-to-right sum (bit-exact); "butterfly" = tolerance mode
         # (wave butterfly with a fixed association + FMA: deterministic, not bit-identical)
         if dot not in ("ordered", "butterfly"):

@@ -418,7 +418,7 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="skip the `also` block (secondary kernels)")
     ap.add_argument("--no-extra", action="store_true", help=argparse.SUPPRESS)   # accepted, no-op
     ap.add_argument("--also-only", default="", help="comma-separated subset of the `also` legs (profiling runs)")
-    ap.add_argument("--storage", choices=["f64", "f32"], default="f64",
+    ap.add_argument("--storage", choices=["f64", "f32", "bf16"], default="f64",
                     help="f32 = NOT the reference's precision: rows stored as f32 (measured option only)")
     ap.add_argument("--cpu-replica", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--start-at", type=float, default=0.0, help=argparse.SUPPRESS)
@@ -589,7 +589,7 @@ def main():
             "ms_per_step": wall * 1e3 / a.steps, "higher_is_better": True,
             "scaling": "weak" if (not multi or a.scaling == "weak") else "strong",
             "vs_baseline": None,
-            "dtype": "f64" if a.storage == "f64" else "f64 arithmetic on f32-stored rows (NOT the reference precision)",
+            "dtype": "f64" if a.storage == "f64" else "f64 arithmetic on %s-stored rows (NOT the reference precision)" % a.storage,
             "data": "synthetic",
             "config": {"workload": "%s: synthetic %dK users x %dK items, %dM ratings%s, k=%d, full-k SGD "
                                    "(train_linear_kernel), %s order, exact level schedule%s" % (

@@ -340,7 +340,40 @@ def test_f32_storage_fast_mode_rmse_budget(golden):
     assert not np.array_equal(u, g["out_lin_u"])                 # it is NOT the exact mode
     np.testing.assert_allclose(u, g["out_lin_u"], rtol=0, atol=2e-5)
     with pytest.raises(ValueError):
-        SgdPlan(idx, r, nu, ni, k, storage="bf16")
+        SgdPlan(idx, r, nu, ni, k, storage="f16")
+
+
+def test_bf16_storage_is_a_measured_option_that_misses_the_budget(golden):
+    # SURVEY 8(f)4 names bf16 row storage next to f32.  Built, measured, NOT recommended: with 8 significant
+    # bits the row updates are quantised to ~0.4 % of the value, and after the fixed epoch count the train RMSE is
+    # off by far more than north_star's 1e-5 (while f32 storage, above, stays inside it).  The test pins both
+    # facts: the mode trains (RMSE falls, finite, deterministic) and it does not meet the budget.
+    from mfrec_amd.plan import SgdPlan
+    from oracle import oracle as O
+    g = golden("g7_cfg1")
+    nu, ni, k, E = int(g["p_nu"]), int(g["p_ni"]), int(g["p_k"]), int(g["p_epochs"])
+    idx, r = g["in_idx"], g["in_r"].astype(np.float64)
+    seed = int(g["p_seed_init"])
+    res = []
+    for rep in range(2):
+        u, v = synth.init_normal(k, ni, seed), synth.init_normal(k, nu, seed + 1)
+        ib, ub = np.zeros(ni), np.zeros(nu)
+        with SgdPlan(idx, r, nu, ni, k, storage="bf16") as p:
+            assert "bf16" in p.kernel_name(0)
+            p.set_factors(u, v, ib, ub)
+            rm = p.run_kmf(0, E, 0.01, 0.1, 0.1, 0.007)
+            p.get_factors(u, v, ib, ub)
+        res.append((u, v, rm))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][2], res[1][2])      # deterministic
+    u, v, rm = res[0]
+    rmse = O.rmse(O.RMSE_KMF_LINEAR, u, v, idx, r, ib, ub)
+    delta = abs(rmse - float(g["out_lin_final_rmse"]))
+    print("bf16 storage: final train RMSE %.6f vs reference %.6f (delta %.2e)" % (rmse, float(g["out_lin_final_rmse"]), delta))
+    assert np.all(np.isfinite(rm)) and rm[-1] < rm[0]            # it does train
+    assert delta > 1e-5                                          # ... and misses north_star's budget
+    assert delta < 0.2                                           # (without diverging)
+    with pytest.raises(ValueError):
+        SgdPlan(idx, r, nu, ni, 12, storage="bf16")              # k must be a multiple of 8
 
 
 def test_butterfly_dot_tolerance_mode(golden):

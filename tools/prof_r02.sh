@@ -49,4 +49,4 @@ for name in ("fetch", "write", "alspmc"):
 json.dump(out, open(O + "/summary.json", "w"), indent=1)
 PY
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -size +5M -delete
-du -sh $O; tail -3 $O/*.log | grep -i -E "malformed|abort|error" | head
+du -sh $O; (tail -q -n 3 $O/*.log | grep -i -E "malformed|abort" | head) || true

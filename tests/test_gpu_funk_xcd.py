@@ -92,3 +92,31 @@ def test_large_levels_take_the_xcd_path_by_default(monkeypatch):
     u2, v2 = synth.init_const(k, ni), synth.init_const(k, nu)
     O.estimator_loop_without_bias(2, 2, 1e9, k, 0.1, 0.001, 0.05, u2, v2, idx, r, nu, ni)
     assert np.array_equal(u, u2) and np.array_equal(v, v2)
+
+
+@pytest.mark.parametrize("skew", ["zipf_items", "zipf_users", "few_users"])
+def test_uneven_load_bitexact(skew):
+    """Hand-offs must hold under UNEVEN load: skewed items (long chains of tiny levels next to fat ones), skewed
+    users (one workgroup's group carries most of a level, others sit in the barrier), and fewer users than groups
+    (most workgroups own empty slices)."""
+    from mfrec_amd.lib import gd_estimator as G
+    from oracle import oracle as O
+    rs = np.random.RandomState(5)
+    nu, ni, nnz, k = 6000, 4000, 300000, 2
+    if skew == "zipf_items":
+        users = rs.randint(0, nu, nnz)
+        items = np.minimum((rs.zipf(1.3, nnz) - 1), ni - 1)
+    elif skew == "zipf_users":
+        users = np.minimum((rs.zipf(1.2, nnz) - 1), nu - 1)
+        items = rs.randint(0, ni, nnz)
+    else:
+        nu = 20
+        users = rs.randint(0, nu, nnz)
+        items = rs.randint(0, ni, nnz)
+    idx = np.ascontiguousarray(np.stack([users, items], 1).astype(np.int32))
+    r = rs.randint(1, 6, nnz).astype(np.float64)
+    u, v = synth.init_const(k, ni), synth.init_const(k, nu)
+    G.estimator_loop_without_bias(2, 2, 1e9, k, 0.1, 0.001, 0.05, u, v, idx, r, nu, ni)
+    u2, v2 = synth.init_const(k, ni), synth.init_const(k, nu)
+    O.estimator_loop_without_bias(2, 2, 1e9, k, 0.1, 0.001, 0.05, u2, v2, idx, r, nu, ni)
+    assert np.array_equal(u, u2) and np.array_equal(v, v2)

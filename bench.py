@@ -464,7 +464,10 @@ def main():
     B.build(verbose=False)
     try:
         # MFX_BENCH_DEVICE: rehearsal hook (several ranks on one GPU); the driver never sets it
-        S.init(int(os.environ.get("MFX_BENCH_DEVICE", local)))
+        # one process per GPU: device = LOCAL_RANK; a launcher that narrows every rank's view to its own GPU
+        # (HIP_VISIBLE_DEVICES per process) leaves a single visible device 0
+        ndev = max(S.device_count(), 1)
+        S.init(int(os.environ.get("MFX_BENCH_DEVICE", local if local < ndev else local % ndev)))
         if multi:
             def make_id():
                 idbuf = C.create_string_buffer(S.UNIQUE_ID_BYTES)

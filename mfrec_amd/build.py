@@ -69,6 +69,14 @@ def build(force=False, verbose=True):
         if verbose:
             print("[mfrec_amd.build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd, cwd=objdir)
+        # keep the object and the device assembly (the lint's input); the other temporaries (preprocessed
+        # sources, bitcode, host assembly) are bulk that would travel with every snapshot
+        stem = os.path.splitext(os.path.basename(src))[0]
+        for f in os.listdir(objdir):
+            if f.startswith(stem + "-") and not f.endswith("gfx950.s"):
+                os.remove(os.path.join(objdir, f))
+            elif f.startswith(os.path.basename(src) + "-") and f.endswith(".hipfb"):
+                os.remove(os.path.join(objdir, f))
         return obj
 
     with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1, 8)) as ex:

@@ -442,6 +442,23 @@ def main():
     if multi and world == 1:
         os.environ["MFX_FORCE_COMM"] = "1"
 
+    if world > 1:
+        # a rank that never comes back from a collective (a peer died, a link is down) would sit there until the
+        # driver's own limit: say which rank and where, then end the process with an error
+        import threading
+        where = ["start"]
+
+        def stuck():
+            fail_line(rank, world, "watchdog", "no progress after %s s, last stage: %s"
+                      % (os.environ.get("MFX_BENCH_TIMEOUT", "1500"), where[0]))
+            os._exit(3)
+
+        main_dog = threading.Timer(float(os.environ.get("MFX_BENCH_TIMEOUT", "1500")), stuck)
+        main_dog.daemon = True
+        main_dog.start()
+    else:
+        where = ["start"]
+
     cfg = CFG2 if (a.workload == "cfg2" or (a.workload == "auto" and not multi)) else CFG3
     nu, ni, nnz = a.users or cfg[0], a.items or cfg[1], a.nnz or cfg[2]
     k = a.k
@@ -462,6 +479,7 @@ def main():
         if rank != 0:
             uid = rendezvous.exchange_unique_id(rank, world, None)
     B.build(verbose=False)
+    where[0] = "device / RCCL communicator init"
     try:
         # MFX_BENCH_DEVICE: rehearsal hook (several ranks on one GPU); the driver never sets it
         # one process per GPU: device = LOCAL_RANK; a launcher that narrows every rank's view to its own GPU
@@ -481,6 +499,7 @@ def main():
         fail_line(rank, world, "device / RCCL communicator init", e)
         raise
 
+    where[0] = "synthetic data + plan (schedule build, upload)"
     # ---- data: the whole job's ratings are a pure function of the counter, so every rank generates them
     # and keeps its own users (strong scaling: same 100M ratings at every N) -------------------------
     if world > 1 and a.scaling == "weak":
@@ -541,6 +560,7 @@ def main():
         S.check(S.lib().mfx_comm_allreduce_max(C.byref(w)))
         return w.value
 
+    where[0] = "warmup / timed region (averaging mode: k1 epochs + ncclAllReduce)"
     try:
         run(max(a.warmup, 0))
         barrier()
@@ -642,6 +662,7 @@ def main():
             emit()
             os._exit(0)
 
+        where[0] = "dsgd leg (block rotation: ncclSend/Recv ring)"
         dog = threading.Timer(limit_s, give_up)
         dog.daemon = True
         dog.start()

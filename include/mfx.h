@@ -92,7 +92,7 @@ int mfx_schedule_balanced_order(const int32_t *ratings_index, int64_t nnz, int n
 /* The same kind of order built on the GPU in milliseconds: the dependency levels of the given order
  * (mfx_schedule_levels_gpu) are first-fit recoloured level by level -- inside a level no two ratings
  * share a user or an item, so a level recolours in parallel, deterministically.  Round-major, ascending
- * input index inside a round.  (The reference's own order is an unseeded shuffle, base.py:1127-1129.) */
+ * item inside a round.  (The reference's own order is an unseeded shuffle, base.py:1127-1129.) */
 int mfx_schedule_balanced_order_gpu(const int32_t *ratings_index, int64_t nnz, int nu, int ni,
                                     int64_t *perm_out, int64_t *n_rounds_out);
 

@@ -2,6 +2,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <chrono>
 #include <thread>
 #include <unordered_map>
@@ -625,6 +626,23 @@ mfx_sgd_plan *mfx_sgd_plan_create2(const int32_t *idx, const double *r, int64_t 
             std::vector<Rec> recs((size_t)(nnz ? nnz : 1));
             if (mfx_schedule_pack(idx, r, level.data(), nnz, p->n_levels, recs.data(), p->level_off.data()))
                 return bail();
+            // inside a level: ascending item, like the device builder (an item occurs once per level)
+            {
+                unsigned hw = std::thread::hardware_concurrency();
+                const int T = nnz < (1 << 18) ? 1 : (int)std::min<unsigned>(hw ? hw : 1, 16);
+                auto work = [&](int i) {
+                    for (int64_t l = i; l < p->n_levels; l += T)
+                        std::sort(recs.begin() + p->level_off[(size_t)l], recs.begin() + p->level_off[(size_t)l + 1],
+                                  [](const Rec &a, const Rec &b) { return a.item < b.item; });
+                };
+                if (T == 1) {
+                    work(0);
+                } else {
+                    std::vector<std::thread> th;
+                    for (int i = 0; i < T; ++i) th.emplace_back(work, i);
+                    for (auto &x : th) x.join();
+                }
+            }
             if (hipMemcpy(p->d_recs, recs.data(), (size_t)nnz * sizeof(Rec), hipMemcpyHostToDevice) != hipSuccess) {
                 fail(MFX_E_HIP, "mfx_sgd_plan_create: upload failed: %s", hipGetErrorString(hipGetLastError()));
                 return bail();

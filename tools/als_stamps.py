@@ -5,7 +5,7 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, scipy.sparse as sp
 from mfrec_amd import _shim as S, synth
-S.LIB_PATH = S.LIB_PATH.replace("libmfx.so", "libmfx_diag.so")
+S.LIB_PATH = os.environ.get("MFX_LIB") or S.LIB_PATH.replace("libmfx.so", "libmfx_diag.so")
 from mfrec_amd.lib.als_implicit import als_wrmf
 from mfrec_amd.lib.datasets import create_bool_sparse_col, create_bool_sparse_row
 S.init(0)

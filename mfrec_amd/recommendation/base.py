@@ -7,6 +7,7 @@ import logging
 import pickle
 
 import numpy as np
+import scipy.sparse as sp
 from scipy.sparse import lil_matrix
 
 
@@ -52,11 +53,33 @@ class BaseRecommender(object):
         self.relationship_matrix[user_index, item_index] = float(value)     # base.py:823-828
 
     def set_ratings(self, ratings_index, ratings):
-        """Bulk load of (user, item) -> rating triples (later duplicates win, as repeated
-        set_item_by_id calls would)."""
+        """Bulk load of (user, item) -> rating triples: the matrix a loop of set_item_by_id calls over the triples
+        would leave (later duplicates win, a cell that is given again is overwritten, a 0 clears its cell),
+        built with array operations -- the per-cell loop needs ~2.5 us per rating (base.py:823-828 is one lil
+        assignment per call), i.e. minutes at 10^8 ratings."""
         ratings_index = np.asarray(ratings_index)
-        for (a, b), x in zip(ratings_index, np.asarray(ratings, dtype=np.float64)):
-            self.relationship_matrix[int(a), int(b)] = float(x)
+        vals = np.asarray(ratings, dtype=np.float64)
+        if ratings_index.ndim != 2 or ratings_index.shape[1] != 2 or ratings_index.shape[0] != vals.shape[0]:
+            raise Error("The index and the ratings array must be the same size")
+        n = vals.shape[0]
+        if n == 0:
+            return
+        u = ratings_index[:, 0].astype(np.int64)
+        i = ratings_index[:, 1].astype(np.int64)
+        if u.min() < 0 or u.max() >= self.nbr_users or i.min() < 0 or i.max() >= self.nbr_items:
+            raise IndexError("rating outside the %d x %d matrix" % (self.nbr_users, self.nbr_items))
+        keys = u * self.nbr_items + i
+        _, first_rev = np.unique(keys[::-1], return_index=True)         # last occurrence of every cell
+        last = n - 1 - first_rev
+        shape = (self.nbr_users, self.nbr_items)
+        new = sp.csr_matrix((vals[last], (u[last], i[last])), shape=shape)
+        old = self.relationship_matrix.tocsr()
+        if old.nnz:
+            given = sp.csr_matrix((np.ones(last.shape[0]), (u[last], i[last])), shape=shape)
+            old = old - old.multiply(given)                             # cells given again lose their old value
+            new = old + new
+        new.eliminate_zeros()
+        self.relationship_matrix = new.tolil()
 
     def get_nbr_ratings(self):
         return int(self.relationship_matrix.tocoo().nnz)

@@ -1,5 +1,6 @@
 """CPU: host-side marshalling that sits either side of the kernels."""
 import numpy as np
+import pytest
 import scipy.sparse as sp
 
 from mfrec_amd.lib import datasets as D
@@ -149,3 +150,28 @@ def test_balanced_order_falls_back_when_a_builder_refuses(monkeypatch):
     idx, r = R.get_ratings(randomize_order="balanced")
     assert calls == ["gpu", "host"]
     assert sorted(r.tolist()) == [1.0, 2.0, 3.0, 4.0, 5.0] and idx.shape == (5, 2)     # the plain shuffle
+
+
+def test_bulk_set_ratings_equals_the_per_cell_loop():
+    """set_ratings (array operations) leaves the matrix a loop of set_item_by_id calls (base.py:823-828) would:
+    later duplicates win, cells given again are overwritten, a 0 clears its cell -- checked over several rounds."""
+    from mfrec_amd.recommendation.base import BaseRecommender, Error
+    rs = np.random.RandomState(3)
+    for trial in range(12):
+        nu, ni = rs.randint(1, 30), rs.randint(1, 30)
+        a, b = BaseRecommender(nu, ni), BaseRecommender(nu, ni)
+        for rnd in range(3):
+            n = rs.randint(0, 200)
+            idx = np.stack([rs.randint(0, nu, n), rs.randint(0, ni, n)], 1).astype(np.int32)
+            r = rs.randint(0, 6, n).astype(np.float64)
+            a.set_ratings(idx, r)
+            for (x, y), v in zip(idx, r):
+                b.set_item_by_id(int(x), int(y), v)
+            assert np.array_equal(a.relationship_matrix.toarray(), b.relationship_matrix.toarray())
+            (ia, ra), (ib, rb) = a.get_ratings(False), b.get_ratings(False)
+            assert np.array_equal(ia, ib) and np.array_equal(ra, rb)
+            assert a.get_nbr_ratings() == b.get_nbr_ratings()
+    with pytest.raises(IndexError):
+        BaseRecommender(3, 3).set_ratings(np.array([[3, 0]]), np.array([1.0]))
+    with pytest.raises(Error):
+        BaseRecommender(3, 3).set_ratings(np.array([[1, 0]]), np.array([1.0, 2.0]))

@@ -49,6 +49,8 @@ int mfx_device_count(void);                 /* hipGetDeviceCount; 0 if none / er
 int mfx_init(int device);                   /* bind this process to `device`, create stream */
 int mfx_sync(void);                         /* hipStreamSynchronize on the library stream  */
 int mfx_device_name(char *buf, int buflen); /* gcnArchName of the bound device             */
+/* hipMemGetInfo of the bound device, bytes (either pointer may be NULL) -- capacity planning and leak tests */
+int mfx_device_mem_info(int64_t *free_bytes, int64_t *total_bytes);
 /* HIP-event stopwatch on the library's stream (the stream every kernel is launched on). */
 int mfx_timer_start(void);
 int mfx_timer_stop(double *elapsed_ms);

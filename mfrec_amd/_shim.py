@@ -29,6 +29,7 @@ SIGNATURES = {
     "mfx_init": (C.c_int, [C.c_int]),
     "mfx_sync": (C.c_int, []),
     "mfx_device_name": (C.c_int, [C.c_char_p, C.c_int]),
+    "mfx_device_mem_info": (C.c_int, [_lp, _lp]),
     "mfx_timer_start": (C.c_int, []),
     "mfx_timer_stop": (C.c_int, [_dp]),
     "mfx_last_compute_ms": (C.c_double, []),

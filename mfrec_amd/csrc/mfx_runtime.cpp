@@ -133,6 +133,16 @@ int mfx_device_name(char *buf, int buflen)
     return MFX_OK;
 }
 
+int mfx_device_mem_info(int64_t *free_bytes, int64_t *total_bytes)
+{
+    if (mfx::ensure_init()) return mfx::last_code();
+    size_t f = 0, t = 0;
+    MFX_HIP(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (int64_t)f;
+    if (total_bytes) *total_bytes = (int64_t)t;
+    return MFX_OK;
+}
+
 int mfx_timer_start(void)
 {
     int rc = mfx::ensure_init();

@@ -119,6 +119,12 @@ class BaseRecommender(object):
             np.random.shuffle(order)
         return np.ascontiguousarray(ratings_index[order]), np.ascontiguousarray(ratings[order])
 
+    def get_items_subset(self, count=100, method="random"):
+        """base.py:1134-1145: `count` item ids of a shuffle drawn from the global numpy RNG."""
+        ids = np.arange(self.nbr_items)
+        np.random.shuffle(ids)
+        return ids[0:count]
+
     def compute_overall_avg(self):
         data = self.relationship_matrix.tocoo().data                         # base.py:504-508
         self.overall_bias = float(data[data != 0].astype(float).mean())

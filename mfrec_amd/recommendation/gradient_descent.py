@@ -106,6 +106,11 @@ class GDRecommender(MFRecommender):
         s = np.dot(self.svd_u[:, item_index], self.svd_v[:, user_index])
         return s + self.overall_bias + (self.items_bias[item_index] + self.users_bias[user_index])
 
+    def find_user_top_match(self, user_index, nbr_recommendations=5):
+        """gradient_descent.py:768-800: every item scored with predict_rating, the user's rated items and the item
+        whose id equals user_index excluded, zero scores dropped -> (items, scores)."""
+        return self._top_items(user_index, self.nbr_items, "predict_rating", nbr_recommendations)
+
     def _retrain(self, sel, ratings_index, ratings, update_users, update_items, verbose):
         if self.items_bias is None or self.users_bias is None:
             self.compute_overall_avg(); self.compute_items_bias_bk(); self.compute_users_bias_bk()

@@ -96,15 +96,41 @@ class MFRecommender(BaseRecommender):
         self.retrain_item(new_id, idx, vals)
         return new_id
 
-    def find_recommended_items(self, user_index, nbr_recommendations=5, predictor="predict"):
-        """Top-N items for a user by predicted rating (mf.py:144-193), one batched GPU pass."""
+    def find_recommended_items(self, user_index=None, user_label=None, nbr_recommendations=5,
+                               output_label=False, predictor="predict"):
+        """Top-N items for a user (mf.py:144-193) -> (items, scores), two lists.  As in the reference: the
+        candidates are items 0 .. neighborhood-1 (it draws a random subset with get_items_subset and then
+        indexes by position, mf.py:159-163 -- the draw is kept so that a seeded RNG stream stays aligned), the
+        user's rated items AND the item whose id equals user_index (mf.py:162) score 0, NaN scores 0, zero
+        scores are dropped, the rest goes by descending score (ties: ascending item).  The scoring itself is
+        one batched GPU pass instead of a Python loop over predict()."""
+        if user_index is None:
+            user_index = self.users_index[user_label]
+        self.neighborhood = min([self.neighborhood, self.nbr_items])
+        n = int(self.neighborhood)
+        self.get_items_subset(count=n)
+        top, scores = self._top_items(user_index, n, predictor, nbr_recommendations)
+        return ([self.items_label[i] for i in top] if output_label else top), scores
+
+    def _top_items(self, user_index, n, predictor, nbr_recommendations):
+        """Score items 0 .. n-1 for the user in one batched GPU pass and rank them the reference's way
+        (mf.py:161-191, gradient_descent.py:774-800)."""
         from .metrics import predict_batch
-        idx = np.zeros([self.nbr_items, 2], dtype=np.int32)
+        idx = np.zeros([n, 2], dtype=np.int32)
         idx[:, 0] = user_index
-        idx[:, 1] = np.arange(self.nbr_items)
-        pred, _ = predict_batch(self, idx, predictor)
-        order = np.argsort(-pred, kind="stable")[:nbr_recommendations]
-        return [(int(i), float(pred[i])) for i in order]
+        idx[:, 1] = np.arange(n)
+        user_ratings, _ = predict_batch(self, idx, predictor)
+        rel = self.relationship_matrix
+        if user_index < rel.shape[0]:              # a folded-in user has no row in the ratings matrix
+            row = rel[user_index, :].tocoo()
+            rated = row.col[row.data != 0]
+            user_ratings[rated[rated < n]] = 0.0
+        if 0 <= user_index < n:
+            user_ratings[user_index] = 0.0
+        user_ratings[np.isnan(user_ratings)] = 0.0
+        nz = user_ratings.nonzero()[0]
+        top = nz[np.argsort(-user_ratings[nz], kind="stable")][:nbr_recommendations]
+        return [int(i) for i in top], [float(user_ratings[i]) for i in top]
 
     def init_feature_const(self):
         """zeros + feature_init (gradient_descent.py:524-525, wrmf.py:92-93)."""

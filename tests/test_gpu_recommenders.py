@@ -138,9 +138,28 @@ def test_folding_in_and_top_n():
     assert np.array_equal(R.svd_u, u_before)                       # items untouched (gate 0)
     assert np.array_equal(R.svd_v[:, :nu], v_before)               # other users untouched
     assert np.any(R.svd_v[:, nu] != 0.0)
-    top = R.find_recommended_items(new, 5, "predict_linear")
-    scores = [R.predict_linear(i, new) for i in range(ni)]
-    assert [t[0] for t in top] == list(np.argsort(-np.array(scores), kind="stable")[:5])
+    top, top_scores = R.find_recommended_items(new, nbr_recommendations=5, predictor="predict_linear")
+    scores = np.array([R.predict_linear(i, new) for i in range(ni)])
+    assert top == list(np.argsort(-scores, kind="stable")[:5])
+    assert np.allclose(top_scores, scores[top], rtol=1e-12)
+    # an existing user: the reference's rules (mf.py:144-193) restated as the loop it runs -- rated items and the
+    # item whose id equals the user id score 0, zero scores are dropped, the global RNG is advanced by one shuffle
+    user = 7
+    R.neighborhood = 60
+    np.random.seed(5)
+    got_items, got_scores = R.find_recommended_items(user_index=user, nbr_recommendations=8, predictor="predict_linear")
+    after = np.random.randint(0, 1 << 30)
+    np.random.seed(5)
+    np.random.shuffle(np.arange(R.nbr_items))
+    assert after == np.random.randint(0, 1 << 30)
+    rated = set(R.relationship_matrix[user, :].tocoo().col.tolist()) | {user}
+    want = {i: R.predict_linear(i, user) for i in range(60) if i not in rated}
+    ranked = sorted(want.items(), key=lambda kv: (-kv[1], kv[0]))[:8]
+    assert got_items == [i for i, _ in ranked] and np.allclose(got_scores, [x for _, x in ranked], rtol=1e-12)
+    R.items_label = {i: "item-%d" % i for i in range(R.nbr_items)}
+    R.users_index = {"u7": user}
+    lab, _ = R.find_recommended_items(user_label="u7", nbr_recommendations=3, output_label=True, predictor="predict_linear")
+    assert lab == ["item-%d" % i for i in got_items[:3]]
     new_item = R.add_item("thing", np.array([1, 2, 3], dtype=np.int32), np.array([4.0, 4.0, 5.0]))
     assert new_item == ni and R.svd_u.shape == (k, ni + 1)
     assert np.array_equal(R.svd_v[:, :nu], v_before)
@@ -230,3 +249,20 @@ def test_folding_in_matches_oracle_and_empty_fold_in_is_a_noop():
                           np.ascontiguousarray(idx[sel]), np.ascontiguousarray(r[sel]), ib0, ub0, 1, 0)
     assert np.array_equal(K.svd_u, u0) and np.array_equal(K.svd_v, v0)
     assert np.array_equal(K.items_bias, ib0) and np.array_equal(K.users_bias, ub0)
+
+
+def test_gd_find_user_top_match_follows_the_reference_rules():
+    """gradient_descent.py:768-800 restated as the loop it runs: every item scored with predict_rating, the
+    user's rated items and the item whose id equals the user id excluded, zero scores dropped, descending."""
+    from mfrec_amd.recommendation import GDRecommender
+    nu, ni, k = 80, 70, 6
+    R = _fill(GDRecommender(nu, ni, {"min_epochs": 2, "max_epochs": 2, "nbr_features": k}), nu, ni, 1500, 4)
+    np.random.seed(2)
+    R.train()
+    for user in (0, 11, 69, 79):
+        items, scores = R.find_user_top_match(user, nbr_recommendations=6)
+        rated = set(R.relationship_matrix[user, :].tocoo().col.tolist()) | {user}
+        want = {i: R.predict_rating(i, user) for i in range(ni) if i not in rated}
+        ranked = sorted(((i, x) for i, x in want.items() if x != 0.0), key=lambda kv: (-kv[1], kv[0]))[:6]
+        assert items == [i for i, _ in ranked]
+        assert np.allclose(scores, [x for _, x in ranked], rtol=1e-12)

@@ -66,6 +66,76 @@ class GDRecommender(MFRecommender):
             ratings_index, ratings, self.items_bias, self.users_bias, self.nbr_users,
             self.nbr_items, int(verbose))
 
+    def feature_training2(self, initialize_model=True, verbose=False):
+        """gradient_descent.py:299-328: the per-epoch variant -- estimator_subloop once per epoch on a dense
+        nu x ni cache owned by the caller, predictor_subloop after every feature; ratings in matrix order.
+        (`rmse` carries over from feature to feature, `rmse_last` is first assigned inside the loop: with
+        min_epochs = 0 the reference raises UnboundLocalError, and so does this.)"""
+        rmse = 2.0
+        if initialize_model:
+            self.init_feature_const()
+        ratings_cache = np.zeros(self.nbr_users * self.nbr_items, dtype=np.float64)
+        ratings_index, ratings = self.get_ratings()
+        for f in range(self.dimensionality):
+            epoch = 0
+            while epoch < self.min_epochs or rmse <= rmse_last - self.min_improvement:
+                rmse_last = rmse
+                rmse = _kernels.estimator_subloop(f, epoch, self.min_improvement, self.dimensionality,
+                                                  self.feature_init, self.learning_rate, self.K, self.svd_u,
+                                                  self.svd_v, ratings_index, ratings, ratings_cache,
+                                                  self.nbr_users, self.nbr_items, int(verbose))
+                epoch += 1
+            _kernels.predictor_subloop(f, epoch, self.dimensionality, self.feature_init, self.svd_u, self.svd_v,
+                                       ratings_index, ratings, ratings_cache, self.nbr_users, self.nbr_items)
+
+    def feature_training_folding(self, initialize_model=False, handle_bias=False, verbose=False):
+        """gradient_descent.py:450-470: feature_training on the model as it stands (no re-initialisation by
+        default, biases as they are), then the per-component means."""
+        if initialize_model:
+            self.init_feature_const()
+        ratings_index, ratings = self.get_ratings(randomize_order=True)
+        if handle_bias:
+            # the reference passes this argument list (:461-463) -- two learning rates short of the kernel's
+            # signature (gd_estimator.pyx:489-507) -- so handle_bias=True raises TypeError there, and here
+            _kernels.estimator_loop_with_bias(
+                self.min_epochs, self.max_epochs, self.min_improvement, self.dimensionality,
+                self.feature_init, self.learning_rate, self.K, self.overall_bias, self.svd_u, self.svd_v,
+                ratings_index, ratings, self.items_bias, self.users_bias, self.nbr_users,
+                self.nbr_items, int(verbose))
+        else:
+            _kernels.estimator_loop_without_bias(
+                self.min_epochs, self.max_epochs, self.min_improvement, self.dimensionality,
+                self.feature_init, self.learning_rate, self.K, self.svd_u, self.svd_v,
+                ratings_index, ratings, self.nbr_users, self.nbr_items, int(verbose))
+        self.compute_components_mean()
+
+    def feature_training_dev(self, initialize_model=True, probe=None, verbose=False):
+        """gradient_descent.py:577-599: estimator_loop (dense cache, honours max_epochs) -> the rmse history
+        f64[max_epochs * k].  The reference draws the shuffle and then overwrites the arrays with the matrix
+        order (:589-593); the draw is kept for the RNG stream, the order is the matrix order."""
+        rmse = np.zeros(self.max_epochs * self.dimensionality)
+        if initialize_model:
+            self.init_feature_const()
+        self.get_ratings(randomize_order=True)
+        ratings_index, ratings = self.get_ratings(randomize_order=False)
+        _kernels.estimator_loop(self.min_epochs, self.max_epochs, self.min_improvement, self.dimensionality,
+                                self.feature_init, self.learning_rate, self.K, self.svd_u, self.svd_v,
+                                ratings_index, ratings, 0, rmse, self.nbr_users, self.nbr_items, int(verbose))
+        return rmse
+
+    def compute_components_mean(self):                                        # :803-809
+        self.components_mean = self.svd_u.mean(axis=1)
+
+    def estimate_rating(self, feature_index, user_index, f, cache=False, trailing=False):
+        """gradient_descent.py:602-619: the Funk estimate of one pair at feature f (host scalar helper)."""
+        total = cache if (cache and cache > 0) else 1.0
+        total += self.svd_u[f, feature_index] * self.svd_v[f, user_index]
+        total = self.clamping(total)
+        if trailing:
+            total += (self.dimensionality - f - 1) * self.feature_init * self.feature_init
+            total = self.clamping(total)
+        return total
+
     def get_feedback(self):
         """gradient_descent.py:269-296: the rated (user, item) pairs in COO order of the boolean ratings matrix
         (users ascending, items ascending) and, per user, (first row, count) -- (-1, -1) for a user without ratings."""

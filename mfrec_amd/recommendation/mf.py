@@ -12,6 +12,21 @@ class MFRecommender(BaseRecommender):
         self.neighborhood = 500
         self.K2 = self.K3 = 0.01
 
+    def clamping(self, value, min=1.0, max=5.0):
+        """mf.py:44-53: hard [1, 5] clamp (the min / max arguments are ignored there too)."""
+        if value > 5.0:
+            value = 5.0
+        if value < 1.0:
+            value = 1.0
+        return value
+
+    def predict_rating_by_label(self, user_label, item_label, predictor="predict_logistic"):
+        """mf.py:67-75: predictor(item, user) by labels; an unknown label gives overall_avg."""
+        try:
+            return getattr(self, predictor)(self.items_index[item_label], self.users_index[user_label])
+        except KeyError:
+            return self.overall_avg
+
     def _coo(self):
         coo = self.relationship_matrix.tocoo()
         keep = coo.data != 0

@@ -266,3 +266,46 @@ def test_gd_find_user_top_match_follows_the_reference_rules():
         ranked = sorted(((i, x) for i, x in want.items() if x != 0.0), key=lambda kv: (-kv[1], kv[0]))[:6]
         assert items == [i for i, _ in ranked]
         assert np.allclose(scores, [x for _, x in ranked], rtol=1e-12)
+
+
+def test_gd_secondary_trainers_match_oracle():
+    """feature_training2 (per-epoch subloop on a dense cache, gradient_descent.py:299-328), feature_training_dev
+    (estimator_loop, :577-599, returns the rmse history) and feature_training_folding (:450-470) against the
+    oracle's loops on the same order and initial factors -- bit for bit."""
+    from mfrec_amd.recommendation import GDRecommender
+    from oracle import oracle as O
+    nu, ni, k = 60, 45, 5
+    P = {"min_epochs": 3, "max_epochs": 4, "nbr_features": k, "min_improvement": 1e9}
+    R = _fill(GDRecommender(nu, ni, P), nu, ni, 900, 6)
+    idx, r = R.get_ratings(False)
+
+    R.feature_training2()
+    u, v = np.full((k, ni), 0.1), np.full((k, nu), 0.1)
+    cache = np.zeros(nu * ni)
+    for f in range(k):
+        for e in range(3):
+            O.estimator_subloop(f, e, 1e9, k, 0.1, R.learning_rate, R.K, u, v, idx, r, cache, nu, ni)
+        O.predictor_subloop(f, 3, k, 0.1, u, v, idx, r, cache, nu, ni)
+    assert np.array_equal(R.svd_u, u) and np.array_equal(R.svd_v, v)
+
+    np.random.seed(9)
+    hist = R.feature_training_dev()
+    u, v = np.full((k, ni), 0.1), np.full((k, nu), 0.1)
+    h2 = np.zeros(4 * k)
+    O.estimator_loop(3, 4, 1e9, k, 0.1, R.learning_rate, R.K, u, v, idx, r, 0, h2, nu, ni)
+    assert np.array_equal(R.svd_u, u) and np.array_equal(R.svd_v, v)
+    assert np.allclose(hist, h2, rtol=1e-12, atol=0) and hist.shape == (4 * k,)
+
+    # folding: continues from the model as it stands, shuffled order from the global RNG, then the means
+    u0, v0 = R.svd_u.copy(), R.svd_v.copy()
+    np.random.seed(4)
+    R.feature_training_folding()
+    np.random.seed(4)
+    sidx, sr = R.get_ratings(True)
+    O.estimator_loop_without_bias(3, 4, 1e9, k, 0.1, R.learning_rate, R.K, u0, v0, sidx, sr, nu, ni)
+    assert np.array_equal(R.svd_u, u0) and np.array_equal(R.svd_v, v0)
+    assert np.array_equal(R.components_mean, R.svd_u.mean(axis=1))
+    with pytest.raises(TypeError):
+        R.feature_training_folding(handle_bias=True)          # the reference's call is two arguments short
+    assert R.estimate_rating(3, 2, 1, trailing=True) == R.clamping(
+        R.clamping(1.0 + R.svd_u[1, 3] * R.svd_v[1, 2]) + (k - 2) * 0.1 * 0.1)

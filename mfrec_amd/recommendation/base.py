@@ -24,14 +24,26 @@ class BaseRecommender(object):
         self.dimensionality = 40                      # base.py:90
         self.min_rating, self.max_rating = 1.0, 5.0   # base.py:92-93
         self._nbr_users, self._nbr_items = int(nbr_users), int(nbr_items)
-        self.relationship_matrix = lil_matrix((self._nbr_users, self._nbr_items))
+        self.relationship_matrix = None
         self.relationship_matrix_csc = None
         self.relationship_matrix_csr = None
         self.svd_u = self.svd_v = self.svd_s = None
         self.users_bias = self.items_bias = self.overall_bias = None
-        # label <-> index maps of the reference's container (base.py:96-101); carried through save_state
-        self.users_label, self.users_index = {}, {}
-        self.items_label, self.items_index, self.items_index_map = {}, {}, {}
+        # label <-> index maps of the reference's container (base.py:96-101): label LISTS indexed by id,
+        # index DICTS keyed by label; carried through save_state
+        self.users_label, self.users_index = [], {}
+        self.items_label, self.items_index, self.items_index_map = [], {}, {}
+        self.initialize_relationship_matrix(self._nbr_users, self._nbr_items)
+
+    def initialize_relationship_matrix(self, nbr_users, nbr_items):
+        """base.py:266-281: an empty users x items lil_matrix and the default labels 'user<i>' / 'item<i>'."""
+        self.relationship_matrix = lil_matrix((nbr_users, nbr_items))
+        for item in range(nbr_items):
+            self.items_label.append("item" + str(item))
+            self.items_index["item" + str(int(item))] = int(item)
+        for user in range(nbr_users):
+            self.users_label.append("user" + str(user))
+            self.users_index["user" + str(user)] = user
 
     @property
     def nbr_users(self):
@@ -51,6 +63,48 @@ class BaseRecommender(object):
     # ---- ratings container ----------------------------------------------------------
     def set_item_by_id(self, user_index, item_index, value):
         self.relationship_matrix[user_index, item_index] = float(value)     # base.py:823-828
+
+    def set_item(self, user, items_list):
+        """base.py:815-820: items_list = [{'label': item label, 'value': rating}, ...] for the user LABEL."""
+        for item in items_list:
+            self.relationship_matrix[int(self.users_index[user]), int(self.items_index[item["label"]])] = float(item["value"])
+
+    def set_item_by_label(self, user, item, value):                          # base.py:831-836
+        self.relationship_matrix[int(self.users_index[user]), int(self.items_index[item])] = float(value)
+
+    def build_index(self):
+        """base.py:839-851: rebuild both index dicts from the label lists."""
+        self.users_index = {}
+        self.items_index = {}
+        for i, user in enumerate(self.users_label):
+            self.users_index[user] = i
+        for i, item in enumerate(self.items_label):
+            self.items_index[item] = i
+
+    def set_user_label(self, user_index, label):                             # base.py:1097-1103
+        del self.users_index[self.users_label[user_index]]
+        self.users_index[label] = user_index
+        self.users_label[user_index] = label
+
+    def set_item_label(self, item_index, label):                             # base.py:1106-1112
+        del self.items_index[self.items_label[item_index]]
+        self.items_index[label] = item_index
+        self.items_label[item_index] = label
+
+    def _get_new_user_id(self):                                              # base.py:1053-1060
+        new_id = len(self.users_label)
+        self.users_label.append("user" + str(new_id))
+        return new_id
+
+    def _get_new_item_id(self):
+        """base.py:1043-1050 takes len(users_label) here -- a slip in a method marked @todo; the item list's
+        own length is what keeps label list and factor columns in step."""
+        new_id = len(self.items_label)
+        self.items_label.append("item" + str(new_id))
+        return new_id
+
+    def set_dimensionality(self, new_dim_value):                             # base.py:289-290
+        self.dimensionality = new_dim_value
 
     def set_ratings(self, ratings_index, ratings):
         """Bulk load of (user, item) -> rating triples: the matrix a loop of set_item_by_id calls over the triples

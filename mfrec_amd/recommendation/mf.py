@@ -89,7 +89,9 @@ class MFRecommender(BaseRecommender):
             from .base import Error
             raise Error("The index and the ratings array must be the same size")
         self._grow(users=1)
-        new_id = self._nbr_users - 1
+        new_id = self._get_new_user_id()               # kmf.py:156-158: default label, then the caller's
+        self.users_index[user_label] = new_id
+        self.users_label[new_id] = user_label
         idx = np.zeros([vals.shape[0], 2], dtype=np.int32)
         idx[:, 0] = new_id
         idx[:, 1] = items
@@ -104,7 +106,9 @@ class MFRecommender(BaseRecommender):
             from .base import Error
             raise Error("The index and the ratings array must be the same size")
         self._grow(items=1)
-        new_id = self._nbr_items - 1
+        new_id = self._get_new_item_id()
+        self.items_index[item_label] = new_id
+        self.items_label[new_id] = item_label
         idx = np.zeros([vals.shape[0], 2], dtype=np.int32)
         idx[:, 0] = users
         idx[:, 1] = new_id

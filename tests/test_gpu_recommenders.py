@@ -135,6 +135,7 @@ def test_folding_in_and_top_n():
     items = np.array([3, 10, 20, 33], dtype=np.int32)
     new = R.add_user("someone", items, np.array([5.0, 4.0, 1.0, 2.0]))
     assert new == nu and R.svd_v.shape == (k, nu + 1) and R.nbr_users == nu + 1
+    assert R.users_index["someone"] == nu and R.users_label[nu] == "someone"     # kmf.py:156-158
     assert np.array_equal(R.svd_u, u_before)                       # items untouched (gate 0)
     assert np.array_equal(R.svd_v[:, :nu], v_before)               # other users untouched
     assert np.any(R.svd_v[:, nu] != 0.0)
@@ -156,8 +157,8 @@ def test_folding_in_and_top_n():
     want = {i: R.predict_linear(i, user) for i in range(60) if i not in rated}
     ranked = sorted(want.items(), key=lambda kv: (-kv[1], kv[0]))[:8]
     assert got_items == [i for i, _ in ranked] and np.allclose(got_scores, [x for _, x in ranked], rtol=1e-12)
-    R.items_label = {i: "item-%d" % i for i in range(R.nbr_items)}
-    R.users_index = {"u7": user}
+    R.items_label = ["item-%d" % i for i in range(R.nbr_items)]
+    R.set_user_label(user, "u7")
     lab, _ = R.find_recommended_items(user_label="u7", nbr_recommendations=3, output_label=True, predictor="predict_linear")
     assert lab == ["item-%d" % i for i in got_items[:3]]
     new_item = R.add_item("thing", np.array([1, 2, 3], dtype=np.int32), np.array([4.0, 4.0, 5.0]))

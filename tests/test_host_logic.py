@@ -94,8 +94,10 @@ def test_save_state_load_state_file_set(tmp_path):
     R = BaseRecommender(5, 7)
     R.set_ratings(np.array([[0, 1], [4, 6], [2, 2]]), [3.0, 5.0, 1.0])
     R.svd_u, R.svd_v = np.arange(14.0).reshape(2, 7), np.arange(10.0).reshape(2, 5)
-    R.users_label, R.users_index = {0: "ann", 4: "bob"}, {"ann": 0, "bob": 4}
-    R.items_label, R.items_index, R.items_index_map = {1: "x"}, {"x": 1}, {1: 1}
+    assert R.users_label == ["user%d" % i for i in range(5)] and R.items_index["item6"] == 6   # base.py:275-281
+    R.set_user_label(0, "ann"); R.set_user_label(4, "bob"); R.set_item_label(1, "x")
+    assert R.users_index["bob"] == 4 and "user4" not in R.users_index and R.items_label[1] == "x"
+    R.items_index_map = {1: 1}
     base = str(tmp_path / "state")
     R.save_state(base)
     for suffix in ("_relations.mtx", "_svd.npz", "_userslabel.dat", "_usersindex.dat", "_itemslabel.dat",
@@ -118,12 +120,12 @@ def test_save_state_load_state_file_set(tmp_path):
     # a file set as the REFERENCE writes it: text-mode protocol-0 pickles, svd_s a real array
     scipy.io.mmwrite(base + "2_relations.mtx", R.relationship_matrix)
     np.savez(base + "2_svd.npz", svd_s=np.array([2.0, 1.0]), svd_u=R.svd_u, svd_v=R.svd_v)
-    for suffix, obj in (("_userslabel.dat", {0: "ann"}), ("_usersindex.dat", {"ann": 0}), ("_itemslabel.dat", {}),
+    for suffix, obj in (("_userslabel.dat", ["ann"]), ("_usersindex.dat", {"ann": 0}), ("_itemslabel.dat", []),
                         ("_itemsindex.dat", {}), ("_itemsindexmap.dat", {})):
         with open(base + "2" + suffix, "w") as f:
             f.write(pickle.dumps(obj, protocol=0).decode("latin1"))
     Q.load_state(base + "2")
-    assert Q.svd_s.tolist() == [2.0, 1.0] and Q.users_label == {0: "ann"}
+    assert Q.svd_s.tolist() == [2.0, 1.0] and Q.users_label == ["ann"]
 
 
 def test_balanced_order_falls_back_when_a_builder_refuses(monkeypatch):
@@ -175,3 +177,24 @@ def test_bulk_set_ratings_equals_the_per_cell_loop():
         BaseRecommender(3, 3).set_ratings(np.array([[3, 0]]), np.array([1.0]))
     with pytest.raises(Error):
         BaseRecommender(3, 3).set_ratings(np.array([[1, 0]]), np.array([1.0, 2.0]))
+
+
+def test_label_based_ingest_follows_the_reference_container():
+    """base.py:815-851,1043-1112: set_item (list of {'label', 'value'} for a user label), set_item_by_label,
+    set_user_label / set_item_label keep list and dict in step, build_index rebuilds the dicts."""
+    from mfrec_amd.recommendation.base import BaseRecommender
+    R = BaseRecommender(3, 4)
+    R.set_user_label(1, "ann")
+    R.set_item_label(2, "book")
+    R.set_item("ann", [{"label": "book", "value": 4}, {"label": "item0", "value": 2}])
+    R.set_item_by_label("user2", "item3", 5)
+    assert R.relationship_matrix.toarray().tolist() == [[0, 0, 0, 0], [2, 0, 4, 0], [0, 0, 0, 5]]
+    with pytest.raises(KeyError):
+        R.set_item_by_label("user1", "item0", 1)              # the old label is gone (base.py:1101)
+    R.users_index, R.items_index = {}, {}
+    R.build_index()
+    assert R.users_index == {"user0": 0, "ann": 1, "user2": 2} and R.items_index["book"] == 2
+    assert R._get_new_user_id() == 3 and R.users_label[3] == "user3"
+    assert R._get_new_item_id() == 4 and R.items_label[4] == "item4"
+    R.set_dimensionality(7)
+    assert R.dimensionality == 7

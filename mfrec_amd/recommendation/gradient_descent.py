@@ -181,6 +181,16 @@ class GDRecommender(MFRecommender):
         whose id equals user_index excluded, zero scores dropped -> (items, scores)."""
         return self._top_items(user_index, self.nbr_items, "predict_rating", nbr_recommendations)
 
+    def predict_rating_implicit(self, item_index, user_index):
+        """gradient_descent.py:651-667: the predictor of the implicit-feedback model -- the user vector plus the
+        normalised sum of the feedback vectors of the items the user rated, dotted with the item vector, + biases."""
+        seek, span = self.feedback_hash[user_index]
+        feedback_norm = 1.0 / np.sqrt(span)
+        items_id = self.feedback_rated[seek:seek + span, 1]
+        p_u = self.svd_v[:, user_index] + feedback_norm * self.items_feedback[:, items_id].sum(axis=1)
+        s = np.dot(self.svd_u[:, item_index], p_u)
+        return s + self.overall_bias + (self.items_bias[item_index] + self.users_bias[user_index])
+
     def _retrain(self, sel, ratings_index, ratings, update_users, update_items, verbose):
         if self.items_bias is None or self.users_bias is None:
             self.compute_overall_avg(); self.compute_items_bias_bk(); self.compute_users_bias_bk()

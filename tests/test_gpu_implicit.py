@@ -80,6 +80,12 @@ def test_recommender_level_and_errors():
     O.estimator_loop_with_implicit_feedback(2, 2, 1e9, k, 0.1, 0.001, 0.001, 0.001, 0.05, R.overall_bias, u, v, y, i2, r2,
                                             rated, h, R.items_bias, R.users_bias, nu, ni)
     assert np.array_equal(R.svd_u, u) and np.array_equal(R.svd_v, v) and np.array_equal(R.items_feedback, y)
+    # the paired predictor (gradient_descent.py:651-667), restated term by term
+    user, item = int(i2[0, 0]), 7
+    items_of_user = rated[h[user, 0]:h[user, 0] + h[user, 1], 1]
+    p_u = R.svd_v[:, user] + (1.0 / np.sqrt(h[user, 1])) * R.items_feedback[:, items_of_user].sum(axis=1)
+    want = np.dot(R.svd_u[:, item], p_u) + R.overall_bias + (R.items_bias[item] + R.users_bias[user])
+    assert R.predict_rating_implicit(item, user) == want
     bad = h.copy(); bad[int(i2[0, 0])] = [5, 10 ** 6]
     with pytest.raises(ValueError, match="does not index"):
         G.estimator_loop_with_implicit_feedback(1, 1, 1e9, k, 0.1, 0.001, 0, 0, 0.05, 3.0, u, v, y, i2, r2, rated, bad,

@@ -43,15 +43,55 @@ def rmse_on(recommender, ratings_index, ratings, predictor="predict"):
 
 def test_predict_rating(recommender, u_test, nbr_samples=10, verbose=False,
                         predictor="predict_rating"):
-    """metrics.py:51-82: u_test rows are (user, item, rating); returns (rmse, errors)."""
+    """metrics.py:51-82: u_test rows are (user, item, rating); returns (rmse, errors) over the first
+    nbr_samples rows, NaN errors left out (metrics.py:69-73).  The predictions are one batched GPU pass."""
     t = np.asarray(u_test)[:nbr_samples]
     idx = t[:, :2].astype(np.int32)
     real = t[:, 2].astype(np.float64)
-    pred, rmse = predict_batch(recommender, idx, predictor, real)
-    errors = real - pred
+    pred, _ = predict_batch(recommender, idx, predictor, real)
+    all_errors = real - pred
+    errors = all_errors[~np.isnan(all_errors)]
+    abs_errors = np.abs(errors)
+    rmse = np.sqrt(np.power(abs_errors, 2).mean())
     if verbose:
+        print("\nNumber of succesful rating: %d/%d" % (len(abs_errors), nbr_samples))
+        print("Mean abs. error: " + str(abs_errors.mean()))
+        print("Variance of the error: " + str(abs_errors.var()))
         print("Mean root mean square error (RMSE): " + str(rmse))
+        print("NMAE: " + str(abs_errors.mean() / 1.6))
+        print("MAE: " + str(abs_errors.mean()) + "\n\n")
     return rmse, errors
+
+
+def precision_recall(recommender, u_test, nbr_recommendations=5, predictor="predict", verbose=False):
+    """metrics.py:85-130: precision / recall / F-measure of find_recommended_items against the test pairs
+    (u_test rows: user, item, ...), user by user; a user whose lookup raises KeyError recommends nothing and
+    is not counted."""
+    precision = recall = 0.0
+    test_sample_dict = {}
+    for rating in u_test:
+        test_sample_dict.setdefault(int(rating[0]), []).append(int(rating[1]))
+    users_count = 0
+    for user_index in test_sample_dict.keys():
+        try:
+            recommended_set = set(recommender.find_recommended_items(
+                user_index=user_index, nbr_recommendations=nbr_recommendations, output_label=False,
+                predictor=predictor)[0])
+            users_count += 1
+        except KeyError:
+            recommended_set = set()
+        already_rated = set(test_sample_dict[user_index])
+        intersection = float(len(recommended_set.intersection(already_rated)))
+        precision += intersection / nbr_recommendations
+        recall += intersection / len(already_rated)
+    precision = precision / users_count
+    recall = recall / users_count
+    f_measure = 2 * (precision * recall) / (precision + recall)
+    if verbose:
+        print("Precision @ " + str(nbr_recommendations) + " : " + str(precision))
+        print("Recall @ " + str(nbr_recommendations) + " : " + str(recall))
+        print("F-Measure : " + str(f_measure))
+    return precision, recall, f_measure
 
 
 test_predict_rating.__test__ = False          # not a pytest test, despite the reference's name

@@ -310,3 +310,39 @@ def test_gd_secondary_trainers_match_oracle():
         R.feature_training_folding(handle_bias=True)          # the reference's call is two arguments short
     assert R.estimate_rating(3, 2, 1, trailing=True) == R.clamping(
         R.clamping(1.0 + R.svd_u[1, 3] * R.svd_v[1, 2]) + (k - 2) * 0.1 * 0.1)
+
+
+def test_metrics_module_follows_the_reference():
+    """metrics.py:51-82 (rmse, errors over the first nbr_samples rows, NaN errors dropped) and :85-130
+    (precision / recall / F over find_recommended_items), restated as the loops the reference runs."""
+    from mfrec_amd.recommendation import KMFRecommender, metrics
+    nu, ni, k = 90, 70, 6
+    R = _fill(KMFRecommender(nu, ni, {"nbr_epochs": 4, "nbr_features": k}), nu, ni, 2500, 8)
+    np.random.seed(3)
+    R.train(kernel="train_linear_kernel")
+    tidx, tr = synth.make_ratings(nu, ni, 400, seed=77)
+    u_test = np.column_stack([tidx, tr])
+    rmse, errors = metrics.test_predict_rating(R, u_test, nbr_samples=300, predictor="predict_linear")
+    want = np.array([row[2] - R.predict_linear(int(row[1]), int(row[0])) for row in u_test[:300]])
+    assert errors.shape == (300,) and np.allclose(errors, want, rtol=1e-12, atol=1e-13)
+    assert abs(rmse - np.sqrt((want ** 2).mean())) < 1e-12
+    R.svd_v[:, 5] = np.nan                                    # a user without a model: its rows drop out
+    rmse2, errors2 = metrics.test_predict_rating(R, u_test, nbr_samples=300, predictor="predict_linear")
+    assert errors2.shape[0] == 300 - int((u_test[:300, 0] == 5).sum()) and np.isfinite(rmse2)
+    R.svd_v[:, 5] = 0.0
+
+    R.neighborhood = ni
+    np.random.seed(1)
+    p, r, f = metrics.precision_recall(R, u_test, nbr_recommendations=5, predictor="predict_linear")
+    np.random.seed(1)
+    by_user = {}
+    for row in u_test:
+        by_user.setdefault(int(row[0]), []).append(int(row[1]))
+    P = Rc = 0.0
+    for user, items in by_user.items():
+        rec = set(R.find_recommended_items(user_index=user, nbr_recommendations=5, predictor="predict_linear")[0])
+        hit = float(len(rec & set(items)))
+        P += hit / 5
+        Rc += hit / len(set(items))
+    P, Rc = P / len(by_user), Rc / len(by_user)
+    assert (p, r) == (P, Rc) and f == 2 * P * Rc / (P + Rc)

@@ -182,6 +182,18 @@ int mfx_predict_rmse(int kind, int dim, const double *u, const double *v,
                      const double *users_bias, double overall_avg, int64_t nnz, int nu, int ni,
                      double *pred_out, double *rmse_out);
 
+/* Batched top-N: the ranking of find_recommended_items (mf.py:144-193) / find_user_top_match
+ * (gradient_descent.py:768-800) for n_sel users in one call.  Candidates are items 0 .. n_cand-1; a user's rated
+ * items (CSR: rated_off int64[n_sel+1], rated_items int32[]; both NULL = none), the item whose id equals the
+ * user id, NaN and zero scores are excluded exactly as the reference excludes them; order: descending score, ties by
+ * ascending item.  kind as in mfx_predict_rmse.  u [k, ni]; v_sel [k, n_sel] = the selected users' columns of v;
+ * ub_sel [n_sel]; users [n_sel] = their ids.  out_items int32[n_sel, N] (-1 where fewer than N qualify),
+ * out_scores f64[n_sel, N].  The dot product is summed as mfx_predict_rmse sums it: same bits. */
+int mfx_topn_batch(int kind, int dim, const double *u, const double *v_sel, const double *items_bias,
+                   const double *users_bias_sel, double overall_avg, int ni, const int32_t *users, int n_sel,
+                   int n_cand, int N, const int64_t *rated_off, const int32_t *rated_items, int32_t *out_items,
+                   double *out_scores);
+
 /* ------------------------------------------------ resident (plan) API
  * Same kernels, but ratings, schedule and factors stay in HBM between calls:
  * create (schedule + upload) -> set_factors -> run_* ... -> get_factors.

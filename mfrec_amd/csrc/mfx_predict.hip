@@ -1,6 +1,9 @@
 // Batched predict + RMSE over rating triples: the step right after train()
 // (mfrec/recommendation/metrics.py:51-82 calling the family's predict()).
 #include <math.h>
+#include <string.h>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
 #include <vector>
 #include "mfx_common.h"
 
@@ -93,5 +96,184 @@ extern "C" int mfx_predict_rmse(int kind, int dim, const double *u, const double
     double tot = 0.0;
     for (double x : se) tot += x;
     if (rmse_out) *rmse_out = sqrt(tot / (double)nnz);
+    return MFX_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Batched top-N (the ranking of mf.py:144-193 / gradient_descent.py:768-800 for MANY users at once):
+// scores of items 0 .. n_cand-1 for every user of the batch, the reference's exclusions (the user's rated
+// items, the item whose id equals the user id, NaN -> 0, zero scores dropped), descending score with ties
+// by ascending item.  The dot product is summed feature by feature exactly as k_predict does, so a batch
+// row carries the same bits as the single-user query.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kUB = 8;          // users per thread in k_scores: one load of U[f, item] feeds eight sums
+
+// vs: [k][n_sel] feature-major columns of the selected users; sub: [n_sel] their biases (nullable)
+__global__ __launch_bounds__(256) void k_scores(int kind, int k, const double *__restrict__ u, const double *__restrict__ vs,
+                                                const double *__restrict__ ib, const double *__restrict__ sub, double mu,
+                                                const int32_t *__restrict__ users, int n_sel, int j_base, int n_chunk,
+                                                int ni, int n_cand, double *scores, int32_t *items)
+{
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    const int j0 = j_base + blockIdx.y * kUB;                 // first user (position in the batch) of this thread
+    if (item >= n_cand) return;
+    double acc[kUB];
+#pragma unroll
+    for (int q = 0; q < kUB; ++q) acc[q] = 0.0;
+    for (int f = 0; f < k; ++f) {
+        const double uf = u[(size_t)f * ni + item];
+#pragma unroll
+        for (int q = 0; q < kUB; ++q) {
+            const int j = j0 + q < n_sel ? j0 + q : n_sel - 1;
+            acc[q] += uf * vs[(size_t)f * n_sel + j];
+        }
+    }
+    const double bi = ib ? ib[item] : 0.0;
+#pragma unroll
+    for (int q = 0; q < kUB; ++q) {
+        const int j = j0 + q;
+        if (j >= j_base + n_chunk || j >= n_sel) break;
+        const double bu = sub ? sub[j] : 0.0;
+        double p;
+        switch (kind) {
+        case 0: p = acc[q] + 1.0; break;
+        case 1: p = acc[q] + (bi + bu); break;
+        case 2: p = 1.0 + (1.0 / (1.0 + exp(-(acc[q] + (bi + bu))))) * 4.0; break;
+        case 3: p = acc[q] + mu + (bi + bu); break;
+        default: p = acc[q]; break;
+        }
+        if (p != p || item == users[j]) p = 0.0;              // NaN -> 0 (mf.py:176); the item named like the user (mf.py:162)
+        const size_t o = (size_t)(j - j_base) * n_cand + item;
+        scores[o] = p;
+        items[o] = item;
+    }
+}
+
+// rated items of the chunk's users score 0 (mf.py:161,171-173)
+__global__ __launch_bounds__(256) void k_clear_rated(const int64_t *__restrict__ off, const int32_t *__restrict__ rated,
+                                                     int j_base, int n_chunk, int n_cand, double *scores)
+{
+    const int j = j_base + blockIdx.y;
+    for (int64_t p = off[j] + blockIdx.x * 256 + threadIdx.x; p < off[j + 1]; p += (int64_t)gridDim.x * 256) {
+        const int it = rated[p];
+        if (it >= 0 && it < n_cand) scores[(size_t)(j - j_base) * n_cand + it] = 0.0;
+    }
+}
+
+__global__ void k_iota_offsets(unsigned int *off, int n, unsigned int stride)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i <= n) off[i] = (unsigned int)i * stride;
+}
+
+// a sorted (descending) segment is  positives | zeros | negatives ; the zeros are dropped (mf.py:178-182)
+__global__ __launch_bounds__(64) void k_take_top(const double *__restrict__ keys, const int32_t *__restrict__ vals, int n_cand,
+                                                 int N, int j_base, int32_t *out_items, double *out_scores)
+{
+    const int jl = blockIdx.x;
+    const double *kk = keys + (size_t)jl * n_cand;
+    const int32_t *vv = vals + (size_t)jl * n_cand;
+    __shared__ int sP, sE;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = n_cand;                                 // first index with key <= 0
+        while (lo < hi) { const int m = (lo + hi) / 2; if (kk[m] > 0.0) lo = m + 1; else hi = m; }
+        sP = lo;
+        hi = n_cand;                                             // first index with key < 0
+        while (lo < hi) { const int m = (lo + hi) / 2; if (kk[m] >= 0.0) lo = m + 1; else hi = m; }
+        sE = lo;
+    }
+    __syncthreads();
+    const int P = sP, Z = sE - sP;
+    for (int t = threadIdx.x; t < N; t += 64) {
+        const int src = t < P ? t : t + Z;
+        const size_t o = (size_t)(j_base + jl) * N + t;
+        if (src < n_cand) { out_items[o] = vv[src]; out_scores[o] = kk[src]; }
+        else { out_items[o] = -1; out_scores[o] = 0.0; }
+    }
+}
+
+struct DevBufs {
+    std::vector<void *> p;
+    ~DevBufs() { for (void *x : p) if (x) (void)hipFree(x); }
+    template <typename T> hipError_t get(T **out, size_t n)
+    {
+        void *q = nullptr;
+        hipError_t e = hipMalloc(&q, (n ? n : 1) * sizeof(T));
+        if (e == hipSuccess) { p.push_back(q); *out = (T *)q; }
+        return e;
+    }
+};
+
+}  // namespace
+
+extern "C" int mfx_topn_batch(int kind, int dim, const double *u, const double *v_sel, const double *ib,
+                              const double *ub_sel, double mu, int ni, const int32_t *users, int n_sel, int n_cand,
+                              int N, const int64_t *rated_off, const int32_t *rated_items, int32_t *out_items,
+                              double *out_scores)
+{
+    if (!u || !v_sel || !users || !out_items || !out_scores || dim < 1 || ni <= 0 || n_sel < 0 || n_cand < 1 ||
+        n_cand > ni || N < 1 || kind < 0 || kind > 4 || ((kind >= 1 && kind <= 3) && (!ib || !ub_sel)) ||
+        (rated_off && !rated_items && n_sel > 0 && rated_off[n_sel] > 0))
+        return mfx::fail(MFX_E_ARG, "mfx_topn_batch: bad argument");
+    int rc = mfx::ensure_init();
+    if (rc) return rc;
+    if (n_sel == 0) return MFX_OK;
+    if (rated_off) {
+        if (rated_off[0] != 0) return mfx::fail(MFX_E_ARG, "mfx_topn_batch: rated_off[0] must be 0");
+        for (int j = 0; j < n_sel; ++j)
+            if (rated_off[j + 1] < rated_off[j]) return mfx::fail(MFX_E_ARG, "mfx_topn_batch: rated_off must ascend");
+    }
+    hipStream_t st = mfx::stream();
+    DevBufs B;
+#define TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (void)hipGetLastError(); \
+        return mfx::fail(e_ == hipErrorOutOfMemory ? MFX_E_NOMEM : MFX_E_HIP, "mfx_topn_batch: %s -> %s", #call, hipGetErrorString(e_)); } } while (0)
+    // users per chunk: the score matrix and its sorted copy stay below ~2 GB
+    int chunk = (int)(((size_t)1 << 27) / (size_t)n_cand);
+    if (chunk < 1) chunk = 1;
+    if (chunk > n_sel) chunk = n_sel;
+    chunk = (chunk + kUB - 1) / kUB * kUB;
+    const size_t cells = (size_t)chunk * n_cand;
+    if (cells >= ((size_t)1 << 32)) return mfx::fail(MFX_E_ARG, "mfx_topn_batch: n_cand too large");
+    double *du, *dv, *dib = nullptr, *dub = nullptr, *k_in, *k_out, *d_scores;
+    int32_t *d_users, *v_in, *v_out, *d_rated = nullptr, *d_items;
+    int64_t *d_off = nullptr;
+    unsigned int *d_seg;
+    TRY(B.get(&du, (size_t)dim * ni)); TRY(B.get(&dv, (size_t)dim * n_sel)); TRY(B.get(&d_users, (size_t)n_sel));
+    TRY(B.get(&k_in, cells)); TRY(B.get(&k_out, cells)); TRY(B.get(&v_in, cells)); TRY(B.get(&v_out, cells));
+    TRY(B.get(&d_seg, (size_t)chunk + 1)); TRY(B.get(&d_items, (size_t)n_sel * N)); TRY(B.get(&d_scores, (size_t)n_sel * N));
+    TRY(hipMemcpyAsync(du, u, (size_t)dim * ni * 8, hipMemcpyHostToDevice, st));
+    TRY(hipMemcpyAsync(dv, v_sel, (size_t)dim * n_sel * 8, hipMemcpyHostToDevice, st));
+    TRY(hipMemcpyAsync(d_users, users, (size_t)n_sel * 4, hipMemcpyHostToDevice, st));
+    if (ib) { TRY(B.get(&dib, (size_t)ni)); TRY(hipMemcpyAsync(dib, ib, (size_t)ni * 8, hipMemcpyHostToDevice, st)); }
+    if (ub_sel) { TRY(B.get(&dub, (size_t)n_sel)); TRY(hipMemcpyAsync(dub, ub_sel, (size_t)n_sel * 8, hipMemcpyHostToDevice, st)); }
+    const int64_t n_rated = rated_off ? rated_off[n_sel] : 0;
+    if (n_rated > 0) {
+        TRY(B.get(&d_off, (size_t)n_sel + 1)); TRY(B.get(&d_rated, (size_t)n_rated));
+        TRY(hipMemcpyAsync(d_off, rated_off, ((size_t)n_sel + 1) * 8, hipMemcpyHostToDevice, st));
+        TRY(hipMemcpyAsync(d_rated, rated_items, (size_t)n_rated * 4, hipMemcpyHostToDevice, st));
+    }
+    k_iota_offsets<<<(chunk + 256) / 256, 256, 0, st>>>(d_seg, chunk, (unsigned int)n_cand);
+    size_t tmp_bytes = 0;
+    TRY(rocprim::segmented_radix_sort_pairs_desc(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, (unsigned int)cells,
+                                                 (unsigned int)chunk, d_seg, d_seg + 1, 0u, 64u, st));
+    char *tmp;
+    TRY(B.get(&tmp, tmp_bytes));
+    for (int jb = 0; jb < n_sel; jb += chunk) {
+        const int nc = n_sel - jb < chunk ? n_sel - jb : chunk;
+        k_scores<<<dim3((n_cand + 255) / 256, (nc + kUB - 1) / kUB), 256, 0, st>>>(kind, dim, du, dv, dib, dub, mu, d_users,
+                                                                                   n_sel, jb, nc, ni, n_cand, k_in, v_in);
+        if (n_rated > 0) k_clear_rated<<<dim3(4, nc), 256, 0, st>>>(d_off, d_rated, jb, nc, n_cand, k_in);
+        TRY(rocprim::segmented_radix_sort_pairs_desc(tmp, tmp_bytes, k_in, k_out, v_in, v_out, (unsigned int)((size_t)nc * n_cand),
+                                                     (unsigned int)nc, d_seg, d_seg + 1, 0u, 64u, st));
+        k_take_top<<<nc, 64, 0, st>>>(k_out, v_out, n_cand, N, jb, d_items, d_scores);
+    }
+    TRY(hipGetLastError());
+    TRY(hipMemcpyAsync(out_items, d_items, (size_t)n_sel * N * 4, hipMemcpyDeviceToHost, st));
+    TRY(hipMemcpyAsync(out_scores, d_scores, (size_t)n_sel * N * 8, hipMemcpyDeviceToHost, st));
+    TRY(hipStreamSynchronize(st));
+#undef TRY
     return MFX_OK;
 }

@@ -102,8 +102,8 @@ WIDE_STORES = ("global_store_dwordx4", "global_store_dwordx3", "buffer_store_dwo
 
 
 def scan_asm_stores(lines):
-    """-> (asm stores of more than 8 bytes, those NOT followed by an `s_nop N` with N >= 1 inside their asm
-    block).  gfx940+/gfx950 need 2 wait states between such a store and a VALU write of its data VGPRs;
+    """-> (asm stores of more than 8 bytes, those NOT followed by an `s_nop N` with N >= 1 -- or a full
+    `s_waitcnt vmcnt(0)` -- inside their asm block).  gfx940+/gfx950 need 2 wait states between such a store and a VALU write of its data VGPRs;
     `s_nop 0` is one."""
     n = bad = 0
     in_asm = False
@@ -126,6 +126,8 @@ def scan_asm_stores(lines):
                 arg = t.split()[1] if len(t.split()) > 1 else "0"
                 if arg.isdigit() and int(arg) >= 1:
                     pending = False
+            elif t.startswith("s_waitcnt") and "vmcnt(0)" in t:
+                pending = False          # the store has completed (rocprim's look-back scan stores do this)
     return n, bad
 
 

@@ -17,8 +17,9 @@ def _kind(recommender, predictor):
     return _KIND[predictor]
 
 
-def predict_batch(recommender, ratings_index, predictor="predict", ratings=None):
-    """-> (predictions f64[n], rmse or None)."""
+def predict_batch(recommender, ratings_index, predictor="predict", ratings=None, one_user=None):
+    """-> (predictions f64[n], rmse or None).  one_user: every row of ratings_index is about this user --
+    only its column of svd_v (and its bias) is sent to the device, as user 0."""
     kind = _kind(recommender, predictor)
     idx = np.ascontiguousarray(ratings_index, dtype=np.int32)
     n = idx.shape[0]
@@ -28,6 +29,11 @@ def predict_batch(recommender, ratings_index, predictor="predict", ratings=None)
     u, v = recommender.svd_u, recommender.svd_v
     ib = recommender.items_bias if kind in (1, 2, 3) else None
     ub = recommender.users_bias if kind in (1, 2, 3) else None
+    if one_user is not None:
+        v = np.ascontiguousarray(v[:, one_user:one_user + 1])
+        ub = None if ub is None else np.ascontiguousarray(ub[one_user:one_user + 1])
+        idx = idx.copy()
+        idx[:, 0] = 0
     mu = float(recommender.overall_bias or 0.0)
     S.check(S.lib().mfx_predict_rmse(kind, u.shape[0], S.f64(u, "svd_u", 2), S.f64(v, "svd_v", 2),
                                      S.i32(idx, "ratings_index", 2), S.f64(r, "ratings", 1),
@@ -35,6 +41,40 @@ def predict_batch(recommender, ratings_index, predictor="predict", ratings=None)
                                      S.f64(ub, "users_bias", 1, allow_none=True), mu, n,
                                      v.shape[1], u.shape[1], S.f64(pred, "pred", 1), C.byref(out)))
     return pred, (None if ratings is None else out.value)
+
+
+def topn_batch(recommender, users, n_candidates, nbr_recommendations, predictor="predict"):
+    """Top-N for many users in one device call (mfx_topn_batch): -> (items int32[n, N] with -1 where fewer than N
+    items qualify, scores f64[n, N]).  Same candidates, exclusions and order as find_recommended_items."""
+    kind = _kind(recommender, predictor)
+    users = np.ascontiguousarray(users, dtype=np.int32)
+    n = users.shape[0]
+    if n and (users.min() < 0 or users.max() >= recommender.svd_v.shape[1]):
+        raise IndexError("user outside the model")
+    u = recommender.svd_u
+    v_sel = np.ascontiguousarray(recommender.svd_v[:, users])
+    ib = recommender.items_bias if kind in (1, 2, 3) else None
+    ub = np.ascontiguousarray(recommender.users_bias[users]) if kind in (1, 2, 3) else None
+    mu = float(recommender.overall_bias or 0.0)
+    rel = recommender.relationship_matrix.tocsr()
+    rel.eliminate_zeros()
+    in_matrix = users < rel.shape[0]                       # folded-in users have no row in the ratings matrix
+    counts = np.zeros(n, dtype=np.int64)
+    counts[in_matrix] = np.diff(rel.indptr)[users[in_matrix]]
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    rated = np.zeros(max(int(off[-1]), 1), dtype=np.int32)
+    for j in np.nonzero(in_matrix)[0]:
+        a = rel.indptr[users[j]]
+        rated[off[j]:off[j + 1]] = rel.indices[a:a + counts[j]]
+    items = np.full((n, nbr_recommendations), -1, dtype=np.int32)
+    scores = np.zeros((n, nbr_recommendations))
+    S.check(S.lib().mfx_topn_batch(kind, u.shape[0], S.f64(u, "svd_u", 2), S.f64(v_sel, "v_sel", 2),
+                                   S.f64(ib, "items_bias", 1, allow_none=True),
+                                   S.f64(ub, "users_bias", 1, allow_none=True), mu, u.shape[1],
+                                   S.i32(users, "users", 1), n, int(n_candidates), int(nbr_recommendations),
+                                   off.ctypes.data_as(S._lp), S.i32(rated, "rated", 1),
+                                   S.i32(items, "items", 2), S.f64(scores, "scores", 2)))
+    return items, scores
 
 
 def rmse_on(recommender, ratings_index, ratings, predictor="predict"):
@@ -63,7 +103,7 @@ def test_predict_rating(recommender, u_test, nbr_samples=10, verbose=False,
     return rmse, errors
 
 
-def precision_recall(recommender, u_test, nbr_recommendations=5, predictor="predict", verbose=False):
+def precision_recall(recommender, u_test, nbr_recommendations=5, predictor="predict", verbose=False, batched=False):
     """metrics.py:85-130: precision / recall / F-measure of find_recommended_items against the test pairs
     (u_test rows: user, item, ...), user by user; a user whose lookup raises KeyError recommends nothing and
     is not counted."""
@@ -72,11 +112,20 @@ def precision_recall(recommender, u_test, nbr_recommendations=5, predictor="pred
     for rating in u_test:
         test_sample_dict.setdefault(int(rating[0]), []).append(int(rating[1]))
     users_count = 0
+    if batched:
+        # extension: every user's ranking in one device call (same rankings; the per-user RNG draws of
+        # find_recommended_items, which do not influence its result, are not made)
+        keys = list(test_sample_dict.keys())
+        top, _ = recommender.find_recommended_items_batch(keys, nbr_recommendations, predictor)
+        ranked = {k: set(int(i) for i in row if i >= 0) for k, row in zip(keys, top)}
     for user_index in test_sample_dict.keys():
         try:
-            recommended_set = set(recommender.find_recommended_items(
-                user_index=user_index, nbr_recommendations=nbr_recommendations, output_label=False,
-                predictor=predictor)[0])
+            if batched:
+                recommended_set = ranked[user_index]
+            else:
+                recommended_set = set(recommender.find_recommended_items(
+                    user_index=user_index, nbr_recommendations=nbr_recommendations, output_label=False,
+                    predictor=predictor)[0])
             users_count += 1
         except KeyError:
             recommended_set = set()

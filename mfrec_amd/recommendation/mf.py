@@ -131,6 +131,15 @@ class MFRecommender(BaseRecommender):
         top, scores = self._top_items(user_index, n, predictor, nbr_recommendations)
         return ([self.items_label[i] for i in top] if output_label else top), scores
 
+    def find_recommended_items_batch(self, users, nbr_recommendations=5, predictor="predict"):
+        """Extension: find_recommended_items for MANY users in one device call -> (items int32[n, N], -1 where
+        fewer than N items qualify; scores f64[n, N]).  Row j equals find_recommended_items(users[j]) -- same
+        candidates (items 0 .. neighborhood-1), exclusions, order and score bits; the per-call RNG draw of the
+        single-user method (which does not influence its result) is not made."""
+        from .metrics import topn_batch
+        self.neighborhood = min([self.neighborhood, self.nbr_items])
+        return topn_batch(self, users, int(self.neighborhood), nbr_recommendations, predictor)
+
     def _top_items(self, user_index, n, predictor, nbr_recommendations):
         """Score items 0 .. n-1 for the user in one batched GPU pass and rank them the reference's way
         (mf.py:161-191, gradient_descent.py:774-800)."""
@@ -138,7 +147,7 @@ class MFRecommender(BaseRecommender):
         idx = np.zeros([n, 2], dtype=np.int32)
         idx[:, 0] = user_index
         idx[:, 1] = np.arange(n)
-        user_ratings, _ = predict_batch(self, idx, predictor)
+        user_ratings, _ = predict_batch(self, idx, predictor, one_user=int(user_index))
         rel = self.relationship_matrix
         if user_index < rel.shape[0]:              # a folded-in user has no row in the ratings matrix
             row = rel[user_index, :].tocoo()

@@ -346,3 +346,47 @@ def test_metrics_module_follows_the_reference():
         Rc += hit / len(set(items))
     P, Rc = P / len(by_user), Rc / len(by_user)
     assert (p, r) == (P, Rc) and f == 2 * P * Rc / (P + Rc)
+
+
+def test_batched_top_n_equals_the_single_user_ranking():
+    """find_recommended_items_batch (mfx_topn_batch: score kernel + segmented radix sort + zero-dropping take):
+    row j is find_recommended_items(users[j]) -- items AND score bits -- for every predictor family, including a
+    folded-in user, a user whose id is a candidate item, exact zeros, ties, and N larger than what qualifies."""
+    from mfrec_amd.recommendation import GDRecommender, KMFRecommender, metrics
+    nu, ni, k = 150, 110, 8
+    K = _fill(KMFRecommender(nu, ni, {"nbr_epochs": 3, "nbr_features": k}), nu, ni, 4000, 12)
+    np.random.seed(2)
+    K.train(kernel="train_logistic_kernel")
+    K.add_user("late", np.array([1, 2, 3], dtype=np.int32), np.array([5.0, 1.0, 3.0]))
+    K.svd_u[:, 40] = 0.0; K.items_bias[40] = 0.0                    # ties / exact zeros for the linear predictor
+    K.svd_u[:, 41] = K.svd_u[:, 42]; K.items_bias[41] = K.items_bias[42]
+    K.svd_u[:, 50] = np.nan                                          # NaN scores -> 0 -> dropped
+    users = [0, 7, 149, 150, 33, 109, 110, 5, 5]
+    for pred in ("predict_linear", "predict_logistic"):
+        for n_cand, N in ((ni, 6), (64, 70), (17, 3)):
+            K.neighborhood = n_cand
+            items, scores = K.find_recommended_items_batch(users, N, pred)
+            assert items.shape == (len(users), N) and scores.shape == (len(users), N)
+            for j, user in enumerate(users):
+                K.neighborhood = n_cand
+                want_i, want_s = K.find_recommended_items(user_index=user, nbr_recommendations=N, predictor=pred)
+                got = [int(x) for x in items[j] if x >= 0]
+                assert got == want_i, (pred, n_cand, N, user)
+                assert np.array_equal(scores[j, :len(want_s)], np.array(want_s))
+                assert np.all(items[j, len(want_i):] == -1)
+    G = _fill(GDRecommender(nu, ni, {"min_epochs": 2, "max_epochs": 2, "nbr_features": 5}), nu, ni, 3000, 13)
+    np.random.seed(3)
+    G.train()
+    G.neighborhood = ni
+    items, scores = G.find_recommended_items_batch(list(range(0, nu, 7)), 5)
+    for j, user in enumerate(range(0, nu, 7)):
+        want_i, want_s = G.find_user_top_match(user, 5)
+        assert list(items[j]) == want_i and np.array_equal(scores[j], np.array(want_s))
+    # the batched precision / recall is the per-user loop's
+    tidx, tr = synth.make_ratings(nu, ni, 300, seed=5)
+    u_test = np.column_stack([tidx, tr])
+    a = metrics.precision_recall(G, u_test, 5, "predict_rating")
+    b = metrics.precision_recall(G, u_test, 5, "predict_rating", batched=True)
+    assert a == b
+    with pytest.raises(IndexError):
+        G.find_recommended_items_batch([nu], 3)

@@ -64,6 +64,8 @@ def test_lint_is_conservative_at_labels_and_rejects_s_nop_0():
     assert L.scan(compiler_dpp, verbose=False) == (1, 0)          # the hazard recogniser's own business
     nop0 = [";;#ASMSTART", "global_store_dwordx4 v[0:1], v[2:5], off sc0 sc1", "s_nop 0", ";;#ASMEND"]
     assert L.scan_asm_stores(nop0) == (1, 1)
+    drained = [";;#ASMSTART", "global_store_dwordx4 v[6:7], v[2:5] off sc1", "s_waitcnt vmcnt(0)", ";;#ASMEND"]
+    assert L.scan_asm_stores(drained) == (1, 0)                   # rocprim's look-back stores: completed, hence safe
 
 
 def test_the_build_lints_what_it_links():

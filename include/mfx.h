@@ -194,6 +194,11 @@ int mfx_topn_batch(int kind, int dim, const double *u, const double *v_sel, cons
                    int n_cand, int N, const int64_t *rated_off, const int32_t *rated_items, int32_t *out_items,
                    double *out_scores);
 
+/* For N <= 16 the ranking is fused into the score pass (no score matrix; a user for which the fused kernel cannot
+ * prove its list complete is redone by the sort path).  stats[0] / stats[1]: users answered by the fused kernel /
+ * redone, totals of this process.  MFX_TOPN_FUSED=0 forces the sort path. */
+int mfx_topn_stats(int64_t stats[2]);
+
 /* ------------------------------------------------ resident (plan) API
  * Same kernels, but ratings, schedule and factors stay in HBM between calls:
  * create (schedule + upload) -> set_factors -> run_* ... -> get_factors.

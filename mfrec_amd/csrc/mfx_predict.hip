@@ -1,6 +1,7 @@
 // Batched predict + RMSE over rating triples: the step right after train()
 // (mfrec/recommendation/metrics.py:51-82 calling the family's predict()).
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <cstring>
 #include <rocprim/rocprim.hpp>
@@ -195,6 +196,154 @@ __global__ __launch_bounds__(64) void k_take_top(const double *__restrict__ keys
     }
 }
 
+
+// ---- fused top-N for N <= kTopMaxN: the scores are never written out ------------------------------------------
+// A workgroup owns kUB users and streams all candidates; every thread keeps, per user, the kTM best of the items
+// it visits (score descending, item ascending: a thread visits its items in ascending order, so a later equal
+// score never displaces an earlier one) and the best score it ever DROPPED.  The 256 x kTM kept entries are
+// merged by N rounds of a workgroup-wide arg-max.  The result is exact whenever no thread dropped anything that
+// could belong to the list -- every thread's best dropped score is strictly below the N-th score taken (or
+// nothing valid was dropped when fewer than N qualify); otherwise the user is flagged and redone by the sort
+// path (a thread would have to visit more than kTM of the top N: ~1e-4 of the users at N = 16, 50 K items).
+// Tried: one WAVE per 8 users with the four waves of a workgroup walking U together (L1 reuse) -- 351 vs 151 ms for
+// 100 K users x 50 K items: four times the visits per lane and 196 VGPRs cost more than the shared reads save..
+// The reference's exclusions are applied before an entry is kept or counted as dropped; the rated-item test is a
+// binary search in the user's ascending list and only runs for the few entries that reach that point.
+constexpr int kTM = 3;
+constexpr int kTopMaxN = 16;
+
+__device__ __forceinline__ bool is_rated(const int64_t *off, const int32_t *rated, int j, int item)
+{
+    if (!off) return false;
+    int64_t lo = off[j], hi = off[j + 1];
+    while (lo < hi) {
+        const int64_t m = (lo + hi) >> 1;
+        const int x = rated[m];
+        if (x == item) return true;
+        if (x < item) lo = m + 1; else hi = m;
+    }
+    return false;
+}
+
+// (s, it) ranks before (s2, it2)?
+__device__ __forceinline__ bool ranks_before(double s, int it, double s2, int it2)
+{
+    return s > s2 || (s == s2 && it < it2);
+}
+
+__global__ __launch_bounds__(256) void k_topn_fused(int kind, int k, const double *__restrict__ u,
+                                                    const double *__restrict__ vs, const double *__restrict__ ib,
+                                                    const double *__restrict__ sub, double mu,
+                                                    const int32_t *__restrict__ users, int n_sel, int ni, int n_cand,
+                                                    int N, const int64_t *__restrict__ off,
+                                                    const int32_t *__restrict__ rated, int force_unsafe,
+                                                    int32_t *out_items, double *out_scores, int32_t *unsafe)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int j0 = blockIdx.x * kUB;
+    double ks[kUB][kTM];
+    int ki[kUB][kTM];
+    double dropped[kUB];
+#pragma unroll
+    for (int q = 0; q < kUB; ++q) {
+        dropped[q] = -INFINITY;
+#pragma unroll
+        for (int m = 0; m < kTM; ++m) { ks[q][m] = -INFINITY; ki[q][m] = 0x7fffffff; }
+    }
+    for (int item = tid; item < n_cand; item += 256) {
+        double acc[kUB];
+#pragma unroll
+        for (int q = 0; q < kUB; ++q) acc[q] = 0.0;
+#pragma unroll 8                                                            // eight column loads in flight
+        for (int f = 0; f < k; ++f) {
+            const double uf = u[(size_t)f * ni + item];
+#pragma unroll
+            for (int q = 0; q < kUB; ++q) {
+                const int j = j0 + q < n_sel ? j0 + q : n_sel - 1;
+                acc[q] += uf * vs[(size_t)f * n_sel + j];
+            }
+        }
+        const double bi = ib ? ib[item] : 0.0;
+#pragma unroll
+        for (int q = 0; q < kUB; ++q) {
+            const int j = j0 + q;
+            if (j >= n_sel) continue;
+            const double bu = sub ? sub[j] : 0.0;
+            double p;
+            switch (kind) {
+            case 0: p = acc[q] + 1.0; break;
+            case 1: p = acc[q] + (bi + bu); break;
+            case 2: p = 1.0 + (1.0 / (1.0 + exp(-(acc[q] + (bi + bu))))) * 4.0; break;
+            case 3: p = acc[q] + mu + (bi + bu); break;
+            default: p = acc[q]; break;
+            }
+            if (p != p || p == 0.0 || item == users[j]) continue;          // never listed (mf.py:162,176-182)
+            if (p > ks[q][kTM - 1]) {                                       // would be kept
+                if (is_rated(off, rated, j, item)) continue;
+                double cs = p;                                              // sorted insertion by compare-and-swap
+                int ci = item;                                              // (static indices: the lists stay in registers)
+#pragma unroll
+                for (int t = 0; t < kTM; ++t)
+                    if (ranks_before(cs, ci, ks[q][t], ki[q][t])) {
+                        const double ts = ks[q][t]; const int ti = ki[q][t];
+                        ks[q][t] = cs; ki[q][t] = ci;
+                        cs = ts; ci = ti;
+                    }
+                if (cs > dropped[q]) dropped[q] = cs;                       // the entry pushed out (valid, or -inf)
+            } else if (p > dropped[q]) {                                    // rejected: remember the best one
+                if (!is_rated(off, rated, j, item)) dropped[q] = p;
+            }
+        }
+    }
+    // ---- merge: N rounds of a workgroup-wide arg-max over the kept entries, user by user ------------------
+    __shared__ double ws[4];
+    __shared__ int wi[4], wo[4];
+    __shared__ int s_unsafe;
+#pragma unroll                                                              // q static: the kept lists stay in registers
+    for (int q = 0; q < kUB; ++q) {
+        const int j = j0 + q;
+        if (j >= n_sel) continue;                                           // uniform
+        if (tid == 0) s_unsafe = 0;
+        int taken = 0;                                                      // this thread's entries taken so far (a prefix)
+        double T = -INFINITY;
+        int n_out = 0;
+        for (int t = 0; t < N; ++t) {
+            double s = -INFINITY;
+            int it = 0x7fffffff;
+#pragma unroll
+            for (int m = 0; m < kTM; ++m)
+                if (m == taken) { s = ks[q][m]; it = ki[q][m]; }
+            int owner = tid;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const double s2 = __shfl_xor(s, d, 64);
+                const int it2 = __shfl_xor(it, d, 64), o2 = __shfl_xor(owner, d, 64);
+                if (ranks_before(s2, it2, s, it)) { s = s2; it = it2; owner = o2; }
+            }
+            __syncthreads();                                                // previous round's ws[] consumed
+            if (lane == 0) { ws[wid] = s; wi[wid] = it; wo[wid] = owner; }
+            __syncthreads();
+            s = ws[0]; it = wi[0]; owner = wo[0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w)
+                if (ranks_before(ws[w], wi[w], s, it)) { s = ws[w]; it = wi[w]; owner = wo[w]; }
+            if (s == -INFINITY) break;                                      // nothing left (uniform)
+            if (owner == tid) ++taken;
+            if (tid == 0) { out_items[(size_t)j * N + t] = it; out_scores[(size_t)j * N + t] = s; }
+            T = s;
+            ++n_out;
+        }
+        if (tid == 0)
+            for (int t = n_out; t < N; ++t) { out_items[(size_t)j * N + t] = -1; out_scores[(size_t)j * N + t] = 0.0; }
+        // a thread that dropped something which could belong to the list makes the user unsafe
+        const bool bad = n_out == N ? dropped[q] >= T : dropped[q] > -INFINITY;
+        if (bad || (force_unsafe && (j % 3) == 0)) s_unsafe = 1;
+        __syncthreads();
+        if (tid == 0) unsafe[j] = s_unsafe;
+        __syncthreads();
+    }
+}
+
 struct DevBufs {
     std::vector<void *> p;
     ~DevBufs() { for (void *x : p) if (x) (void)hipFree(x); }
@@ -209,10 +358,12 @@ struct DevBufs {
 
 }  // namespace
 
-extern "C" int mfx_topn_batch(int kind, int dim, const double *u, const double *v_sel, const double *ib,
-                              const double *ub_sel, double mu, int ni, const int32_t *users, int n_sel, int n_cand,
-                              int N, const int64_t *rated_off, const int32_t *rated_items, int32_t *out_items,
-                              double *out_scores)
+static int64_t g_topn_stats[2] = {0, 0};      // users served by the fused kernel / users redone by the sort path
+
+static int topn_impl(int kind, int dim, const double *u, const double *v_sel, const double *ib,
+                     const double *ub_sel, double mu, int ni, const int32_t *users, int n_sel, int n_cand,
+                     int N, const int64_t *rated_off, const int32_t *rated_items, int32_t *out_items,
+                     double *out_scores, bool allow_fused)
 {
     if (!u || !v_sel || !users || !out_items || !out_scores || dim < 1 || ni <= 0 || n_sel < 0 || n_cand < 1 ||
         n_cand > ni || N < 1 || kind < 0 || kind > 4 || ((kind >= 1 && kind <= 3) && (!ib || !ub_sel)) ||
@@ -230,20 +381,11 @@ extern "C" int mfx_topn_batch(int kind, int dim, const double *u, const double *
     DevBufs B;
 #define TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (void)hipGetLastError(); \
         return mfx::fail(e_ == hipErrorOutOfMemory ? MFX_E_NOMEM : MFX_E_HIP, "mfx_topn_batch: %s -> %s", #call, hipGetErrorString(e_)); } } while (0)
-    // users per chunk: the score matrix and its sorted copy stay below ~2 GB
-    int chunk = (int)(((size_t)1 << 27) / (size_t)n_cand);
-    if (chunk < 1) chunk = 1;
-    if (chunk > n_sel) chunk = n_sel;
-    chunk = (chunk + kUB - 1) / kUB * kUB;
-    const size_t cells = (size_t)chunk * n_cand;
-    if (cells >= ((size_t)1 << 32)) return mfx::fail(MFX_E_ARG, "mfx_topn_batch: n_cand too large");
-    double *du, *dv, *dib = nullptr, *dub = nullptr, *k_in, *k_out, *d_scores;
-    int32_t *d_users, *v_in, *v_out, *d_rated = nullptr, *d_items;
+    double *du, *dv, *dib = nullptr, *dub = nullptr, *d_scores;
+    int32_t *d_users, *d_rated = nullptr, *d_items;
     int64_t *d_off = nullptr;
-    unsigned int *d_seg;
     TRY(B.get(&du, (size_t)dim * ni)); TRY(B.get(&dv, (size_t)dim * n_sel)); TRY(B.get(&d_users, (size_t)n_sel));
-    TRY(B.get(&k_in, cells)); TRY(B.get(&k_out, cells)); TRY(B.get(&v_in, cells)); TRY(B.get(&v_out, cells));
-    TRY(B.get(&d_seg, (size_t)chunk + 1)); TRY(B.get(&d_items, (size_t)n_sel * N)); TRY(B.get(&d_scores, (size_t)n_sel * N));
+    TRY(B.get(&d_items, (size_t)n_sel * N)); TRY(B.get(&d_scores, (size_t)n_sel * N));
     TRY(hipMemcpyAsync(du, u, (size_t)dim * ni * 8, hipMemcpyHostToDevice, st));
     TRY(hipMemcpyAsync(dv, v_sel, (size_t)dim * n_sel * 8, hipMemcpyHostToDevice, st));
     TRY(hipMemcpyAsync(d_users, users, (size_t)n_sel * 4, hipMemcpyHostToDevice, st));
@@ -255,6 +397,71 @@ extern "C" int mfx_topn_batch(int kind, int dim, const double *u, const double *
         TRY(hipMemcpyAsync(d_off, rated_off, ((size_t)n_sel + 1) * 8, hipMemcpyHostToDevice, st));
         TRY(hipMemcpyAsync(d_rated, rated_items, (size_t)n_rated * 4, hipMemcpyHostToDevice, st));
     }
+
+    // ---- fused path (N <= 16, every rated list ascending): no score matrix at all ---------------------------
+    const char *ef = getenv("MFX_TOPN_FUSED");
+    if (allow_fused && N <= kTopMaxN && !(ef && ef[0] == '0')) {
+        bool ascending = true;
+        for (int j = 0; j < n_sel && ascending && n_rated > 0; ++j)
+            for (int64_t q = rated_off[j] + 1; q < rated_off[j + 1]; ++q)
+                if (rated_items[q] <= rated_items[q - 1]) { ascending = false; break; }
+        if (ascending) {
+            int32_t *d_unsafe;
+            TRY(B.get(&d_unsafe, (size_t)n_sel));
+            const char *fu = getenv("MFX_TOPN_FORCE_UNSAFE");          // test hook: every third user goes the long way
+            k_topn_fused<<<(n_sel + kUB - 1) / kUB, 256, 0, st>>>(kind, dim, du, dv, dib, dub, mu, d_users, n_sel, ni, n_cand, N,
+                                                                   n_rated > 0 ? d_off : nullptr, d_rated,
+                                                                   (fu && fu[0] == '1') ? 1 : 0, d_items, d_scores, d_unsafe);
+            TRY(hipGetLastError());
+            std::vector<int32_t> flag((size_t)n_sel);
+            TRY(hipMemcpyAsync(flag.data(), d_unsafe, (size_t)n_sel * 4, hipMemcpyDeviceToHost, st));
+            TRY(hipMemcpyAsync(out_items, d_items, (size_t)n_sel * N * 4, hipMemcpyDeviceToHost, st));
+            TRY(hipMemcpyAsync(out_scores, d_scores, (size_t)n_sel * N * 8, hipMemcpyDeviceToHost, st));
+            TRY(hipStreamSynchronize(st));
+            std::vector<int> redo;
+            for (int j = 0; j < n_sel; ++j) if (flag[(size_t)j]) redo.push_back(j);
+            g_topn_stats[0] += n_sel - (int64_t)redo.size();
+            g_topn_stats[1] += (int64_t)redo.size();
+            if (redo.empty()) return MFX_OK;
+            // the flagged users once more, through the sort path, as a batch of their own
+            const int m = (int)redo.size();
+            std::vector<double> v2((size_t)dim * m), ub2(ub_sel ? (size_t)m : 0), sc2((size_t)m * N);
+            std::vector<int32_t> us2((size_t)m), it2((size_t)m * N), ra2;
+            std::vector<int64_t> off2((size_t)m + 1, 0);
+            for (int a = 0; a < m; ++a) {
+                const int j = redo[(size_t)a];
+                for (int f = 0; f < dim; ++f) v2[(size_t)f * m + a] = v_sel[(size_t)f * n_sel + j];
+                if (ub_sel) ub2[(size_t)a] = ub_sel[j];
+                us2[(size_t)a] = users[j];
+                if (rated_off) {
+                    ra2.insert(ra2.end(), rated_items + rated_off[j], rated_items + rated_off[j + 1]);
+                    off2[(size_t)a + 1] = (int64_t)ra2.size();
+                }
+            }
+            if (ra2.empty()) ra2.push_back(0);
+            int rc2 = topn_impl(kind, dim, u, v2.data(), ib, ub_sel ? ub2.data() : nullptr, mu, ni, us2.data(), m, n_cand, N,
+                                rated_off ? off2.data() : nullptr, ra2.data(), it2.data(), sc2.data(), false);
+            if (rc2) return rc2;
+            for (int a = 0; a < m; ++a) {
+                memcpy(out_items + (size_t)redo[(size_t)a] * N, it2.data() + (size_t)a * N, (size_t)N * 4);
+                memcpy(out_scores + (size_t)redo[(size_t)a] * N, sc2.data() + (size_t)a * N, (size_t)N * 8);
+            }
+            return MFX_OK;
+        }
+    }
+
+    // ---- sort path: score matrix by chunks of users (it and its sorted copy stay below ~3 GB) -----------------
+    int chunk = (int)(((size_t)1 << 27) / (size_t)n_cand);
+    if (chunk < 1) chunk = 1;
+    if (chunk > n_sel) chunk = n_sel;
+    chunk = (chunk + kUB - 1) / kUB * kUB;
+    const size_t cells = (size_t)chunk * n_cand;
+    if (cells >= ((size_t)1 << 32)) return mfx::fail(MFX_E_ARG, "mfx_topn_batch: n_cand too large");
+    double *k_in, *k_out;
+    int32_t *v_in, *v_out;
+    unsigned int *d_seg;
+    TRY(B.get(&k_in, cells)); TRY(B.get(&k_out, cells)); TRY(B.get(&v_in, cells)); TRY(B.get(&v_out, cells));
+    TRY(B.get(&d_seg, (size_t)chunk + 1));
     k_iota_offsets<<<(chunk + 256) / 256, 256, 0, st>>>(d_seg, chunk, (unsigned int)n_cand);
     size_t tmp_bytes = 0;
     TRY(rocprim::segmented_radix_sort_pairs_desc(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, (unsigned int)cells,
@@ -275,5 +482,23 @@ extern "C" int mfx_topn_batch(int kind, int dim, const double *u, const double *
     TRY(hipMemcpyAsync(out_scores, d_scores, (size_t)n_sel * N * 8, hipMemcpyDeviceToHost, st));
     TRY(hipStreamSynchronize(st));
 #undef TRY
+    return MFX_OK;
+}
+
+extern "C" int mfx_topn_batch(int kind, int dim, const double *u, const double *v_sel, const double *ib,
+                              const double *ub_sel, double mu, int ni, const int32_t *users, int n_sel, int n_cand,
+                              int N, const int64_t *rated_off, const int32_t *rated_items, int32_t *out_items,
+                              double *out_scores)
+{
+    return topn_impl(kind, dim, u, v_sel, ib, ub_sel, mu, ni, users, n_sel, n_cand, N, rated_off, rated_items, out_items,
+                     out_scores, true);
+}
+
+// stats[0] = users answered by the fused kernel, stats[1] = users it flagged and the sort path redid (process totals)
+extern "C" int mfx_topn_stats(int64_t stats[2])
+{
+    if (!stats) return mfx::fail(MFX_E_ARG, "mfx_topn_stats: NULL");
+    stats[0] = g_topn_stats[0];
+    stats[1] = g_topn_stats[1];
     return MFX_OK;
 }

@@ -58,14 +58,15 @@ def topn_batch(recommender, users, n_candidates, nbr_recommendations, predictor=
     mu = float(recommender.overall_bias or 0.0)
     rel = recommender.relationship_matrix.tocsr()
     rel.eliminate_zeros()
+    rel.sort_indices()                                     # ascending lists: the fused kernel searches them
     in_matrix = users < rel.shape[0]                       # folded-in users have no row in the ratings matrix
     counts = np.zeros(n, dtype=np.int64)
     counts[in_matrix] = np.diff(rel.indptr)[users[in_matrix]]
     off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-    rated = np.zeros(max(int(off[-1]), 1), dtype=np.int32)
-    for j in np.nonzero(in_matrix)[0]:
-        a = rel.indptr[users[j]]
-        rated[off[j]:off[j + 1]] = rel.indices[a:a + counts[j]]
+    # users outside the matrix contribute empty lists, so the rows of the others, in order, are the whole array
+    rated = np.ascontiguousarray(rel[users[in_matrix]].indices, dtype=np.int32) if in_matrix.any() else np.zeros(0, np.int32)
+    if rated.shape[0] == 0:
+        rated = np.zeros(1, dtype=np.int32)
     items = np.full((n, nbr_recommendations), -1, dtype=np.int32)
     scores = np.zeros((n, nbr_recommendations))
     S.check(S.lib().mfx_topn_batch(kind, u.shape[0], S.f64(u, "svd_u", 2), S.f64(v_sel, "v_sel", 2),

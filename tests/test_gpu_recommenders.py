@@ -390,3 +390,59 @@ def test_batched_top_n_equals_the_single_user_ranking():
     assert a == b
     with pytest.raises(IndexError):
         G.find_recommended_items_batch([nu], 3)
+
+
+def test_fused_top_n_proves_or_falls_back(monkeypatch):
+    """N <= 16 goes through the fused kernel (no score matrix).  It must (a) equal the sort path and the single-user
+    ranking, (b) notice when a thread visits more than its three kept slots' worth of the list -- four of the best
+    items sharing the stride-256 lane -- and hand that user to the sort path, (c) survive every user being sent the
+    long way (test hook)."""
+    import ctypes as C
+    from mfrec_amd import _shim as S
+    from mfrec_amd.recommendation import KMFRecommender
+
+    def stats():
+        a = (C.c_int64 * 2)()
+        S.check(S.lib().mfx_topn_stats(a))
+        return a[0], a[1]
+
+    nu, ni, k = 64, 1500, 6
+    rs = np.random.RandomState(8)
+    R = KMFRecommender(nu, ni, {"nbr_features": k})
+    R.set_ratings(np.stack([rs.randint(0, nu, 3000), rs.randint(0, ni, 3000)], 1), rs.randint(1, 6, 3000).astype(float))
+    R.svd_u, R.svd_v = rs.normal(0, 0.3, (k, ni)), rs.normal(0, 0.3, (k, nu))
+    R.items_bias, R.users_bias, R.overall_bias = rs.normal(0, 0.1, ni), rs.normal(0, 0.1, nu), 3.0
+    R.neighborhood = ni
+    users = list(range(nu))
+    for N in (1, 5, 16):
+        f0, r0 = stats()
+        fi, fs = R.find_recommended_items_batch(users, N, "predict_linear")
+        f1, r1 = stats()
+        assert (f1 - f0) + (r1 - r0) == nu and (f1 - f0) >= nu - 4          # fused, almost always proven
+        monkeypatch.setenv("MFX_TOPN_FUSED", "0")
+        si, ss = R.find_recommended_items_batch(users, N, "predict_linear")
+        monkeypatch.delenv("MFX_TOPN_FUSED")
+        assert stats() == (f1, r1)                                          # the sort path does not count
+        assert np.array_equal(fi, si) and np.array_equal(fs, ss)
+        monkeypatch.setenv("MFX_TOPN_FORCE_UNSAFE", "1")
+        ui, us = R.find_recommended_items_batch(users, N, "predict_linear")
+        monkeypatch.delenv("MFX_TOPN_FORCE_UNSAFE")
+        assert stats()[1] - r1 >= (nu + 2) // 3
+        assert np.array_equal(fi, ui) and np.array_equal(fs, us)
+    # (b): items 5, 261, 517, 773 are visited by the same thread; make them user 9's four best by far
+    for it in (5, 261, 517, 773):
+        R.svd_u[:, it] = 0.0
+        R.items_bias[it] = 50.0 + it / 1000.0
+        R.relationship_matrix[9, it] = 0
+    f0, r0 = stats()
+    gi, gs = R.find_recommended_items_batch([9, 10], 6, "predict_linear")
+    f1, r1 = stats()
+    assert r1 - r0 >= 1                                                     # noticed, redone
+    for row, user in zip(range(2), (9, 10)):
+        wi, wsc = R.find_recommended_items(user_index=user, nbr_recommendations=6, predictor="predict_linear")
+        assert list(gi[row]) == wi and np.array_equal(gs[row], np.array(wsc))
+    assert list(gi[0][:4]) == [773, 517, 261, 5]
+    # N = 17 is the sort path's
+    f0, r0 = stats()
+    R.find_recommended_items_batch(users, 17, "predict_linear")
+    assert stats() == (f0, r0)

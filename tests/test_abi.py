@@ -45,6 +45,28 @@ def test_fails_loudly_without_gpu(lib):
     with pytest.raises(S.MfxError):
         kmf_train.train_linear_kernel(1, 4, 0.1, 0.01, 0, 0, 0.1, 0.1, 0.007, 0.0, u, v, idx,
                                       np.array([3.0, 4.0]), np.zeros(3), np.zeros(5))
+    # every family: the Funk pass, ALS, the resident plan, the batched predict / top-N, the device queries
+    from mfrec_amd.lib import gd_estimator, als_implicit
+    from mfrec_amd.plan import SgdPlan
+    from mfrec_amd.recommendation import KMFRecommender, metrics
+    r = np.array([3.0, 4.0])
+    with pytest.raises(S.MfxError):
+        gd_estimator.estimator_loop_without_bias(1, 1, 1e9, 4, 0.1, 0.001, 0.05, u, v, idx, r, 5, 3)
+    with pytest.raises(S.MfxError):
+        als_implicit.als_wrmf(1, 4, u, v, None, None, np.array([0, 1, 1, 0, 0, 0], dtype=np.int32),
+                              np.array([0, 2], dtype=np.int32), np.array([0, 1, 0, 1], dtype=np.int32),
+                              np.array([0, 1], dtype=np.int32), 5, 3)
+    with pytest.raises(S.MfxError):
+        SgdPlan(idx, r, 5, 3, 4)
+    R = KMFRecommender(5, 3, {"nbr_features": 4})
+    R.set_ratings(idx, r)
+    R.svd_u, R.svd_v, R.items_bias, R.users_bias, R.overall_bias = u, v, np.zeros(3), np.zeros(5), 3.5
+    with pytest.raises(S.MfxError):
+        metrics.predict_batch(R, idx, "predict_linear", r)
+    with pytest.raises(S.MfxError):
+        R.find_recommended_items_batch([0, 1], 2, "predict_linear")
+    with pytest.raises(S.MfxError):
+        S.check(lib.mfx_device_mem_info(None, None))
 
 
 def test_buffer_validation_mimics_cython(lib):

@@ -115,8 +115,8 @@ constexpr int kUB = 8;          // users per thread in k_scores: one load of U[f
 // vs: [k][n_sel] feature-major columns of the selected users; sub: [n_sel] their biases (nullable)
 __global__ __launch_bounds__(256) void k_scores(int kind, int k, const double *__restrict__ u, const double *__restrict__ vs,
                                                 const double *__restrict__ ib, const double *__restrict__ sub, double mu,
-                                                const int32_t *__restrict__ users, int n_sel, int j_base, int n_chunk,
-                                                int ni, int n_cand, double *scores, int32_t *items)
+                                                const int32_t *__restrict__ users, int n_sel, int n_pad, int j_base,
+                                                int n_chunk, int ni, int n_cand, double *scores, int32_t *items)
 {
     const int item = blockIdx.x * 256 + threadIdx.x;
     const int j0 = j_base + blockIdx.y * kUB;                 // first user (position in the batch) of this thread
@@ -124,13 +124,12 @@ __global__ __launch_bounds__(256) void k_scores(int kind, int k, const double *_
     double acc[kUB];
 #pragma unroll
     for (int q = 0; q < kUB; ++q) acc[q] = 0.0;
+#pragma unroll 8
     for (int f = 0; f < k; ++f) {
         const double uf = u[(size_t)f * ni + item];
+        const double *vrow = vs + (size_t)f * n_pad + j0;                   // eight users: contiguous, uniform, padded
 #pragma unroll
-        for (int q = 0; q < kUB; ++q) {
-            const int j = j0 + q < n_sel ? j0 + q : n_sel - 1;
-            acc[q] += uf * vs[(size_t)f * n_sel + j];
-        }
+        for (int q = 0; q < kUB; ++q) acc[q] += uf * vrow[q];
     }
     const double bi = ib ? ib[item] : 0.0;
 #pragma unroll
@@ -234,8 +233,8 @@ __device__ __forceinline__ bool ranks_before(double s, int it, double s2, int it
 __global__ __launch_bounds__(256) void k_topn_fused(int kind, int k, const double *__restrict__ u,
                                                     const double *__restrict__ vs, const double *__restrict__ ib,
                                                     const double *__restrict__ sub, double mu,
-                                                    const int32_t *__restrict__ users, int n_sel, int ni, int n_cand,
-                                                    int N, const int64_t *__restrict__ off,
+                                                    const int32_t *__restrict__ users, int n_sel, int n_pad, int ni,
+                                                    int n_cand, int N, const int64_t *__restrict__ off,
                                                     const int32_t *__restrict__ rated, int force_unsafe,
                                                     int32_t *out_items, double *out_scores, int32_t *unsafe)
 {
@@ -254,14 +253,30 @@ __global__ __launch_bounds__(256) void k_topn_fused(int kind, int k, const doubl
         double acc[kUB];
 #pragma unroll
         for (int q = 0; q < kUB; ++q) acc[q] = 0.0;
-#pragma unroll 8                                                            // eight column loads in flight
-        for (int f = 0; f < k; ++f) {
-            const double uf = u[(size_t)f * ni + item];
+        // four features per round: their column loads and their four 64-byte scalar loads (eight users: contiguous,
+        // uniform, padded) are issued together and waited for once -- one scalar load per feature, waited for before
+        // its multiplies, left ~200 clocks of latency between every eight multiplies
+        int f = 0;
+        for (; f + 4 <= k; f += 4) {
+            double uf[4], vv[4][kUB];
 #pragma unroll
-            for (int q = 0; q < kUB; ++q) {
-                const int j = j0 + q < n_sel ? j0 + q : n_sel - 1;
-                acc[q] += uf * vs[(size_t)f * n_sel + j];
+            for (int r = 0; r < 4; ++r) uf[r] = u[(size_t)(f + r) * ni + item];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double *vrow = vs + (size_t)(f + r) * n_pad + j0;
+#pragma unroll
+                for (int q = 0; q < kUB; ++q) vv[r][q] = vrow[q];
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int q = 0; q < kUB; ++q) acc[q] += uf[r] * vv[r][q];
+        }
+        for (; f < k; ++f) {
+            const double uf = u[(size_t)f * ni + item];
+            const double *vrow = vs + (size_t)f * n_pad + j0;
+#pragma unroll
+            for (int q = 0; q < kUB; ++q) acc[q] += uf * vrow[q];
         }
         const double bi = ib ? ib[item] : 0.0;
 #pragma unroll
@@ -344,6 +359,168 @@ __global__ __launch_bounds__(256) void k_topn_fused(int kind, int k, const doubl
     }
 }
 
+// ---- the same ranking with U staged through LDS ---------------------------------------------------------------
+// k_topn_fused re-reads all of U once per 8 users with 400-KB-strided column loads; it measured 8x off its VALU bound.
+// Here a workgroup owns 32 users (wave w: users 8w .. 8w+7) and walks U in tiles of 64 features x 64 items that the
+// 256 threads load together, fully coalesced, one tile ahead (registers -> the other LDS buffer, one barrier per
+// tile).  lane = item inside the tile; a wave's eight user values per feature sit in its own LDS block (vs is padded to a
+// multiple of 8 users, so the block is a contiguous copy).  Same sums in the same order, same keep / drop bookkeeping per lane, the merge is a
+// wave-wide arg-max.  A lane visits n_cand / 64 items, so a few more users are flagged (< 1 % at N = 16).
+constexpr int kTF = 64, kTI = 64;                   // tile: features x items
+
+__global__ __launch_bounds__(256) void k_topn_tiled(int kind, int k, const double *__restrict__ u,
+                                                    const double *__restrict__ vs, const double *__restrict__ ib,
+                                                    const double *__restrict__ sub, double mu,
+                                                    const int32_t *__restrict__ users, int n_sel, int n_pad, int ni,
+                                                    int n_cand, int N, const int64_t *__restrict__ off,
+                                                    const int32_t *__restrict__ rated, int force_unsafe,
+                                                    int32_t *out_items, double *out_scores, int32_t *unsafe)
+{
+    __shared__ double tile[2][kTF][kTI];                                    // 64 KB
+    __shared__ __attribute__((aligned(16))) double vt[4][kTF][kUB];         // 16 KB: per wave, its users' values of a feature chunk
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int j0 = (blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wid)) * kUB;   // uniform; < n_pad by construction of the grid
+    const bool wave_on = j0 < n_sel;
+    double ks[kUB][kTM];
+    int ki[kUB][kTM];
+    double dropped[kUB];
+#pragma unroll
+    for (int q = 0; q < kUB; ++q) {
+        dropped[q] = -INFINITY;
+#pragma unroll
+        for (int m = 0; m < kTM; ++m) { ks[q][m] = -INFINITY; ki[q][m] = 0x7fffffff; }
+    }
+    const int n_it = (n_cand + kTI - 1) / kTI, n_fc = (k + kTF - 1) / kTF, n_tiles = n_it * n_fc;
+    constexpr int PER = kTF * kTI / 256;                                    // 16 doubles per thread per tile
+    double pre[PER];
+    auto fetch = [&](int t) {                                               // tile t -> registers
+        const int i0 = (t / n_fc) * kTI, f0 = (t % n_fc) * kTF;
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+            const int f = f0 + r * 4 + wid, it = i0 + lane;
+            pre[r] = (f < k && it < n_cand) ? u[(size_t)f * ni + it] : 0.0;
+        }
+    };
+    auto stash = [&](int b) {
+#pragma unroll
+        for (int r = 0; r < PER; ++r) tile[b][r * 4 + wid][lane] = pre[r];
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    double acc[kUB];
+    for (int t = 0; t < n_tiles; ++t) {
+        const int fc = t % n_fc, i0 = (t / n_fc) * kTI, f0 = fc * kTF;
+        if (t + 1 < n_tiles) fetch(t + 1);
+        if (fc == 0) {
+#pragma unroll
+            for (int q = 0; q < kUB; ++q) acc[q] = 0.0;
+        }
+        if (wave_on) {
+            const int nf = k - f0 < kTF ? k - f0 : kTF;
+            const double(*tb)[kTI] = tile[t & 1];
+            // the wave's eight user values of every feature of this chunk go from (padded, contiguous) global memory into
+            // its own LDS block once per chunk and are read back as broadcast b128 reads the scheduler can hoist.
+            // Measured alternatives for 100 K users x 50 K items: one scalar load per (feature, user) 150 ms; one 64-byte
+            // scalar load per feature 123 ms; four of them batched per round 104 ms (SMEM shares its counter with the
+            // LDS tile reads and returns out of order: every wait is a full one); this form 90 ms -- now LDS-bound, a
+            // broadcast read costs its full 64-lane bandwidth.
+            if (n_fc > 1 || t == 0) {
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < kTF * kUB / 64; ++r) {
+                    const int e = r * 64 + lane, f = e / kUB, q = e % kUB;
+                    vt[wid][f][q] = f0 + f < k ? vs[(size_t)(f0 + f) * n_pad + j0 + q] : 0.0;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            const double(*vb)[kUB] = vt[wid];
+#pragma unroll 4
+            for (int f = 0; f < nf; ++f) {
+                const double uf = tb[f][lane];
+                double vv[kUB];
+#pragma unroll
+                for (int q = 0; q < kUB; q += 2) {
+                    const double2 w = *reinterpret_cast<const double2 *>(&vb[f][q]);
+                    vv[q] = w.x; vv[q + 1] = w.y;
+                }
+#pragma unroll
+                for (int q = 0; q < kUB; ++q) acc[q] += uf * vv[q];
+            }
+            const int item = i0 + lane;
+            if (fc == n_fc - 1 && item < n_cand) {
+                const double bi = ib ? ib[item] : 0.0;
+#pragma unroll
+                for (int q = 0; q < kUB; ++q) {
+                    const int j = j0 + q;
+                    if (j >= n_sel) continue;
+                    const double bu = sub ? sub[j] : 0.0;
+                    double p;
+                    switch (kind) {
+                    case 0: p = acc[q] + 1.0; break;
+                    case 1: p = acc[q] + (bi + bu); break;
+                    case 2: p = 1.0 + (1.0 / (1.0 + exp(-(acc[q] + (bi + bu))))) * 4.0; break;
+                    case 3: p = acc[q] + mu + (bi + bu); break;
+                    default: p = acc[q]; break;
+                    }
+                    if (p != p || p == 0.0 || item == users[j]) continue;  // never listed (mf.py:162,176-182)
+                    if (p > ks[q][kTM - 1]) {                               // would be kept
+                        if (is_rated(off, rated, j, item)) continue;
+                        double cs = p;
+                        int ci = item;
+#pragma unroll
+                        for (int m = 0; m < kTM; ++m)
+                            if (ranks_before(cs, ci, ks[q][m], ki[q][m])) {
+                                const double ts = ks[q][m]; const int ti = ki[q][m];
+                                ks[q][m] = cs; ki[q][m] = ci;
+                                cs = ts; ci = ti;
+                            }
+                        if (cs > dropped[q]) dropped[q] = cs;
+                    } else if (p > dropped[q]) {
+                        if (!is_rated(off, rated, j, item)) dropped[q] = p;
+                    }
+                }
+            }
+        }
+        if (t + 1 < n_tiles) stash((t + 1) & 1);                            // that buffer was last read in round t - 1
+        __syncthreads();
+    }
+    if (!wave_on) return;
+    // ---- merge: N rounds of a wave-wide arg-max over the kept entries, user by user ---------------------------
+#pragma unroll
+    for (int q = 0; q < kUB; ++q) {
+        const int j = j0 + q;
+        if (j >= n_sel) continue;                                           // uniform
+        int taken = 0;
+        double T = -INFINITY;
+        int n_out = 0;
+        for (int t = 0; t < N; ++t) {
+            double s = -INFINITY;
+            int it = 0x7fffffff;
+#pragma unroll
+            for (int m = 0; m < kTM; ++m)
+                if (m == taken) { s = ks[q][m]; it = ki[q][m]; }
+            int owner = lane;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const double s2 = __shfl_xor(s, d, 64);
+                const int it2 = __shfl_xor(it, d, 64), o2 = __shfl_xor(owner, d, 64);
+                if (ranks_before(s2, it2, s, it)) { s = s2; it = it2; owner = o2; }
+            }
+            if (s == -INFINITY) break;                                      // nothing left (uniform)
+            if (owner == lane) ++taken;
+            if (lane == 0) { out_items[(size_t)j * N + t] = it; out_scores[(size_t)j * N + t] = s; }
+            T = s;
+            ++n_out;
+        }
+        if (lane == 0)
+            for (int t = n_out; t < N; ++t) { out_items[(size_t)j * N + t] = -1; out_scores[(size_t)j * N + t] = 0.0; }
+        const bool bad = n_out == N ? dropped[q] >= T : dropped[q] > -INFINITY;
+        const bool any_bad = __any(bad || (force_unsafe && (j % 3) == 0));
+        if (lane == 0) unsafe[j] = any_bad ? 1 : 0;
+    }
+}
+
 struct DevBufs {
     std::vector<void *> p;
     ~DevBufs() { for (void *x : p) if (x) (void)hipFree(x); }
@@ -384,10 +561,12 @@ static int topn_impl(int kind, int dim, const double *u, const double *v_sel, co
     double *du, *dv, *dib = nullptr, *dub = nullptr, *d_scores;
     int32_t *d_users, *d_rated = nullptr, *d_items;
     int64_t *d_off = nullptr;
-    TRY(B.get(&du, (size_t)dim * ni)); TRY(B.get(&dv, (size_t)dim * n_sel)); TRY(B.get(&d_users, (size_t)n_sel));
+    const int n_pad = (n_sel + 4 * kUB - 1) / (4 * kUB) * (4 * kUB);       // vs rows padded: eight users are one uniform load
+    TRY(B.get(&du, (size_t)dim * ni)); TRY(B.get(&dv, (size_t)dim * n_pad)); TRY(B.get(&d_users, (size_t)n_sel));
     TRY(B.get(&d_items, (size_t)n_sel * N)); TRY(B.get(&d_scores, (size_t)n_sel * N));
     TRY(hipMemcpyAsync(du, u, (size_t)dim * ni * 8, hipMemcpyHostToDevice, st));
-    TRY(hipMemcpyAsync(dv, v_sel, (size_t)dim * n_sel * 8, hipMemcpyHostToDevice, st));
+    if (n_pad != n_sel) TRY(hipMemsetAsync(dv, 0, (size_t)dim * n_pad * 8, st));
+    TRY(hipMemcpy2DAsync(dv, (size_t)n_pad * 8, v_sel, (size_t)n_sel * 8, (size_t)n_sel * 8, (size_t)dim, hipMemcpyHostToDevice, st));
     TRY(hipMemcpyAsync(d_users, users, (size_t)n_sel * 4, hipMemcpyHostToDevice, st));
     if (ib) { TRY(B.get(&dib, (size_t)ni)); TRY(hipMemcpyAsync(dib, ib, (size_t)ni * 8, hipMemcpyHostToDevice, st)); }
     if (ub_sel) { TRY(B.get(&dub, (size_t)n_sel)); TRY(hipMemcpyAsync(dub, ub_sel, (size_t)n_sel * 8, hipMemcpyHostToDevice, st)); }
@@ -409,9 +588,15 @@ static int topn_impl(int kind, int dim, const double *u, const double *v_sel, co
             int32_t *d_unsafe;
             TRY(B.get(&d_unsafe, (size_t)n_sel));
             const char *fu = getenv("MFX_TOPN_FORCE_UNSAFE");          // test hook: every third user goes the long way
-            k_topn_fused<<<(n_sel + kUB - 1) / kUB, 256, 0, st>>>(kind, dim, du, dv, dib, dub, mu, d_users, n_sel, ni, n_cand, N,
-                                                                   n_rated > 0 ? d_off : nullptr, d_rated,
-                                                                   (fu && fu[0] == '1') ? 1 : 0, d_items, d_scores, d_unsafe);
+            const char *tv = getenv("MFX_TOPN_KERNEL");                 // "strided": the first fused kernel (A/B, tests)
+            if (tv && tv[0] == 's')
+                k_topn_fused<<<(n_sel + kUB - 1) / kUB, 256, 0, st>>>(kind, dim, du, dv, dib, dub, mu, d_users, n_sel, n_pad, ni, n_cand,
+                                                                       N, n_rated > 0 ? d_off : nullptr, d_rated,
+                                                                       (fu && fu[0] == '1') ? 1 : 0, d_items, d_scores, d_unsafe);
+            else
+                k_topn_tiled<<<n_pad / (4 * kUB), 256, 0, st>>>(kind, dim, du, dv, dib, dub, mu, d_users, n_sel, n_pad, ni, n_cand, N,
+                                                                n_rated > 0 ? d_off : nullptr, d_rated,
+                                                                (fu && fu[0] == '1') ? 1 : 0, d_items, d_scores, d_unsafe);
             TRY(hipGetLastError());
             std::vector<int32_t> flag((size_t)n_sel);
             TRY(hipMemcpyAsync(flag.data(), d_unsafe, (size_t)n_sel * 4, hipMemcpyDeviceToHost, st));
@@ -471,7 +656,7 @@ static int topn_impl(int kind, int dim, const double *u, const double *v_sel, co
     for (int jb = 0; jb < n_sel; jb += chunk) {
         const int nc = n_sel - jb < chunk ? n_sel - jb : chunk;
         k_scores<<<dim3((n_cand + 255) / 256, (nc + kUB - 1) / kUB), 256, 0, st>>>(kind, dim, du, dv, dib, dub, mu, d_users,
-                                                                                   n_sel, jb, nc, ni, n_cand, k_in, v_in);
+                                                                                   n_sel, n_pad, jb, nc, ni, n_cand, k_in, v_in);
         if (n_rated > 0) k_clear_rated<<<dim3(4, nc), 256, 0, st>>>(d_off, d_rated, jb, nc, n_cand, k_in);
         TRY(rocprim::segmented_radix_sort_pairs_desc(tmp, tmp_bytes, k_in, k_out, v_in, v_out, (unsigned int)((size_t)nc * n_cand),
                                                      (unsigned int)nc, d_seg, d_seg + 1, 0u, 64u, st));

@@ -392,6 +392,59 @@ def also_als(idx3, nu, ni, k):
                          "traffic": None, "flop_model": "SURVEY 8(d)"}}
 
 
+def also_topn(idx, r, nu, ni, k, with_cpu):
+    """Evaluation side: top-10 of every item for 100 K users in one call (mfx_topn_batch, fused
+    kernel) on cfg 2's shape, and -- as the CPU baseline -- the reference's own procedure for ONE user: a Python
+    loop calling predict() per item (mf.py:161-173), timed on a bounded number of users."""
+    import ctypes as C
+    import scipy.sparse as sp
+    from mfrec_amd import _shim as S
+    from mfrec_amd import synth
+    from mfrec_amd.recommendation import KMFRecommender
+    R = KMFRecommender(4, 6, {"nbr_features": k})
+    R._nbr_users, R._nbr_items = nu, ni
+    R.relationship_matrix = sp.csr_matrix((r, (idx[:, 0], idx[:, 1])), shape=(nu, ni)).tolil()
+    R.svd_u, R.svd_v = synth.init_normal(k, ni, synth.SEED_INIT), synth.init_normal(k, nu, synth.SEED_INIT + 1)
+    R.items_bias, R.users_bias, R.overall_bias = np.zeros(ni), np.zeros(nu), 3.0
+    R.neighborhood = ni
+    users = np.arange(nu, dtype=np.int32)
+    N = 10
+    R.find_recommended_items_batch(users[:1000], N, "predict_linear")            # warm-up
+    st0 = (C.c_int64 * 2)(); S.check(S.lib().mfx_topn_stats(st0))
+    t = time.perf_counter()
+    items, scores = R.find_recommended_items_batch(users, N, "predict_linear")
+    wall = time.perf_counter() - t
+    st1 = (C.c_int64 * 2)(); S.check(S.lib().mfx_topn_stats(st1))
+    flops = 2.0 * k * nu * ni                                                     # one multiply + one add per term
+    out = {"value": nu / wall, "unit": "users/s", "seconds": wall, "users": nu, "candidates": ni, "N": N,
+           "users_redone_by_sort_path": int(st1[1] - st0[1]),
+           "workload": "cfg2 shape: top-%d of %dK candidate items for each of %dK users, k=%d, predict_linear, rated items "
+                       "excluded (mf.py:144-193 rules), end to end from host arrays (CSR marshalling of 10M ratings, "
+                       "H2D, fused kernel, D2H)" % (N, ni // 1000, nu // 1000, k),
+           "roofline": {"bound": "valu-f64", "achieved": flops / wall / 1e12, "peak": F64_MFMA_PEAK / 2e12,
+                        "unit": "TFLOP/s (unfused mul + add)", "frac": flops / wall / (F64_MFMA_PEAK / 2),
+                        "kernel": "k_topn_tiled", "traffic": None,
+                        "note": "whole-call rate; the kernel alone: 90 ms (DESIGN section 1)"}}
+    if with_cpu:
+        t = time.perf_counter()
+        done = 0
+        while time.perf_counter() - t < 6.0 and done < 50:
+            user = done
+            rated = set(R.relationship_matrix.rows[user]) | {user}
+            sc = np.zeros(ni)
+            for i in range(ni):                                                   # the reference's loop, predict() per item
+                sc[i] = 0.0 if i in rated else R.predict_linear(i, user)
+            nzi = sc.nonzero()[0]
+            top = nzi[np.argsort(-sc[nzi], kind="stable")][:N]
+            assert list(top) == [int(x) for x in items[user] if x >= 0]
+            done += 1
+        cw = time.perf_counter() - t
+        out["cpu_baseline"] = {"value": done / cw, "unit": "users/s", "cores": 1, "kind": "port",
+                               "sample": "%d users, the reference's per-item predict() loop (mf.py:161-173) in NumPy, "
+                                         "%.1f s; each list checked against the GPU's" % (done, cw)}
+    return out
+
+
 def fail_line(rank, world, what, err):
     """One greppable line per failing rank (RCCL's own text is inside the library's error message; with
     NCCL_DEBUG=WARN, set below for N > 1, RCCL also prints its warnings to stderr)."""
@@ -724,6 +777,8 @@ def main():
                 also["k2_funk"]["cpu_baseline"] = cpu_baseline_funk(idx, r, nu, ni)
             except Exception as e:
                 also["k2_funk"]["cpu_baseline"] = {"error": repr(e)}
+
+        leg("topn_batch", lambda: also_topn(idx, r, nu, ni, k, not a.no_cpu))
 
         def cfg3_and_als():
             nu3, ni3, nnz3, k3 = CFG3

@@ -449,3 +449,26 @@ def test_fused_top_n_proves_or_falls_back(monkeypatch, kernel):
     f0, r0 = stats()
     R.find_recommended_items_batch(users, 17, "predict_linear")
     assert stats() == (f0, r0)
+
+
+@pytest.mark.parametrize("k", [64, 80, 130])
+def test_fused_top_n_with_more_than_one_feature_chunk(k, monkeypatch):
+    """k > 64: the tiled kernel walks the features in chunks of 64 with the sums carried across chunks -- same bits
+    as the sort path and the single-user query (k = 80: a ragged second chunk; k = 130: three chunks)."""
+    from mfrec_amd.recommendation import KMFRecommender
+    nu, ni = 70, 333
+    rs = np.random.RandomState(k)
+    R = KMFRecommender(nu, ni, {"nbr_features": k})
+    R.set_ratings(np.stack([rs.randint(0, nu, 2000), rs.randint(0, ni, 2000)], 1), rs.randint(1, 6, 2000).astype(float))
+    R.svd_u, R.svd_v = rs.normal(0, 0.2, (k, ni)), rs.normal(0, 0.2, (k, nu))
+    R.items_bias, R.users_bias, R.overall_bias = rs.normal(0, 0.1, ni), rs.normal(0, 0.1, nu), 3.0
+    R.neighborhood = ni
+    users = list(range(nu))
+    fi, fs = R.find_recommended_items_batch(users, 7, "predict_logistic")
+    monkeypatch.setenv("MFX_TOPN_FUSED", "0")
+    si, ss = R.find_recommended_items_batch(users, 7, "predict_logistic")
+    monkeypatch.delenv("MFX_TOPN_FUSED")
+    assert np.array_equal(fi, si) and np.array_equal(fs, ss)
+    for user in (0, 33, 69):
+        wi, ws = R.find_recommended_items(user_index=user, nbr_recommendations=7, predictor="predict_logistic")
+        assert list(fi[user]) == wi and np.array_equal(fs[user], np.array(ws))

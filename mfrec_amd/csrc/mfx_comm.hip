@@ -43,10 +43,13 @@ double *g_token = nullptr;
 int load_rccl()
 {
     if (R.h) return MFX_OK;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // MFX_RCCL_LIB: a library with the same twelve entry points -- the tests' shared-memory stand-in that lets
+    // several processes on ONE GPU rehearse the N > 1 paths (tests/mock_rccl); the product never sets it
+    const char *over = getenv("MFX_RCCL_LIB");
+    const char *names[] = {over && over[0] ? over : "librccl.so.1", "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char *n : names) {
         R.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-        if (R.h) break;
+        if (R.h || (over && over[0])) break;              // an override that does not load is an error, not a fallback
     }
     if (!R.h) return mfx::fail(MFX_E_RCCL, "cannot dlopen librccl: %s", dlerror());
     R.GetUniqueId = (decltype(R.GetUniqueId))dlsym(R.h, "ncclGetUniqueId");

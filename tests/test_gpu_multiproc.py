@@ -1,0 +1,201 @@
+"""GPU: the N > 1 code paths of libmfx with REAL processes -- two or three ranks, each its own process with its own
+HIP context, stream and communicator, all on the one GPU of the box.  RCCL refuses two ranks on one device, so the
+ranks talk through tests/mock_rccl (a shared-memory stand-in with the same twelve entry points, found through
+MFX_RCCL_LIB; its reductions add in rank order).  What is exercised is everything of ours that a hardware run
+exercises and that the single-process tests cannot reach: the file rendezvous of the unique id, mfx_comm_init at
+world > 1, the real-rank branch of the block rotation (send to g - 1 / receive from g + 1 inside one group on the
+transfer stream, events both ways), its rank-ordered squared-error all-gather and the home-rank broadcasts of
+get_factors, the item-delta all-reduce of the averaging mode, row-sharded ALS, and bench.py's whole N > 1 path.
+Every result must equal the single-process fake world's bit for bit (which the other tests tie to the oracle)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from mfrec_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NU, NI, NNZ, K, E = 3000, 1100, 120000, 16, 3
+HP = (0.01, 0.1, 0.1, 0.007)
+
+
+@pytest.fixture(scope="module")
+def mock_lib():
+    """tests/mock_rccl/mock_rccl.cpp -> build/libmock_rccl.so (hipcc; a few seconds)."""
+    from mfrec_amd import _shim as S, build as B
+    B.build(verbose=False)
+    S.init(0)
+    out = os.path.join(ROOT, "build", "libmock_rccl.so")
+    src = os.path.join(ROOT, "tests", "mock_rccl", "mock_rccl.cpp")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
+        subprocess.run([hipcc, "-O2", "-fPIC", "-shared", "--offload-arch=gfx950", "-o", out, src, "-lrt", "-lpthread"],
+                       check=True, capture_output=True, timeout=300)
+    return out
+
+
+WORKER = r"""
+import ctypes as C, os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+from mfrec_amd import _shim as S, rendezvous, synth
+from mfrec_amd import sharding as SH
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+mode, out = sys.argv[1], sys.argv[2]
+NU, NI, NNZ, K, E = %(dims)s
+HP = %(hp)s
+uid = None
+if rank != 0:
+    uid = rendezvous.exchange_unique_id(rank, world, None, timeout_s=120.0)
+S.init(0)                                                     # every rank on the box's one GPU
+def make_id():
+    b = C.create_string_buffer(S.UNIQUE_ID_BYTES)
+    S.check(S.lib().mfx_comm_unique_id(b))
+    return b.raw
+if rank == 0:
+    uid = rendezvous.exchange_unique_id(rank, world, make_id)
+S.check(S.lib().mfx_comm_init(rank, world, uid))
+idx, r = synth.make_ratings(NU, NI, NNZ, seed=41)
+u0, v0 = synth.init_normal(K, NI, 1), synth.init_normal(K, NU, 2)
+res = {}
+if mode.startswith("dsgd"):
+    overlap, balanced = "overlap" in mode, "balanced" in mode
+    d = SH.DsgdKMF(idx, r, NU, NI, K, rank, world, overlap=overlap, balanced=balanced)
+    lo, hi = int(d.user_bounds[rank]), int(d.user_bounds[rank + 1])
+    d.set_factors(u0, np.ascontiguousarray(v0[:, lo:hi]), np.zeros(NI), np.zeros(hi - lo))
+    se = d.train(0, E, *HP)
+    u, v, ib, ub = np.zeros((K, NI)), np.zeros((K, hi - lo)), np.zeros(NI), np.zeros(hi - lo)
+    d.get_factors(u, v, ib, ub)
+    res = dict(u=u, v=v, ib=ib, ub=ub, se=np.asarray(se), lo=lo, hi=hi, order=d.order())
+    d.close()
+elif mode == "avg":
+    s = SH.ShardedKMF(idx, r, NU, NI, K, rank, world)
+    s.set_factors(u0, v0, np.zeros(NI), np.zeros(NU))
+    rm, se = s.train(0, E, *HP)
+    u, v, ib, ub = s.get_local()
+    res = dict(u=u, v=v[:, :s.nu_local], ib=ib, ub=ub[:s.nu_local], se=np.asarray(se), lo=s.user_lo, hi=s.user_lo + s.nu_local)
+    s.close()
+elif mode == "als":
+    import scipy.sparse as sp
+    from mfrec_amd.lib.als_implicit import als_wrmf_sharded
+    from mfrec_amd.lib.datasets import create_bool_sparse_col, create_bool_sparse_row
+    M = sp.csr_matrix((np.ones(NNZ), (idx[:, 0], idx[:, 1])), shape=(NU, NI)); M.sum_duplicates()
+    views = create_bool_sparse_row(M) + create_bool_sparse_col(M)
+    rs = np.random.RandomState(3)
+    u, v = rs.normal(0, 0.1, (24, NI)), rs.normal(0, 0.1, (24, NU))
+    als_wrmf_sharded(2, 24, u, v, None, None, *views, NU, NI)
+    res = dict(u=u, v=v)
+np.savez(out + ".rank%%d.npz" %% rank, **res)
+S.check(S.lib().mfx_comm_barrier())
+S.check(S.lib().mfx_comm_destroy())
+rendezvous.cleanup(rank)
+"""
+
+
+def _launch(mock_lib, tmp_path, world, mode, port):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT, "dims": repr((NU, NI, NNZ, K, E)), "hp": repr(HP)})
+    out = str(tmp_path / ("res_" + mode.replace(",", "_")))
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), MFX_RCCL_LIB=mock_lib)
+        procs.append(subprocess.Popen([sys.executable, str(script), mode, out], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o)
+    for rank, (p, o) in enumerate(zip(procs, logs)):
+        assert p.returncode == 0, "rank %d:\n%s" % (rank, o[-3000:])
+    return [np.load(out + ".rank%d.npz" % rank) for rank in range(world)]
+
+
+def _problem():
+    idx, r = synth.make_ratings(NU, NI, NNZ, seed=41)
+    return idx, r, synth.init_normal(K, NI, 1), synth.init_normal(K, NU, 2)
+
+
+@pytest.mark.parametrize("world,mode,port", [(2, "dsgd", 29711), (3, "dsgd,balanced", 29712), (2, "dsgd,overlap", 29713)])
+def test_block_rotation_over_real_processes_equals_the_fake_world(mock_lib, tmp_path, world, mode, port):
+    from mfrec_amd import sharding as SH
+    idx, r, u0, v0 = _problem()
+    res = _launch(mock_lib, tmp_path, world, mode, port)
+    d = SH.DsgdKMF(idx, r, NU, NI, K, -1, world, overlap="overlap" in mode, balanced="balanced" in mode)
+    d.set_factors(u0, v0, np.zeros(NI), np.zeros(NU))
+    se = d.train(0, E, *HP)
+    u, v, ib, ub = np.zeros((K, NI)), np.zeros((K, NU)), np.zeros(NI), np.zeros(NU)
+    d.get_factors(u, v, ib, ub)
+    order = d.order()
+    d.close()
+    for rank, z in enumerate(res):
+        lo, hi = int(z["lo"]), int(z["hi"])
+        assert np.array_equal(z["u"], u) and np.array_equal(z["ib"], ib)          # every rank ends with the whole item side
+        assert np.array_equal(z["v"], v[:, lo:hi]) and np.array_equal(z["ub"], ub[lo:hi])
+        # squared errors: per-rank partials added in rank order -- the same bits on every rank, and the fake world's
+        # (step, rank)-ordered total up to the association
+        assert np.array_equal(z["se"], res[0]["se"]) and np.allclose(z["se"], np.asarray(se), rtol=1e-13, atol=0)
+    # the ranks' local orders, interleaved step by step, are the fake world's order
+    assert sorted(np.concatenate([z["order"] for z in res]).tolist()) == sorted(order.tolist())
+
+
+def test_averaging_mode_over_real_processes_equals_the_fake_world(mock_lib, tmp_path):
+    from mfrec_amd import sharding as SH
+    idx, r, u0, v0 = _problem()
+    res = _launch(mock_lib, tmp_path, 2, "avg", 29721)
+    f = SH.FakeWorldKMF(idx, r, NU, NI, K, 2)
+    f.set_factors(u0, v0, np.zeros(NI), np.zeros(NU))
+    f.train(0, E, *HP)
+    u, v, ib, ub = f.get_factors()
+    f.close()
+    for z in res:
+        lo, hi = int(z["lo"]), int(z["hi"])
+        assert np.array_equal(z["u"], u) and np.array_equal(z["ib"], ib)
+        assert np.array_equal(z["v"], v[:, lo:hi]) and np.array_equal(z["ub"], ub[lo:hi])
+
+
+def test_row_sharded_als_over_real_processes_equals_one_process(mock_lib, tmp_path):
+    import scipy.sparse as sp
+    from mfrec_amd.lib.als_implicit import als_wrmf
+    from mfrec_amd.lib.datasets import create_bool_sparse_col, create_bool_sparse_row
+    idx, r, _, _ = _problem()
+    res = _launch(mock_lib, tmp_path, 2, "als", 29731)
+    M = sp.csr_matrix((np.ones(NNZ), (idx[:, 0], idx[:, 1])), shape=(NU, NI)); M.sum_duplicates()
+    views = create_bool_sparse_row(M) + create_bool_sparse_col(M)
+    rs = np.random.RandomState(3)
+    u, v = rs.normal(0, 0.1, (24, NI)), rs.normal(0, 0.1, (24, NU))
+    als_wrmf(2, 24, u, v, None, None, *views, NU, NI)
+    for z in res:
+        assert np.allclose(z["u"], u, rtol=1e-9, atol=1e-12) and np.allclose(z["v"], v, rtol=1e-9, atol=1e-12)
+    assert np.array_equal(res[0]["u"], res[1]["u"]) and np.array_equal(res[0]["v"], res[1]["v"])
+
+
+def test_bench_two_ranks_prints_one_line_with_both_modes(mock_lib, tmp_path):
+    """bench.py exactly as the driver starts it for N = 2 (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+    environment), both ranks on device 0, small problem."""
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT="29741", MFX_RCCL_LIB=mock_lib, MFX_BENCH_DEVICE="0", MFX_BENCH_DSGD_TIMEOUT="200")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                                       "--warmup", "1", "--users", "60000", "--items", "20000", "--nnz", "3000000"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT))
+    outs = [p.communicate(timeout=420) for p in procs]
+    for rank, (p, (o, e)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d:\n%s" % (rank, e[-3000:])
+    lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith("{")]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert "users sharded over 2 GPUs" in d["config"]["workload"]
+    assert d["also"]["dsgd_exact"]["value"] > 0 and "error" not in d["also"]["dsgd_exact"]

@@ -1,7 +1,8 @@
 // TEST INFRASTRUCTURE -- a stand-in for librccl.so that lets several PROCESSES SHARING ONE GPU run libmfx's
 // multi-GPU code paths (RCCL itself refuses two ranks on one device).  It implements the twelve nccl* entry points
 // libmfx binds (mfrec_amd/csrc/mfx_comm.hip) over a shared-memory file: every call synchronises the caller's stream,
-// stages the data through the host and exchanges it with the other ranks.  Reductions add the ranks' contributions in
+// stages the data through the host, exchanges it with the other ranks and delivers the result LATE and asynchronously
+// in stream order (deliver()).  Reductions add the ranks' contributions in
 // RANK ORDER (deterministic, the order of oracle/sharded_sim.py).  Point-to-point calls inside a group make progress
 // together, chunk by chunk, so two ranks that both send first cannot deadlock.  Never linked into the product;
 // libmfx only finds it when MFX_RCCL_LIB names it (tests/test_gpu_multiproc.py).
@@ -45,6 +46,46 @@ struct Comm {
 };
 
 struct P2P { bool send; char *dev; size_t bytes; int peer; hipStream_t st; };
+
+// Results are DELIVERED LATE, in stream order: a kernel that idles for ~150 us goes first, then an asynchronous copy
+// from a pinned buffer, and the call returns at once -- like the real library, whose data lands when the stream gets
+// there.  A caller that forgets to order its next kernel behind the communication stream (a missing or wrong event)
+// reads stale rows and fails the bit-for-bit comparison instead of being saved by a blocking copy.
+__global__ void k_idle(long long ticks)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+struct Pending { void *pinned; hipEvent_t done; };
+std::vector<Pending> g_pending;
+
+void reap(bool all)
+{
+    for (size_t i = 0; i < g_pending.size();) {
+        if (all) (void)hipEventSynchronize(g_pending[i].done);
+        if (all || hipEventQuery(g_pending[i].done) == hipSuccess) {
+            (void)hipEventDestroy(g_pending[i].done);
+            (void)hipHostFree(g_pending[i].pinned);
+            g_pending[i] = g_pending.back();
+            g_pending.pop_back();
+        } else ++i;
+    }
+}
+
+int deliver(void *dev, const void *host, size_t bytes, hipStream_t st)
+{
+    reap(false);
+    if (!bytes) return 0;
+    void *pin = nullptr;
+    hipEvent_t ev;
+    if (hipHostMalloc(&pin, bytes, hipHostMallocDefault) != hipSuccess) return 1;
+    memcpy(pin, host, bytes);
+    k_idle<<<1, 1, 0, st>>>(15000);                                       // wall_clock64 ticks at 100 MHz: ~150 us
+    if (hipMemcpyAsync(dev, pin, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return 1;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, st) != hipSuccess) return 1;
+    g_pending.push_back({pin, ev});
+    return 0;
+}
 thread_local int g_group = 0;
 thread_local std::vector<P2P> g_ops;
 thread_local Comm *g_group_comm = nullptr;
@@ -129,7 +170,7 @@ int run_p2p(Comm *c, std::vector<P2P> &ops)
         if (busy && !spin(c->h->failed, t0)) { c->h->failed.store(1); g_last = "mock rccl: send/recv timed out"; return 1; }
     }
     for (size_t i = 0; i < ops.size(); ++i)
-        if (!ops[i].send && ops[i].bytes && hipMemcpy(ops[i].dev, st[i].host.data(), ops[i].bytes, hipMemcpyHostToDevice) != hipSuccess) return 1;
+        if (!ops[i].send && deliver(ops[i].dev, st[i].host.data(), ops[i].bytes, ops[i].st)) return 1;
     return 0;
 }
 
@@ -197,6 +238,7 @@ int ncclCommDestroy(void *comm)
 {
     Comm *c = (Comm *)comm;
     if (!c) return 0;
+    reap(true);
     if (c->h->attached.fetch_sub(1) == 1) shm_unlink(c->name);
     munmap((void *)c->h, c->map_bytes);
     delete c;
@@ -218,8 +260,7 @@ int ncclAllReduce(const void *send, void *recv, size_t count, int dtype, int op,
         for (size_t i = 0; i < n / 8; ++i) a[i] = r == 0 ? x[i] : (op == 0 ? a[i] + x[i] : (x[i] > a[i] ? x[i] : a[i]));
     });
     if (rc) return 1;
-    if (count && hipMemcpy(recv, acc.data(), count * 8, hipMemcpyHostToDevice) != hipSuccess) return 1;
-    return 0;
+    return deliver(recv, acc.data(), count * 8, st);
 }
 
 int ncclAllGather(const void *send, void *recv, size_t count, int dtype, void *comm, hipStream_t st)
@@ -233,8 +274,7 @@ int ncclAllGather(const void *send, void *recv, size_t count, int dtype, void *c
         memcpy((char *)all.data() + (size_t)r * count * 8 + off, chunk, n);
     });
     if (rc) return 1;
-    if (count && hipMemcpy(recv, all.data(), all.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return 1;
-    return 0;
+    return deliver(recv, all.data(), all.size() * 8, st);
 }
 
 int ncclBroadcast(const void *send, void *recv, size_t count, int dtype, int root, void *comm, hipStream_t st)
@@ -248,8 +288,7 @@ int ncclBroadcast(const void *send, void *recv, size_t count, int dtype, int roo
         if (r == root) memcpy((char *)out.data() + off, chunk, n);
     });
     if (rc) return 1;
-    if (count && hipMemcpy(recv, out.data(), count * 8, hipMemcpyHostToDevice) != hipSuccess) return 1;
-    return 0;
+    return deliver(recv, out.data(), count * 8, st);
 }
 
 int ncclGroupStart() { ++g_group; return 0; }

@@ -6,7 +6,10 @@ exercises and that the single-process tests cannot reach: the file rendezvous of
 world > 1, the real-rank branch of the block rotation (send to g - 1 / receive from g + 1 inside one group on the
 transfer stream, events both ways), its rank-ordered squared-error all-gather and the home-rank broadcasts of
 get_factors, the item-delta all-reduce of the averaging mode, row-sharded ALS, and bench.py's whole N > 1 path.
-Every result must equal the single-process fake world's bit for bit (which the other tests tie to the oracle)."""
+Every result must equal the single-process fake world's bit for bit (which the other tests tie to the oracle).
+The stand-in delivers results LATE and asynchronously in stream order (an idling kernel, then an async copy), so a
+missing or wrong event between the transfer stream and the compute stream reads stale rows: with the wait on
+`arrived[j]` removed from mfx_dsgd_run_kmf two of the three rotation cases fail (checked by hand, round 2)."""
 import json
 import os
 import subprocess

@@ -83,6 +83,20 @@ elif mode == "avg":
     u, v, ib, ub = s.get_local()
     res = dict(u=u, v=v[:, :s.nu_local], ib=ib, ub=ub[:s.nu_local], se=np.asarray(se), lo=s.user_lo, hi=s.user_lo + s.nu_local)
     s.close()
+elif mode == "funk":
+    from mfrec_amd.plan import SgdPlan
+    rs = np.random.RandomState(4)
+    cells = rs.permutation(NU * NI)[:60000]                      # no duplicate (user, item) pairs
+    fidx = np.stack([cells %% NU, cells // NU], 1).astype(np.int32)
+    fr = rs.randint(1, 6, len(cells)).astype(np.float64)
+    bounds = SH.user_blocks(fidx, NU, world)
+    sidx, sr, lo, n = SH.shard(fidx, fr, bounds, rank)
+    u, v = synth.init_const(5, NI), synth.init_const(5, max(n, 1))
+    with SgdPlan(sidx, sr, max(n, 1), NI, 5) as p:
+        p.set_factors(u, v)
+        hist = p.run_funk_sharded(2, 1e9, 0.1, 0.01, 0.05, scale=1.0 / world)
+        p.get_factors(u, v)
+    res = dict(u=u, v=v[:, :n], hist=np.asarray(hist), lo=lo, hi=lo + n)
 elif mode == "als":
     import scipy.sparse as sp
     from mfrec_amd.lib.als_implicit import als_wrmf_sharded
@@ -165,6 +179,44 @@ def test_averaging_mode_over_real_processes_equals_the_fake_world(mock_lib, tmp_
         lo, hi = int(z["lo"]), int(z["hi"])
         assert np.array_equal(z["u"], u) and np.array_equal(z["ib"], ib)
         assert np.array_equal(z["v"], v[:, lo:hi]) and np.array_equal(z["ub"], ub[lo:hi])
+
+
+def test_sharded_funk_pass_over_real_processes_equals_its_simulation(mock_lib, tmp_path):
+    """The per-(feature, epoch) delta / all-reduce / combine of the sharded Funk trainer with two real ranks against
+    its CPU simulation: every shard runs the oracle's epoch from the common item vector, the deltas are added in
+    rank order and combined with scale 1/2 (gd_estimator.pyx:742-777 per shard; sharding.combine)."""
+    from mfrec_amd import sharding as SH
+    from oracle import oracle as O
+    world, k, E = 2, 5, 2
+    res = _launch(mock_lib, tmp_path, world, "funk", 29751)
+    rs = np.random.RandomState(4)
+    cells = rs.permutation(NU * NI)[:60000]
+    fidx = np.stack([cells % NU, cells // NU], 1).astype(np.int32)
+    fr = rs.randint(1, 6, len(cells)).astype(np.float64)
+    bounds = SH.user_blocks(fidx, NU, world)
+    shards = [SH.shard(fidx, fr, bounds, g) for g in range(world)]
+    U = synth.init_const(k, NI)
+    V = [synth.init_const(k, max(n, 1)) for _, _, _, n in shards]
+    cache = [np.zeros(max(n, 1) * NI) for _, _, _, n in shards]
+    hist = []
+    for f in range(k):
+        for _ in range(E):
+            start = U[f].copy()
+            dsum, se = None, 0.0
+            for g, (sidx, sr, lo, n) in enumerate(shards):
+                Ug = U.copy()
+                rm = O.estimator_subloop(f, 1, 0.0, k, 0.1, 0.01, 0.05, Ug, V[g], sidx, sr, cache[g], max(n, 1), NI)
+                se += rm * rm * len(sr)
+                d = Ug[f] - start
+                dsum = d if dsum is None else dsum + d
+            U[f] = SH.combine(start, dsum, 1.0 / world)
+            hist.append(np.sqrt(se / len(fr)))
+        for g, (sidx, sr, lo, n) in enumerate(shards):
+            O.predictor_subloop(f, 1, k, 0.1, U, V[g], sidx, sr, cache[g], max(n, 1), NI)
+    for g, z in enumerate(res):
+        n = shards[g][3]
+        assert np.array_equal(z["u"], U) and np.array_equal(z["v"], V[g][:, :n])
+        np.testing.assert_allclose(z["hist"][:len(hist)], hist, rtol=1e-11)
 
 
 def test_row_sharded_als_over_real_processes_equals_one_process(mock_lib, tmp_path):

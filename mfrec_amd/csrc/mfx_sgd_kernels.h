@@ -762,13 +762,21 @@ __global__ __launch_bounds__((kXWorkers + 1) * 64) void k2_xcd_pass(K2XParams P)
         Rec rec;
         double cache;
     };
+    // the segment bounds of my first group for the level about to open are read together with the prefetch, one level
+    // ahead of their use: a scalar load in front of every part sat on the level's critical path (same-process A/B,
+    // MFX_K2_TUNE bit 4 = the old way: 1.536 -> 1.431 ms per shuffled pass, 1.052 -> 1.039 balanced).  Two further
+    // steps -- bounds two levels ahead in a three-way rotation, and a prefetch of the EARLY part's first chunk -- each
+    // pushed the kernel (106 SGPRs: the limit) into scratch memory and cost 10-60 %: reverted.
+    int nb_level = -1, nb_off = 0, nb_mid = 0, nb_next = 0;
     auto fetch_first_late = [&](int l, Pre &x) {
         x.cache = 0.0;
         x.rec.user = 0; x.rec.item = 0; x.rec.r = 0.0;
         if (l < P.n_levels && (int)slot < NG) {
             const int q = l * NG + (int)slot;
-            const int t = P.seg_off[q] + worker * 64 + lane;
-            if (worker >= 0 && t < P.seg_mid[q]) {
+            const int o = P.seg_off[q], m = P.seg_mid[q];
+            if (!(P.tune & 4)) { nb_level = l; nb_off = o; nb_mid = m; nb_next = P.seg_off[q + 1]; }
+            const int t = o + worker * 64 + lane;
+            if (worker >= 0 && t < m) {
                 x.rec = P.recs[t];
                 x.cache = P.cache[t];
             }
@@ -780,7 +788,14 @@ __global__ __launch_bounds__((kXWorkers + 1) * 64) void k2_xcd_pass(K2XParams P)
         for (int g = slot; g < NG; g += nx, ++gi) {
             const int lo = glo(g);
             const int q = l * NG + g;
-            const int s0 = late ? P.seg_off[q] : P.seg_mid[q], s1 = late ? P.seg_mid[q] : P.seg_off[q + 1];
+            int s0, s1;
+            if (gi == 0 && nb_level == l) {
+                s0 = late ? nb_off : nb_mid;
+                s1 = late ? nb_mid : nb_next;
+            } else {
+                s0 = late ? P.seg_off[q] : P.seg_mid[q];
+                s1 = late ? P.seg_mid[q] : P.seg_off[q + 1];
+            }
             for (int tb = s0 + worker * 64; tb < s1; tb += kXWorkers * 64) {      // wave-uniform
                 const int t = tb + lane;
                 if (t < s1) {

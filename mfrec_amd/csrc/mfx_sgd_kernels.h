@@ -706,7 +706,10 @@ __global__ __launch_bounds__((kXWorkers + 1) * 64) void k2_xcd_pass(K2XParams P)
     if (slot >= nx) return;
     unsigned *flags = P.ctl + 1024;
     double *const uf = P.dyn->uf, *const vf = P.dyn->vf;
-    const double trail = P.dyn->trail, lr = P.lr, K = P.K;
+    double trail = P.dyn->trail, lr = P.lr, K = P.K, mu = P.mu;
+    // uniform, but kept in VECTOR registers on purpose: the kernel sits at the SGPR limit (the per-level prefetch state
+    // is uniform), and a spill to scratch memory costs 10-60 % (measured); 54 of 128 VGPRs are in use
+    asm volatile("" : "+v"(trail), "+v"(lr), "+v"(K), "+v"(mu));
     const int NG = kXGroups, nu = P.nu;
     auto glo = [nu](int g) { return (int)(((int64_t)nu * g + kXGroups - 1) / kXGroups); };   // first user of group g
     // (group(u) = u * NG / nu  <=>  u in [ceil(nu * g / NG), ceil(nu * (g+1) / NG)))
@@ -764,27 +767,35 @@ __global__ __launch_bounds__((kXWorkers + 1) * 64) void k2_xcd_pass(K2XParams P)
     };
     // the segment bounds of my first group for the level about to open are read together with the prefetch, one level
     // ahead of their use: a scalar load in front of every part sat on the level's critical path (same-process A/B,
-    // MFX_K2_TUNE bit 4 = the old way: 1.536 -> 1.431 ms per shuffled pass, 1.052 -> 1.039 balanced).  Two further
-    // steps -- bounds two levels ahead in a three-way rotation, and a prefetch of the EARLY part's first chunk -- each
-    // pushed the kernel (106 SGPRs: the limit) into scratch memory and cost 10-60 %: reverted.
+    // MFX_K2_TUNE bit 4 = the old way: 1.580 -> 1.466 ms per shuffled pass), and so is the first chunk of the EARLY part
+    // of that level (bit 8 = off: 1.466 -> 1.354 ms), which runs right behind barrier A with a ~1 us record load in front
+    // otherwise.  Two traps on the way, both measured: a prefetch struct handed to run_part through a pointer that may
+    // be null is pinned in scratch memory (+10-60 %), and so is per-level state kept in an indexed array.
     int nb_level = -1, nb_off = 0, nb_mid = 0, nb_next = 0;
-    auto fetch_first_late = [&](int l, Pre &x) {
+    const bool pre_early = !(P.tune & (2 | 4 | 8));      // bit 8: no prefetch of the early part's first chunk
+    auto fetch_first_late = [&](int l, Pre &x, Pre &e) {
         x.cache = 0.0;
         x.rec.user = 0; x.rec.item = 0; x.rec.r = 0.0;
+        e = x;
         if (l < P.n_levels && (int)slot < NG) {
             const int q = l * NG + (int)slot;
-            const int o = P.seg_off[q], m = P.seg_mid[q];
-            if (!(P.tune & 4)) { nb_level = l; nb_off = o; nb_mid = m; nb_next = P.seg_off[q + 1]; }
+            const int o = P.seg_off[q], m = P.seg_mid[q], nx_ = P.seg_off[q + 1];
+            if (!(P.tune & 4)) { nb_level = l; nb_off = o; nb_mid = m; nb_next = nx_; }
             const int t = o + worker * 64 + lane;
             if (worker >= 0 && t < m) {
                 x.rec = P.recs[t];
                 x.cache = P.cache[t];
             }
+            const int te = m + worker * 64 + lane;       // early(l) runs right behind barrier A: its records too
+            if (pre_early && worker >= 0 && te < nx_) {
+                e.rec = P.recs[te];
+                e.cache = P.cache[te];
+            }
         }
     };
-    auto run_part = [&](int l, bool late, const Pre *pre) {
-        int base = 0, gi = 0;
-        bool first = pre != nullptr;
+    auto run_part = [&](int l, bool late, const Pre &pre, bool have) {   // (a pointer that may be null would pin the
+        int base = 0, gi = 0;                                            //  struct in scratch memory: measured)
+        bool first = have;
         for (int g = slot; g < NG; g += nx, ++gi) {
             const int lo = glo(g);
             const int q = l * NG + g;
@@ -799,11 +810,11 @@ __global__ __launch_bounds__((kXWorkers + 1) * 64) void k2_xcd_pass(K2XParams P)
             for (int tb = s0 + worker * 64; tb < s1; tb += kXWorkers * 64) {      // wave-uniform
                 const int t = tb + lane;
                 if (t < s1) {
-                    const Rec rec = first ? pre->rec : P.recs[t];
-                    const double c = first ? pre->cache : P.cache[t];
+                    const Rec rec = first ? pre.rec : P.recs[t];
+                    const double c = first ? pre.cache : P.cache[t];
                     double bs;
-                    if (P.ib) bs = P.mu + P.ib[rec.item] + P.ub[rec.user];
-                    else bs = P.mu + 0.0 + 0.0;
+                    if (P.ib) bs = mu + P.ib[rec.item] + P.ub[rec.user];
+                    else bs = mu + 0.0 + 0.0;
                     const double mf = __hip_atomic_load(uf + rec.item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const double cf = vlds[base + rec.user - lo];
                     const double p = funk_estimate(mf, cf, c, bs, trail, true);
@@ -820,17 +831,17 @@ __global__ __launch_bounds__((kXWorkers + 1) * 64) void k2_xcd_pass(K2XParams P)
         }
     };
     // (requesting it two levels ahead instead of one: measured neutral)
-    Pre cur;
+    Pre cur, pe;
     if (worker >= 0) {
-        run_part(0, false, nullptr);                     // level 0 has no late ratings: all of it is early
-        fetch_first_late(0, cur);                        // (empty; keeps the loop uniform)
+        run_part(0, false, cur, false);                  // level 0 has no late ratings: all of it is early
+        fetch_first_late(0, cur, pe);                    // (empty; keeps the loop uniform)
     }
     for (int l = 0; l < P.n_levels; ++l) {
         if (worker >= 0) {
-            run_part(l, true, &cur);                              // late(l): needs barrier l - 1, which has passed
-            if ((P.tune & 2) && l > 0) run_part(l, false, nullptr);
+            run_part(l, true, cur, true);                         // late(l): needs barrier l - 1, which has passed
+            if ((P.tune & 2) && l > 0) run_part(l, false, cur, false);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my stores of level l (late and early) are in L2
-            fetch_first_late(l + 1, cur);
+            fetch_first_late(l + 1, cur, pe);
         }
         // level l is complete in this workgroup: signal; while the flags travel, the workers run early(l + 1)
         __syncthreads();                                          // A
@@ -847,7 +858,7 @@ __global__ __launch_bounds__((kXWorkers + 1) * 64) void k2_xcd_pass(K2XParams P)
                 }
             }
         } else if (worker >= 0 && l + 1 < P.n_levels && !(P.tune & 2)) {
-            run_part(l + 1, false, nullptr);                      // early(l + 1): items final since level l - 1
+            run_part(l + 1, false, pe, pre_early);                // early(l + 1): items final since level l - 1
         }
         __syncthreads();                                          // B
         if (ld_sc1_u32(P.ctl + 512)) return;

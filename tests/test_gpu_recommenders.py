@@ -472,3 +472,42 @@ def test_fused_top_n_with_more_than_one_feature_chunk(k, monkeypatch):
     for user in (0, 33, 69):
         wi, ws = R.find_recommended_items(user_index=user, nbr_recommendations=7, predictor="predict_logistic")
         assert list(fi[user]) == wi and np.array_equal(fs[user], np.array(ws))
+
+
+def test_topn_batch_argument_checks_and_unsorted_rated_lists():
+    """mfx_topn_batch refuses malformed arguments with MFX_E_ARG, and rated lists that are not ascending (the fused
+    kernel searches them) silently take the sort path -- same answer."""
+    import ctypes as C
+    from mfrec_amd import _shim as S
+    k, ni, nsel, N = 4, 50, 3, 5
+    rs = np.random.RandomState(1)
+    u, v = rs.normal(0, 1, (k, ni)), rs.normal(0, 1, (k, nsel))
+    users = np.array([0, 1, 2], dtype=np.int32)
+    off = np.array([0, 3, 3, 5], dtype=np.int64)
+    rated_sorted = np.array([4, 9, 30, 1, 2], dtype=np.int32)
+    rated_shuffled = np.array([30, 4, 9, 2, 1], dtype=np.int32)
+
+    def call(kind=4, n_cand=ni, n=N, rated=rated_sorted, offs=off):
+        items = np.full((nsel, max(n, 1)), -7, dtype=np.int32)
+        scores = np.zeros((nsel, max(n, 1)))
+        rc = S.lib().mfx_topn_batch(kind, k, S.f64(u, "u", 2), S.f64(v, "v", 2), None, None, 0.0, ni,
+                                    S.i32(users, "users", 1), nsel, n_cand, n, offs.ctypes.data_as(S._lp),
+                                    S.i32(rated, "rated", 1), S.i32(items, "items", 2), S.f64(scores, "scores", 2))
+        return rc, items, scores
+
+    rc, a_items, a_scores = call()
+    assert rc == 0
+    st0 = (C.c_int64 * 2)(); S.check(S.lib().mfx_topn_stats(st0))
+    rc, b_items, b_scores = call(rated=rated_shuffled)
+    st1 = (C.c_int64 * 2)(); S.check(S.lib().mfx_topn_stats(st1))
+    assert rc == 0 and np.array_equal(a_items, b_items) and np.array_equal(a_scores, b_scores)
+    assert (st1[0], st1[1]) == (st0[0], st0[1])                       # not the fused kernel's business
+    for j, banned in enumerate(({4, 9, 30, 0}, {1}, {1, 2})):         # rated items and the item named like the user
+        assert not (set(a_items[j].tolist()) & banned)
+        full = u.T @ v[:, j]
+        want = [i for i in np.argsort(-full, kind="stable") if i not in banned and full[i] != 0.0][:N]
+        assert a_items[j].tolist() == want
+    for bad in (dict(kind=5), dict(kind=1), dict(n_cand=ni + 1), dict(n_cand=0), dict(n=0),
+                dict(offs=np.array([1, 3, 3, 5], dtype=np.int64)), dict(offs=np.array([0, 3, 2, 5], dtype=np.int64))):
+        rc, _, _ = call(**bad)
+        assert rc != 0 and "mfx_topn_batch" in S.last_error()

@@ -10,7 +10,8 @@
 // scalar part, thread 0 applies the u / v updates, all threads share the y updates; two workgroup barriers per
 // rating.  The three feature vectors live in LDS when they fit (2 ni + nu doubles <= 150 KB: MovieLens-100K
 // does), else in global memory behind sc1 loads.  A legal call is served with the reference's exact bits;
-// it is NOT fast and cannot be: 0.6 us per rating with the vectors in LDS against 0.06-0.09 us for the
+// it is NOT fast and cannot be: 0.52-0.57 us per rating with the vectors in LDS (0.61 before 1 / sqrt(count) became a
+// per-user table; a single wave without barriers: 0.66-0.87) against 0.07-0.09 us for the
 // reference's own C loop on one host core (tools/svdpp_timing.py: MovieLens-100K / -1M shapes) -- a chain of
 // two workgroup barriers per rating is what a GPU has to offer a sequential loop.  Documented as such.
 #include <math.h>
@@ -25,6 +26,7 @@ struct SParams {
     const int32_t *rated_item; // [n_rated]: column 1 of `rated`
     const int2 *hash;          // [nu]: (first row of the user in `rated`, count)
     const double *ib, *ub;
+    const double *norm;        // [nu]: 1 / sqrt(count) (gd_estimator.pyx:853-854), formed once per call
     double *uf, *vf, *yf;      // U[f,:], V[f,:], y[f,:] (feature-major rows of the host layout)
     double *cache;             // [nnz]
     double *se_out;
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(kSThreads) void k_svdpp_epoch(SParams P)
             x.r = P.r[t];
             x.c = P.cache[t];
             x.base = P.mu + P.ib[ui.y] + P.ub[ui.x];
-            x.norm = 1.0 / sqrt((double)x.h.y);                              // :853-854, off the chain
+            x.norm = P.norm[ui.x];                                           // :853-854: same operations, once per user
             if (tid < x.h.y) x.jj = P.rated_item[x.h.x + tid];
         }
     };
@@ -128,6 +130,14 @@ __global__ __launch_bounds__(kSThreads) void k_svdpp_epoch(SParams P)
         for (int i = tid; i < P.nu; i += kSThreads) P.vf[i] = sh[P.ni + i];
     }
     if (tid == 0) *P.se_out = se;
+}
+
+// 1 / sqrt(count) per user: the reference forms it for every rating (:853-854); it only depends on the user, and the
+// division + square root cost ~60 instructions of every wave's in-order stream per rating
+__global__ __launch_bounds__(256) void k_svdpp_norm(const int2 *hash, int nu, double *norm)
+{
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u < nu) norm[u] = hash[u].y > 0 ? 1.0 / sqrt((double)hash[u].y) : 0.0;
 }
 
 // cache commit (:891-896): no implicit term, no trailing term
@@ -193,12 +203,12 @@ extern "C" int mfx_funk_implicit(int min_epochs, double min_improvement, int dim
         if (n_hist) *n_hist = n;
         return MFX_OK;
     }
-    Buf dU, dV, dY, dIdx, dR, dRi, dHash, dIb, dUb, dCache, dSe;
+    Buf dU, dV, dY, dIdx, dR, dRi, dHash, dIb, dUb, dCache, dSe, dNorm;
     const size_t su = (size_t)dim * ni * 8, sv = (size_t)dim * nu * 8;
     if ((rc = dU.get(su)) || (rc = dV.get(sv)) || (rc = dY.get(su)) || (rc = dIdx.get((size_t)nnz * 8)) ||
         (rc = dR.get((size_t)nnz * 8)) || (rc = dRi.get((size_t)n_rated * 4)) || (rc = dHash.get((size_t)nu * 8)) ||
         (rc = dIb.get((size_t)ni * 8)) || (rc = dUb.get((size_t)nu * 8)) || (rc = dCache.get((size_t)nnz * 8)) ||
-        (rc = dSe.get(8)))
+        (rc = dSe.get(8)) || (rc = dNorm.get((size_t)nu * 8)))
         return rc;
     hipStream_t s = mfx::stream();
     MFX_HIP(hipMemcpy(dU.p, u, su, hipMemcpyHostToDevice));
@@ -215,6 +225,9 @@ extern "C" int mfx_funk_implicit(int min_epochs, double min_improvement, int dim
     P.idx = dIdx.as<int2>(); P.r = dR.as<double>(); P.rated_item = dRi.as<int32_t>(); P.hash = dHash.as<int2>();
     P.ib = dIb.as<double>(); P.ub = dUb.as<double>(); P.cache = dCache.as<double>(); P.se_out = dSe.as<double>();
     P.nnz = nnz; P.nu = nu; P.ni = ni; P.lr = lr; P.K = K; P.mu = mu;
+    P.norm = dNorm.as<double>();
+    hipLaunchKernelGGL(k_svdpp_norm, dim3((nu + 255) / 256), dim3(256), 0, s, P.hash, nu, dNorm.as<double>());
+    MFX_HIP(hipGetLastError());
     const size_t lds = ((size_t)2 * ni + nu) * sizeof(double);
     const bool use_lds = lds <= 150 * 1024;
     if (use_lds && lds > 64 * 1024)

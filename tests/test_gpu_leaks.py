@@ -57,6 +57,15 @@ def _round():
     d.set_factors(u0, v0, np.zeros(ni), np.zeros(nu))
     d.train(0, 1, 0.01, 0.1, 0.1, 0.007)
     d.close()
+    # batched top-N: fused kernel and sort path
+    from mfrec_amd.recommendation import KMFRecommender
+    R = KMFRecommender(4, 6, {"nbr_features": k})
+    R._nbr_users, R._nbr_items = nu, ni
+    R.relationship_matrix = sp.csr_matrix((r[s], (idx[s, 0], idx[s, 1])), shape=(nu, ni)).tolil()
+    R.svd_u, R.svd_v, R.items_bias, R.users_bias, R.overall_bias = u0, v0, np.zeros(ni), np.zeros(nu), 3.0
+    R.neighborhood = ni
+    R.find_recommended_items_batch(np.arange(2000), 10, "predict_linear")
+    R.find_recommended_items_batch(np.arange(500), 20, "predict_linear")
     # ALS: tuned kernel and the k > 128 scratch kernel
     M = sp.csr_matrix((np.ones(200000), (idx[s, 0] % 5000, idx[s, 1] % 3000)), shape=(5000, 3000))
     M.sum_duplicates()

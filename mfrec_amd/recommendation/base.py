@@ -25,8 +25,9 @@ class BaseRecommender(object):
         self.min_rating, self.max_rating = 1.0, 5.0   # base.py:92-93
         self._nbr_users, self._nbr_items = int(nbr_users), int(nbr_items)
         self.relationship_matrix = None
-        self.relationship_matrix_csc = None
+        self._csc, self._csc_due = None, False
         self.relationship_matrix_csr = None
+        self.items_feedback = self.feedback_rated = self.feedback_hash = None
         self.svd_u = self.svd_v = self.svd_s = None
         self.users_bias = self.items_bias = self.overall_bias = None
         # label <-> index maps of the reference's container (base.py:96-101): label LISTS indexed by id,
@@ -44,6 +45,23 @@ class BaseRecommender(object):
         for user in range(nbr_users):
             self.users_label.append("user" + str(user))
             self.users_index["user" + str(user)] = user
+
+    @property
+    def relationship_matrix_csc(self):
+        """items x users CSC view of the ratings (the trainers set `relationship_matrix.T.tocsc()`, kmf.py:207,
+        wrmf.py:88).  Formed on first use after a train() -- at 10^7 ratings the conversion costs more than the
+        training it precedes."""
+        if self._csc is None and self._csc_due:
+            self._csc = self.relationship_matrix.T.tocsc()
+            self._csc_due = False
+        return self._csc
+
+    @relationship_matrix_csc.setter
+    def relationship_matrix_csc(self, value):
+        self._csc, self._csc_due = value, False
+
+    def _mark_csc_due(self):
+        self._csc, self._csc_due = None, True
 
     @property
     def nbr_users(self):
@@ -172,6 +190,22 @@ class BaseRecommender(object):
         elif randomize_order:
             np.random.shuffle(order)
         return np.ascontiguousarray(ratings_index[order]), np.ascontiguousarray(ratings[order])
+
+    def get_feedback(self):
+        """base.py:269-296: the rated (user, item) pairs in COO order of the boolean ratings matrix
+        (users ascending, items ascending) and, per user, (first row, count) -- (-1, -1) for a user without ratings."""
+        coo = self.relationship_matrix.tocoo()
+        keep = coo.data != 0
+        pairs = np.stack([coo.row[keep], coo.col[keep]], axis=1).astype(np.int32)
+        pairs = pairs[np.lexsort((pairs[:, 1], pairs[:, 0]))]
+        counts = np.bincount(pairs[:, 0], minlength=self.nbr_users).astype(np.int64)
+        first = np.concatenate([[0], np.cumsum(counts)[:-1]])
+        rated_hash = np.stack([np.where(counts > 0, first, -1), np.where(counts > 0, counts, -1)], axis=1).astype(np.int32)
+        return np.ascontiguousarray(pairs), np.ascontiguousarray(rated_hash)
+
+    def initialize_rated_feedback(self):                                      # base.py:261-263
+        self.N = self.relationship_matrix.astype(bool)
+        self.feedback_rated, self.feedback_hash = self.get_feedback()
 
     def get_items_subset(self, count=100, method="random"):
         """base.py:1134-1145: `count` item ids of a shuffle drawn from the global numpy RNG."""

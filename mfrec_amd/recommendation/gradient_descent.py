@@ -136,21 +136,6 @@ class GDRecommender(MFRecommender):
             total = self.clamping(total)
         return total
 
-    def get_feedback(self):
-        """gradient_descent.py:269-296: the rated (user, item) pairs in COO order of the boolean ratings matrix
-        (users ascending, items ascending) and, per user, (first row, count) -- (-1, -1) for a user without ratings."""
-        coo = self.relationship_matrix.tocoo()
-        keep = coo.data != 0
-        pairs = np.stack([coo.row[keep], coo.col[keep]], axis=1).astype(np.int32)
-        pairs = pairs[np.lexsort((pairs[:, 1], pairs[:, 0]))]
-        counts = np.bincount(pairs[:, 0], minlength=self.nbr_users).astype(np.int64)
-        first = np.concatenate([[0], np.cumsum(counts)[:-1]])
-        rated_hash = np.stack([np.where(counts > 0, first, -1), np.where(counts > 0, counts, -1)], axis=1).astype(np.int32)
-        return np.ascontiguousarray(pairs), np.ascontiguousarray(rated_hash)
-
-    def initialize_rated_feedback(self):                                      # :261-263
-        self.feedback_rated, self.feedback_hash = self.get_feedback()
-
     def feature_training_implicit(self, initialize_model=True, verbose=False):
         """gradient_descent.py:547-574: the SVD++-like trainer (sequential by nature; see lib.gd_estimator)."""
         if initialize_model:
@@ -179,6 +164,7 @@ class GDRecommender(MFRecommender):
     def find_user_top_match(self, user_index, nbr_recommendations=5):
         """gradient_descent.py:768-800: every item scored with predict_rating, the user's rated items and the item
         whose id equals user_index excluded, zero scores dropped -> (items, scores)."""
+        self._mark_csc_due()                         # :777
         return self._top_items(user_index, self.nbr_items, "predict_rating", nbr_recommendations)
 
     def predict_rating_implicit(self, item_index, user_index):

@@ -48,6 +48,7 @@ class KMFRecommender(MFRecommender):
         """kmf.py:197-220: N(0, 0.1) init, shuffled ratings, zero biases, one kernel call."""
         if kernel not in ("train_logistic_kernel", "train_linear_kernel"):
             raise NameError("name '%s' is not defined" % kernel)     # the reference eval()s the name
+        self._mark_csc_due()                         # kmf.py:207 (relationship_matrix_csc: formed on first use)
         if initialize_model:
             self.init_feature_normal(0.0, 0.1)
         # order=True: the reference's shuffle; order="balanced": fewest dependency levels (extension)

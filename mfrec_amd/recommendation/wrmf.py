@@ -31,6 +31,13 @@ class WRMFRecommender(MFRecommender):
         """Preference score = plain dot product of the two factor columns (wrmf.py:67-69)."""
         return np.dot(self.svd_u[:, item_index], self.svd_v[:, user_index])
 
+    def predict_rating_by_label(self, user_label, item_label):
+        """wrmf.py:72-80: the dot product by labels; an unknown label scores 0.0."""
+        try:
+            return np.dot(self.svd_u[:, self.items_index[item_label]], self.svd_v[:, self.users_index[user_label]])
+        except KeyError:
+            return 0.0
+
     def _run_length_views(self):
         rows = create_bool_sparse_row(self.relationship_matrix)
         cols = create_bool_sparse_col(self.relationship_matrix)
@@ -39,8 +46,12 @@ class WRMFRecommender(MFRecommender):
     def train(self, initialize_model=True, handle_bias=False, verbose=False, sharded=False):
         """One als_wrmf call over `nbr_epochs` user/item half-passes (wrmf.py:83-110).
         sharded=True: this process is one rank of an initialised RCCL communicator."""
+        self._mark_csc_due()                  # wrmf.py:88 (relationship_matrix_csc: formed on first use)
         if initialize_model:
             self.init_feature_const()
+        # wrmf.py:98-99 also rebuilds the rated-feedback tables here although the ALS solver never reads them (two
+        # Python loops over every rating); they are built on demand by initialize_rated_feedback()
+        self.items_feedback = np.zeros([self.dimensionality, self.nbr_items])
         k = self.dimensionality
         scratch = np.zeros([k, k])            # the reference's m / m_inv arguments (unused here)
         users_row, users_col, items_row, items_col = self._run_length_views()

@@ -511,3 +511,18 @@ def test_topn_batch_argument_checks_and_unsorted_rated_lists():
                 dict(offs=np.array([1, 3, 3, 5], dtype=np.int64)), dict(offs=np.array([0, 3, 2, 5], dtype=np.int64))):
         rc, _, _ = call(**bad)
         assert rc != 0 and "mfx_topn_batch" in S.last_error()
+
+
+def test_reference_example_flow_runs_end_to_end():
+    """examples/example1b_synthetic_wrmf.py = the reference's own example script (mfrec/examples/
+    example1b_movielens_100k_wrmf.py) with synthetic MovieLens-100K-shaped data: same calls, same order."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", "example1b_synthetic_wrmf.py")],
+                         capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "Precision @ 5" in out.stdout and "F-Measure" in out.stdout and "Epoch : 29" in out.stdout
+    lines = [l for l in out.stdout.splitlines() if l.startswith("(")]
+    assert len(lines) == 2 and lines[0] == lines[1]                  # per-user loop == batched evaluation

@@ -156,9 +156,10 @@ __device__ __forceinline__ void store16_sc1(TS *p, typename Chunk16<TS>::type c)
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
-template <int KP, int FPL, int BATCH, int MODE, int NT, bool FULL, typename TS, bool VEC = false, int DOT = 0>
+// PRE: the lane's record comes in `pre` (requested one level ahead by k1_tail) instead of being loaded here
+template <int KP, int FPL, int BATCH, int MODE, int NT, bool FULL, typename TS, bool VEC = false, int DOT = 0, bool PRE = false>
 __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cnt, int64_t base,
-                                        int64_t slot, double *prod, int lane)
+                                        int64_t slot, double *prod, int lane, Rec pre = Rec())
 {
     constexpr int SPW = 64 / KP;
     constexpr int NR = BATCH / SPW;
@@ -174,7 +175,9 @@ __device__ __forceinline__ void k1_body(const K1Params &P, int64_t start, int cn
     // ---- the rating owned by this lane (lanes 0..cnt-1) -------------------------------
     Rec rec;
     rec.user = 0; rec.item = 0; rec.r = 0.0;
-    if (FULL ? (lane < BATCH) : (lane < cnt)) {
+    if constexpr (PRE) {
+        rec = pre;
+    } else if (FULL ? (lane < BATCH) : (lane < cnt)) {
         // records are read once per epoch: non-temporal, so that the stream does not displace factor
         // rows from L2 / Infinity Cache (cfg 2 +0.1 %, cfg-3 shard shape +2.5 %, cfg-5 shard shape +0.6 %)
         typedef int v4i32 __attribute__((ext_vector_type(4)));
@@ -502,23 +505,41 @@ __global__ __launch_bounds__(kTailWaves * 64) void k1_tail(K1Params P, const int
     const int lane = threadIdx.x & 63;
     const int wid = threadIdx.x >> 6;
     double *prod = lds + (size_t)wid * BATCH * k1_stride(P.k);
+    // Small levels are latency chains: offsets (scalar loads) -> record -> row gathers -> stores -> barrier.  The
+    // offsets of level l + 3 and the records of level l + 1 are requested while level l runs (records never change).
+    typedef int v4i32 __attribute__((ext_vector_type(4)));
+    const int base = wid * BATCH;
+    int64_t s0 = level_off[l0], s1 = level_off[l0 + 1], w0 = wave_off[l0], w1 = wave_off[l0 + 1];
+    int64_t s2 = s1, w2 = w1;                            // level l + 1's end: read one level before it is needed
+    if (l0 + 1 < l1) { s2 = level_off[l0 + 2]; w2 = wave_off[l0 + 2]; }
+    Rec cur;
+    cur.user = 0; cur.item = 0; cur.r = 0.0;
+    if (base + lane < (int)(s1 - s0) && lane < BATCH)
+        cur = __builtin_bit_cast(Rec, __builtin_nontemporal_load(reinterpret_cast<const v4i32 *>(P.recs + s0 + base + lane)));
     for (int l = l0; l < l1; ++l) {
-        const int64_t start = level_off[l];
-        const int count = (int)(level_off[l + 1] - start);
-        const int64_t woff = wave_off[l];
-        const int nslots = (int)(wave_off[l + 1] - woff);
-        const int base = wid * BATCH;
+        const int64_t start = s0;
+        const int count = (int)(s1 - s0);
+        const int64_t woff = w0;
+        const int nslots = (int)(w1 - w0);
+        int64_t s3 = s2, w3 = w2;
+        if (l + 2 < l1) { s3 = level_off[l + 3]; w3 = wave_off[l + 3]; }
+        Rec nxt;
+        nxt.user = 0; nxt.item = 0; nxt.r = 0.0;
+        if (l + 1 < l1 && base + lane < (int)(s2 - s1) && lane < BATCH)
+            nxt = __builtin_bit_cast(Rec, __builtin_nontemporal_load(reinterpret_cast<const v4i32 *>(P.recs + s1 + base + lane)));
         if (wid < nslots) {
             if (base >= count) {
                 if (lane == 0) P.se_partial[woff + wid] = 0.0;
             } else {
                 const int cnt = (count - base) < BATCH ? (count - base) : BATCH;
                 if (cnt == BATCH && P.upd_u && P.upd_i)
-                    k1_body<KP, FPL, BATCH, MODE, NT, true, TS, VEC, DOT>(P, start, cnt, base, woff + wid, prod, lane);
+                    k1_body<KP, FPL, BATCH, MODE, NT, true, TS, VEC, DOT, true>(P, start, cnt, base, woff + wid, prod, lane, cur);
                 else
-                    k1_body<KP, FPL, BATCH, MODE, NT, false, TS, VEC, DOT>(P, start, cnt, base, woff + wid, prod, lane);
+                    k1_body<KP, FPL, BATCH, MODE, NT, false, TS, VEC, DOT, true>(P, start, cnt, base, woff + wid, prod, lane, cur);
             }
         }
+        cur = nxt;
+        s0 = s1; s1 = s2; s2 = s3; w0 = w1; w1 = w2; w2 = w3;
         __syncthreads();
     }
 }

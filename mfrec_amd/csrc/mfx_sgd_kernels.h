@@ -583,14 +583,17 @@ __device__ __forceinline__ double funk_estimate(double uf, double vf, double cac
     return sum;
 }
 
-template <bool WT = false>
+// PRE: record and cache word come in (rec0, c0), requested one level ahead by k2_tail
+template <bool WT = false, bool PRE = false>
 __device__ __forceinline__ double k2_one(const K2Params &P, double *uf, double *vf, double trail,
-                                         int64_t start, int t, int count)
+                                         int64_t start, int t, int count, Rec rec0 = Rec(), double c0 = 0.0)
 {
     double e2 = 0.0;
     if (t < count) {
-        const Rec rec = P.recs[start + t];
-        const double c = P.cache[P.slot ? (int64_t)P.slot[start + t] : start + t];
+        Rec rec;
+        double c;
+        if constexpr (PRE) { rec = rec0; c = c0; }
+        else { rec = P.recs[start + t]; c = P.cache[P.slot ? (int64_t)P.slot[start + t] : start + t]; }
         double base;
         if (P.ib) base = P.mu + P.ib[rec.item] + P.ub[rec.user];
         else base = P.mu + 0.0 + 0.0;
@@ -638,15 +641,35 @@ __global__ __launch_bounds__(kTail2) void k2_tail(K2Params P, const int64_t *lev
 {
     double *const uf = P.dyn->uf, *const vf = P.dyn->vf;
     const double trail = P.dyn->trail;
-    const int wid = threadIdx.x >> 6;
+    const int wid = threadIdx.x >> 6, t = (int)threadIdx.x;
+    // as in k1_tail: offsets two levels ahead, the next level's records and cache words (no update touches them
+    // inside a pass) requested while this level runs
+    int64_t s0 = level_off[l0], s1 = level_off[l0 + 1], w0 = wave_off[l0], w1 = wave_off[l0 + 1];
+    int64_t s2 = s1, w2 = w1;
+    if (l0 + 1 < l1) { s2 = level_off[l0 + 2]; w2 = wave_off[l0 + 2]; }
+    auto fetch = [&](int64_t st, int cnt, Rec &rc, double &c) {
+        rc.user = 0; rc.item = 0; rc.r = 0.0; c = 0.0;
+        if (t < cnt) {
+            rc = P.recs[st + t];
+            c = P.cache[P.slot ? (int64_t)P.slot[st + t] : st + t];
+        }
+    };
+    Rec cur, nxt;
+    double ccur, cnxt;
+    fetch(s0, (int)(s1 - s0), cur, ccur);
     for (int l = l0; l < l1; ++l) {
-        const int64_t start = level_off[l];
-        const int count = (int)(level_off[l + 1] - start);
-        const int64_t woff = wave_off[l];
-        const int nslots = (int)(wave_off[l + 1] - woff);        // one slot per launched wave of the level
-        const double e2 = k2_one(P, uf, vf, trail, start, (int)threadIdx.x, count);
+        const int64_t start = s0;
+        const int count = (int)(s1 - s0);
+        const int64_t woff = w0;
+        const int nslots = (int)(w1 - w0);                       // one slot per launched wave of the level
+        int64_t s3 = s2, w3 = w2;
+        if (l + 2 < l1) { s3 = level_off[l + 3]; w3 = wave_off[l + 3]; }
+        fetch(s1, l + 1 < l1 ? (int)(s2 - s1) : 0, nxt, cnxt);
+        const double e2 = k2_one<false, true>(P, uf, vf, trail, start, t, count, cur, ccur);
         const double wsum = wave_sum_fixed(e2);
         if ((threadIdx.x & 63) == 0 && wid < nslots) P.se_partial[woff + wid] = wsum;
+        cur = nxt; ccur = cnxt;
+        s0 = s1; s1 = s2; s2 = s3; w0 = w1; w1 = w2; w2 = w3;
         __syncthreads();
     }
 }

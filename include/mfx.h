@@ -194,6 +194,18 @@ int mfx_topn_batch(int kind, int dim, const double *u, const double *v_sel, cons
                    int n_cand, int N, const int64_t *rated_off, const int32_t *rated_items, int32_t *out_items,
                    double *out_scores);
 
+/* The serving form of the same ranking: the model (u [k, ni], v [k, nu], biases, every user's rated list as a CSR over
+ * user ids: rated_off int64[nu+1], rated_items; both NULL = none) is uploaded ONCE; a query names users by id and costs
+ * a gather of their columns and the kernel -- no factor upload.  Row j of a query equals row j of mfx_topn_batch for the
+ * same users, bit for bit.  The plan is a snapshot: train again -> create again. */
+typedef struct mfx_topn_plan mfx_topn_plan;
+mfx_topn_plan *mfx_topn_plan_create(int kind, int dim, const double *u, const double *v, const double *items_bias,
+                                    const double *users_bias, double overall_avg, int nu, int ni,
+                                    const int64_t *rated_off, const int32_t *rated_items);
+int mfx_topn_plan_query(mfx_topn_plan *p, const int32_t *users, int n_sel, int n_cand, int N, int32_t *out_items,
+                        double *out_scores);
+void mfx_topn_plan_destroy(mfx_topn_plan *p);
+
 /* For N <= 16 the ranking is fused into the score pass (no score matrix; a user for which the fused kernel cannot
  * prove its list complete is redone by the sort path).  stats[0] / stats[1]: users answered by the fused kernel /
  * redone, totals of this process.  MFX_TOPN_FUSED=0 forces the sort path. */

@@ -66,6 +66,9 @@ SIGNATURES = {
     "mfx_predict_rmse": (C.c_int, [C.c_int, C.c_int, _dp, _dp, _ip, _dp, _dp, _dp, C.c_double,
                                    C.c_int64, C.c_int, C.c_int, _dp, _dp]),
     "mfx_topn_stats": (C.c_int, [_lp]),
+    "mfx_topn_plan_create": (C.c_void_p, [C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_double, C.c_int, C.c_int, _lp, _ip]),
+    "mfx_topn_plan_query": (C.c_int, [C.c_void_p, _ip, C.c_int, C.c_int, C.c_int, _ip, _dp]),
+    "mfx_topn_plan_destroy": (None, [C.c_void_p]),
     "mfx_topn_batch": (C.c_int, [C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_double, C.c_int, _ip, C.c_int,
                                  C.c_int, C.c_int, _lp, _ip, _ip, _dp]),
     "mfx_sgd_plan_create": (C.c_void_p, [_ip, _dp, C.c_int64, C.c_int, C.c_int, C.c_int]),

@@ -235,11 +235,12 @@ __global__ __launch_bounds__(256) void k_scores(int kind, int k, const double *_
 }
 
 // rated items of the chunk's users score 0 (mf.py:161,171-173)
-__global__ __launch_bounds__(256) void k_clear_rated(const int64_t *__restrict__ off, const int32_t *__restrict__ rated,
-                                                     int j_base, int n_chunk, int n_cand, double *scores)
+__global__ __launch_bounds__(256) void k_clear_rated(const int64_t *__restrict__ lo, const int64_t *__restrict__ hi,
+                                                     const int32_t *__restrict__ rated, int j_base, int n_chunk, int n_cand,
+                                                     double *scores)
 {
     const int j = j_base + blockIdx.y;
-    for (int64_t p = off[j] + blockIdx.x * 256 + threadIdx.x; p < off[j + 1]; p += (int64_t)gridDim.x * 256) {
+    for (int64_t p = lo[j] + blockIdx.x * 256 + threadIdx.x; p < hi[j]; p += (int64_t)gridDim.x * 256) {
         const int it = rated[p];
         if (it >= 0 && it < n_cand) scores[(size_t)(j - j_base) * n_cand + it] = 0.0;
     }
@@ -293,10 +294,10 @@ __global__ __launch_bounds__(64) void k_take_top(const double *__restrict__ keys
 constexpr int kTM = 3;
 constexpr int kTopMaxN = 16;
 
-__device__ __forceinline__ bool is_rated(const int64_t *off, const int32_t *rated, int j, int item)
+__device__ __forceinline__ bool is_rated(const int64_t *lo_, const int64_t *hi_, const int32_t *rated, int j, int item)
 {
-    if (!off) return false;
-    int64_t lo = off[j], hi = off[j + 1];
+    if (!lo_) return false;
+    int64_t lo = lo_[j], hi = hi_[j];
     while (lo < hi) {
         const int64_t m = (lo + hi) >> 1;
         const int x = rated[m];
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(256) void k_topn_fused(int kind, int k, const doubl
                                                     const double *__restrict__ vs, const double *__restrict__ ib,
                                                     const double *__restrict__ sub, double mu,
                                                     const int32_t *__restrict__ users, int n_sel, int n_pad, int ni,
-                                                    int n_cand, int N, const int64_t *__restrict__ off,
+                                                    int n_cand, int N, const int64_t *__restrict__ off, const int64_t *__restrict__ off_hi,
                                                     const int32_t *__restrict__ rated, int force_unsafe,
                                                     int32_t *out_items, double *out_scores, int32_t *unsafe)
 {
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(256) void k_topn_fused(int kind, int k, const doubl
             }
             if (p != p || p == 0.0 || item == users[j]) continue;          // never listed (mf.py:162,176-182)
             if (p > ks[q][kTM - 1]) {                                       // would be kept
-                if (is_rated(off, rated, j, item)) continue;
+                if (is_rated(off, off_hi, rated, j, item)) continue;
                 double cs = p;                                              // sorted insertion by compare-and-swap
                 int ci = item;                                              // (static indices: the lists stay in registers)
 #pragma unroll
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(256) void k_topn_fused(int kind, int k, const doubl
                     }
                 if (cs > dropped[q]) dropped[q] = cs;                       // the entry pushed out (valid, or -inf)
             } else if (p > dropped[q]) {                                    // rejected: remember the best one
-                if (!is_rated(off, rated, j, item)) dropped[q] = p;
+                if (!is_rated(off, off_hi, rated, j, item)) dropped[q] = p;
             }
         }
     }
@@ -454,9 +455,9 @@ __global__ __launch_bounds__(256) void k_topn_tiled(int kind, int k, const doubl
                                                     const double *__restrict__ vs, const double *__restrict__ ib,
                                                     const double *__restrict__ sub, double mu,
                                                     const int32_t *__restrict__ users, int n_sel, int n_pad, int ni,
-                                                    int n_cand, int N, const int64_t *__restrict__ off,
+                                                    int n_cand, int N, const int64_t *__restrict__ off, const int64_t *__restrict__ off_hi,
                                                     const int32_t *__restrict__ rated, int force_unsafe,
-                                                    int32_t *out_items, double *out_scores, int32_t *unsafe)
+                                                    int32_t *out_items, double *out_scores, int32_t *unsafe, double *pdrop)
 {
     __shared__ double tile[2][kTF][kTI];                                    // 64 KB
     __shared__ __attribute__((aligned(16))) double vt[4][kTF][kUB];         // 16 KB: per wave, its users' values of a feature chunk
@@ -472,11 +473,15 @@ __global__ __launch_bounds__(256) void k_topn_tiled(int kind, int k, const doubl
 #pragma unroll
         for (int m = 0; m < kTM; ++m) { ks[q][m] = -INFINITY; ki[q][m] = 0x7fffffff; }
     }
-    const int n_it = (n_cand + kTI - 1) / kTI, n_fc = (k + kTF - 1) / kTF, n_tiles = n_it * n_fc;
+    // gridDim.y > 1 (small batches): the candidate tiles are split over blockIdx.y, every split writes its own top-N
+    // (row j * splits + y of the outputs) and k_topn_merge picks the N best of the splits' lists
+    const int n_it_all = (n_cand + kTI - 1) / kTI, n_fc = (k + kTF - 1) / kTF;
+    const int it_lo = (int)((int64_t)n_it_all * blockIdx.y / gridDim.y), it_hi = (int)((int64_t)n_it_all * (blockIdx.y + 1) / gridDim.y);
+    const int n_tiles = (it_hi - it_lo) * n_fc;
     constexpr int PER = kTF * kTI / 256;                                    // 16 doubles per thread per tile
     double pre[PER];
     auto fetch = [&](int t) {                                               // tile t -> registers
-        const int i0 = (t / n_fc) * kTI, f0 = (t % n_fc) * kTF;
+        const int i0 = (it_lo + t / n_fc) * kTI, f0 = (t % n_fc) * kTF;
 #pragma unroll
         for (int r = 0; r < PER; ++r) {
             const int f = f0 + r * 4 + wid, it = i0 + lane;
@@ -487,12 +492,14 @@ __global__ __launch_bounds__(256) void k_topn_tiled(int kind, int k, const doubl
 #pragma unroll
         for (int r = 0; r < PER; ++r) tile[b][r * 4 + wid][lane] = pre[r];
     };
-    fetch(0);
-    stash(0);
+    if (n_tiles > 0) {
+        fetch(0);
+        stash(0);
+    }
     __syncthreads();
     double acc[kUB];
     for (int t = 0; t < n_tiles; ++t) {
-        const int fc = t % n_fc, i0 = (t / n_fc) * kTI, f0 = fc * kTF;
+        const int fc = t % n_fc, i0 = (it_lo + t / n_fc) * kTI, f0 = fc * kTF;
         if (t + 1 < n_tiles) fetch(t + 1);
         if (fc == 0) {
 #pragma unroll
@@ -547,7 +554,7 @@ __global__ __launch_bounds__(256) void k_topn_tiled(int kind, int k, const doubl
                     }
                     if (p != p || p == 0.0 || item == users[j]) continue;  // never listed (mf.py:162,176-182)
                     if (p > ks[q][kTM - 1]) {                               // would be kept
-                        if (is_rated(off, rated, j, item)) continue;
+                        if (is_rated(off, off_hi, rated, j, item)) continue;
                         double cs = p;
                         int ci = item;
 #pragma unroll
@@ -559,7 +566,7 @@ __global__ __launch_bounds__(256) void k_topn_tiled(int kind, int k, const doubl
                             }
                         if (cs > dropped[q]) dropped[q] = cs;
                     } else if (p > dropped[q]) {
-                        if (!is_rated(off, rated, j, item)) dropped[q] = p;
+                        if (!is_rated(off, off_hi, rated, j, item)) dropped[q] = p;
                     }
                 }
             }
@@ -573,6 +580,7 @@ __global__ __launch_bounds__(256) void k_topn_tiled(int kind, int k, const doubl
     for (int q = 0; q < kUB; ++q) {
         const int j = j0 + q;
         if (j >= n_sel) continue;                                           // uniform
+        const size_t orow = (size_t)j * gridDim.y + blockIdx.y;
         int taken = 0;
         double T = -INFINITY;
         int n_out = 0;
@@ -591,16 +599,76 @@ __global__ __launch_bounds__(256) void k_topn_tiled(int kind, int k, const doubl
             }
             if (s == -INFINITY) break;                                      // nothing left (uniform)
             if (owner == lane) ++taken;
-            if (lane == 0) { out_items[(size_t)j * N + t] = it; out_scores[(size_t)j * N + t] = s; }
+            if (lane == 0) { out_items[orow * N + t] = it; out_scores[orow * N + t] = s; }
             T = s;
             ++n_out;
         }
         if (lane == 0)
-            for (int t = n_out; t < N; ++t) { out_items[(size_t)j * N + t] = -1; out_scores[(size_t)j * N + t] = 0.0; }
-        const bool bad = n_out == N ? dropped[q] >= T : dropped[q] > -INFINITY;
-        const bool any_bad = __any(bad || (force_unsafe && (j % 3) == 0));
-        if (lane == 0) unsafe[j] = any_bad ? 1 : 0;
+            for (int t = n_out; t < N; ++t) { out_items[orow * N + t] = -1; out_scores[orow * N + t] = 0.0; }
+        if (gridDim.y > 1) {
+            // split mode: whether something dropped here could belong to the list is decided against the MERGED list's
+            // N-th score (k_topn_merge) -- a split's own N-th score is lower and would flag users needlessly
+            double dm = dropped[q];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { const double o = __shfl_xor(dm, d, 64); dm = o > dm ? o : dm; }
+            if (lane == 0) pdrop[orow] = dm;
+        } else {
+            const bool bad = n_out == N ? dropped[q] >= T : dropped[q] > -INFINITY;
+            const bool any_bad = __any(bad || (force_unsafe && (j % 3) == 0));
+            if (lane == 0 && any_bad) unsafe[j] = 1;                        // zeroed by the host
+        }
     }
+}
+
+
+// small batches: the N best of `splits` lists of N (each sorted: score descending, item ascending; -1 = no entry).
+// One wave per user, lane y holds split y's list; the same arg-max rounds as above (splits <= 64, N <= kTopMaxN).
+__global__ __launch_bounds__(64) void k_topn_merge(const int32_t *__restrict__ pit, const double *__restrict__ psc,
+                                                   const double *__restrict__ pdrop, int splits, int N, int force_unsafe,
+                                                   int32_t *out_items, double *out_scores, int32_t *unsafe)
+{
+    const int j = blockIdx.x, lane = threadIdx.x;
+    double ls[kTopMaxN];
+    int li[kTopMaxN];
+#pragma unroll
+    for (int m = 0; m < kTopMaxN; ++m) {
+        const bool have = lane < splits && m < N && pit[((size_t)j * splits + lane) * N + m] >= 0;
+        li[m] = have ? pit[((size_t)j * splits + lane) * N + m] : 0x7fffffff;
+        ls[m] = have ? psc[((size_t)j * splits + lane) * N + m] : -INFINITY;
+    }
+    int taken = 0, n_out = 0;
+    double T = -INFINITY;
+    for (int t = 0; t < N; ++t) {
+        double s = -INFINITY;
+        int it = 0x7fffffff;
+#pragma unroll
+        for (int m = 0; m < kTopMaxN; ++m)
+            if (m == taken) { s = ls[m]; it = li[m]; }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const double s2 = __shfl_xor(s, d, 64);
+            const int it2 = __shfl_xor(it, d, 64);
+            if (ranks_before(s2, it2, s, it)) { s = s2; it = it2; }
+        }
+        if (s == -INFINITY) break;
+        if (taken < kTopMaxN) {
+            double hs = -INFINITY; int hi = 0x7fffffff;
+#pragma unroll
+            for (int m = 0; m < kTopMaxN; ++m)
+                if (m == taken) { hs = ls[m]; hi = li[m]; }
+            if (hs == s && hi == it) ++taken;                               // an item belongs to exactly one split
+        }
+        if (lane == 0) { out_items[(size_t)j * N + t] = it; out_scores[(size_t)j * N + t] = s; }
+        T = s;
+        ++n_out;
+    }
+    if (lane == 0)
+        for (int t = n_out; t < N; ++t) { out_items[(size_t)j * N + t] = -1; out_scores[(size_t)j * N + t] = 0.0; }
+    // a split that dropped something which could belong to the merged list makes the user unsafe
+    const double dm = lane < splits ? pdrop[(size_t)j * splits + lane] : -INFINITY;
+    const bool bad = n_out == N ? dm >= T : dm > -INFINITY;
+    const bool any_bad = __any(bad || (force_unsafe && (j % 3) == 0));
+    if (lane == 0) unsafe[j] = any_bad ? 1 : 0;
 }
 
 struct DevBufs {
@@ -619,10 +687,198 @@ struct DevBufs {
 
 static int64_t g_topn_stats[2] = {0, 0};      // users served by the fused kernel / users redone by the sort path
 
-static int topn_impl(int kind, int dim, const double *u, const double *v_sel, const double *ib,
-                     const double *ub_sel, double mu, int ni, const int32_t *users, int n_sel, int n_cand,
-                     int N, const int64_t *rated_off, const int32_t *rated_items, int32_t *out_items,
-                     double *out_scores, bool allow_fused)
+// Device-resident model for top-N queries: the one-shot mfx_topn_batch builds one for the call (V = the selected
+// users' columns, a user's position = its place in the batch), mfx_topn_plan_* keep one across calls (V = every
+// user, position = user id) -- the serving form: a query then costs a 64-byte-per-feature gather and the kernel,
+// not an upload of the item factors.
+struct mfx_topn_plan {
+    int kind = 0, k = 0, nu = 0, ni = 0;
+    double mu = 0.0;
+    double *dU = nullptr, *dV = nullptr, *dib = nullptr, *dub = nullptr;   // [k][ni], [k][nu], [ni], [nu]
+    int64_t *d_off = nullptr;                                              // [nu + 1] rated lists by position (CSR), or null
+    int32_t *d_rated = nullptr;
+    bool ascending = true;                                                 // every rated list ascending (fused kernel's search)
+    ~mfx_topn_plan()
+    {
+        void *q[] = {dU, dV, dib, dub, d_off, d_rated};
+        for (void *x : q) if (x) (void)hipFree(x);
+    }
+};
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_gather_users(const double *__restrict__ V, const double *__restrict__ ub, int nu, int k,
+                                                      const int32_t *__restrict__ pos, int n_sel, int n_pad, double *vs,
+                                                      double *ubs)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_pad) return;
+    const int p = j < n_sel ? pos[j] : -1;
+    for (int f = 0; f < k; ++f) vs[(size_t)f * n_pad + j] = p >= 0 ? V[(size_t)f * nu + p] : 0.0;
+    if (ubs && j < n_sel) ubs[j] = ub[p];
+}
+
+// per-batch CSR of the rated lists: off_sel[j] = start of the list of the user at position pos[j]
+__global__ __launch_bounds__(256) void k_batch_lists(const int64_t *__restrict__ off, const int32_t *__restrict__ pos, int n_sel,
+                                                     int64_t *lo, int64_t *hi)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < n_sel) { lo[j] = off[pos[j]]; hi[j] = off[pos[j] + 1]; }
+}
+
+}  // namespace
+
+#define TOPN_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (void)hipGetLastError(); \
+        return mfx::fail(e_ == hipErrorOutOfMemory ? MFX_E_NOMEM : MFX_E_HIP, "mfx_topn: %s -> %s", #call, hipGetErrorString(e_)); } } while (0)
+
+static int topn_state_init(mfx_topn_plan &S, int kind, int dim, const double *u, const double *v, const double *ib,
+                           const double *ub, double mu, int nu, int ni, const int64_t *rated_off, const int32_t *rated_items)
+{
+    hipStream_t st = mfx::stream();
+    S.kind = kind; S.k = dim; S.nu = nu; S.ni = ni; S.mu = mu;
+    TOPN_TRY(hipMalloc((void **)&S.dU, (size_t)dim * ni * 8));
+    TOPN_TRY(hipMalloc((void **)&S.dV, (size_t)dim * nu * 8));
+    TOPN_TRY(hipMemcpyAsync(S.dU, u, (size_t)dim * ni * 8, hipMemcpyHostToDevice, st));
+    TOPN_TRY(hipMemcpyAsync(S.dV, v, (size_t)dim * nu * 8, hipMemcpyHostToDevice, st));
+    if (ib) { TOPN_TRY(hipMalloc((void **)&S.dib, (size_t)ni * 8)); TOPN_TRY(hipMemcpyAsync(S.dib, ib, (size_t)ni * 8, hipMemcpyHostToDevice, st)); }
+    if (ub) { TOPN_TRY(hipMalloc((void **)&S.dub, (size_t)nu * 8)); TOPN_TRY(hipMemcpyAsync(S.dub, ub, (size_t)nu * 8, hipMemcpyHostToDevice, st)); }
+    const int64_t n_rated = rated_off ? rated_off[nu] : 0;
+    if (n_rated > 0) {
+        for (int j = 0; j < nu && S.ascending; ++j)
+            for (int64_t q = rated_off[j] + 1; q < rated_off[j + 1]; ++q)
+                if (rated_items[q] <= rated_items[q - 1]) { S.ascending = false; break; }
+        TOPN_TRY(hipMalloc((void **)&S.d_off, ((size_t)nu + 1) * 8));
+        TOPN_TRY(hipMalloc((void **)&S.d_rated, (size_t)n_rated * 4));
+        TOPN_TRY(hipMemcpyAsync(S.d_off, rated_off, ((size_t)nu + 1) * 8, hipMemcpyHostToDevice, st));
+        TOPN_TRY(hipMemcpyAsync(S.d_rated, rated_items, (size_t)n_rated * 4, hipMemcpyHostToDevice, st));
+    }
+    TOPN_TRY(hipStreamSynchronize(st));
+    return MFX_OK;
+}
+
+// pos[j]: the user's position in the state (row of V, list of the CSR); label[j]: its id for the "item named like the
+// user" rule (mf.py:162)
+static int topn_query(mfx_topn_plan &S, const int32_t *pos, const int32_t *label, int n_sel, int n_cand, int N,
+                      int32_t *out_items, double *out_scores, bool allow_fused)
+{
+    if (n_sel == 0) return MFX_OK;
+    hipStream_t st = mfx::stream();
+    DevBufs B;
+    const int dim = S.k, ni = S.ni, kind = S.kind;
+    const int n_pad = (n_sel + 4 * kUB - 1) / (4 * kUB) * (4 * kUB);
+    double *dv, *dubs = nullptr, *d_scores;
+    int32_t *d_pos, *d_label, *d_items;
+    int64_t *d_lo = nullptr;
+    TOPN_TRY(B.get(&dv, (size_t)dim * n_pad)); TOPN_TRY(B.get(&d_pos, (size_t)n_sel)); TOPN_TRY(B.get(&d_label, (size_t)n_sel));
+    TOPN_TRY(B.get(&d_items, (size_t)n_sel * N)); TOPN_TRY(B.get(&d_scores, (size_t)n_sel * N));
+    if (S.dub) TOPN_TRY(B.get(&dubs, (size_t)n_sel));
+    TOPN_TRY(hipMemcpyAsync(d_pos, pos, (size_t)n_sel * 4, hipMemcpyHostToDevice, st));
+    TOPN_TRY(hipMemcpyAsync(d_label, label, (size_t)n_sel * 4, hipMemcpyHostToDevice, st));
+    k_gather_users<<<(n_pad + 255) / 256, 256, 0, st>>>(S.dV, S.dub, S.nu, dim, d_pos, n_sel, n_pad, dv, dubs);
+    if (S.d_off) {                                  // the batch's lists: [lo[j], hi[j]) -> one array lo[0 .. 2 n_sel)
+        TOPN_TRY(B.get(&d_lo, (size_t)2 * n_sel));
+        k_batch_lists<<<(n_sel + 255) / 256, 256, 0, st>>>(S.d_off, d_pos, n_sel, d_lo, d_lo + n_sel);
+    }
+
+    // ---- fused path (N <= 16, every rated list ascending): no score matrix at all ---------------------------
+    const char *ef = getenv("MFX_TOPN_FUSED");
+    if (allow_fused && N <= kTopMaxN && S.ascending && !(ef && ef[0] == '0')) {
+        int32_t *d_unsafe;
+        TOPN_TRY(B.get(&d_unsafe, (size_t)n_sel));
+        const char *fu = getenv("MFX_TOPN_FORCE_UNSAFE");          // test hook: every third user goes the long way
+        const char *tv = getenv("MFX_TOPN_KERNEL");                // "strided": the first fused kernel (A/B, tests)
+        const int force = (fu && fu[0] == '1') ? 1 : 0;
+        TOPN_TRY(hipMemsetAsync(d_unsafe, 0, (size_t)n_sel * 4, st));
+        // few users: one workgroup per 32 users would walk all candidates alone (4.8 ms for ONE user at 50 K items);
+        // the candidate tiles are split over up to 64 workgroups per user group and the lists merged
+        const int groups = n_pad / (4 * kUB), n_it = (n_cand + kTI - 1) / kTI;
+        const char *es = getenv("MFX_TOPN_SPLITS");
+        int splits = es ? atoi(es) : 1024 / groups;
+        if (splits > 64) splits = 64;
+        if (splits > n_it) splits = n_it;
+        if (splits < 1 || (tv && tv[0] == 's')) splits = 1;
+        int32_t *p_items = d_items;
+        double *p_scores = d_scores;
+        double *p_drop = nullptr;
+        if (splits > 1) {
+            TOPN_TRY(B.get(&p_items, (size_t)n_sel * splits * N)); TOPN_TRY(B.get(&p_scores, (size_t)n_sel * splits * N));
+            TOPN_TRY(B.get(&p_drop, (size_t)n_sel * splits));
+        }
+        if (tv && tv[0] == 's')
+            k_topn_fused<<<(n_sel + kUB - 1) / kUB, 256, 0, st>>>(kind, dim, S.dU, dv, S.dib, dubs, S.mu, d_label, n_sel, n_pad, ni,
+                                                                   n_cand, N, d_lo, d_lo ? d_lo + n_sel : nullptr, S.d_rated, force,
+                                                                   d_items, d_scores, d_unsafe);
+        else
+        {
+            k_topn_tiled<<<dim3(groups, splits), 256, 0, st>>>(kind, dim, S.dU, dv, S.dib, dubs, S.mu, d_label, n_sel, n_pad, ni,
+                                                               n_cand, N, d_lo, d_lo ? d_lo + n_sel : nullptr, S.d_rated, force,
+                                                               p_items, p_scores, d_unsafe, p_drop);
+            if (splits > 1) k_topn_merge<<<n_sel, 64, 0, st>>>(p_items, p_scores, p_drop, splits, N, force, d_items, d_scores, d_unsafe);
+        }
+        TOPN_TRY(hipGetLastError());
+        std::vector<int32_t> flag((size_t)n_sel);
+        TOPN_TRY(hipMemcpyAsync(flag.data(), d_unsafe, (size_t)n_sel * 4, hipMemcpyDeviceToHost, st));
+        TOPN_TRY(hipMemcpyAsync(out_items, d_items, (size_t)n_sel * N * 4, hipMemcpyDeviceToHost, st));
+        TOPN_TRY(hipMemcpyAsync(out_scores, d_scores, (size_t)n_sel * N * 8, hipMemcpyDeviceToHost, st));
+        TOPN_TRY(hipStreamSynchronize(st));
+        std::vector<int32_t> rpos, rlab;
+        std::vector<int> redo;
+        for (int j = 0; j < n_sel; ++j)
+            if (flag[(size_t)j]) { redo.push_back(j); rpos.push_back(pos[j]); rlab.push_back(label[j]); }
+        g_topn_stats[0] += n_sel - (int64_t)redo.size();
+        g_topn_stats[1] += (int64_t)redo.size();
+        if (redo.empty()) return MFX_OK;
+        // the flagged users once more, through the sort path, as a batch of their own
+        const int m = (int)redo.size();
+        std::vector<int32_t> it2((size_t)m * N);
+        std::vector<double> sc2((size_t)m * N);
+        int rc2 = topn_query(S, rpos.data(), rlab.data(), m, n_cand, N, it2.data(), sc2.data(), false);
+        if (rc2) return rc2;
+        for (int a = 0; a < m; ++a) {
+            memcpy(out_items + (size_t)redo[(size_t)a] * N, it2.data() + (size_t)a * N, (size_t)N * 4);
+            memcpy(out_scores + (size_t)redo[(size_t)a] * N, sc2.data() + (size_t)a * N, (size_t)N * 8);
+        }
+        return MFX_OK;
+    }
+
+    // ---- sort path: score matrix by chunks of users (it and its sorted copy stay below ~3 GB) -----------------
+    int chunk = (int)(((size_t)1 << 27) / (size_t)n_cand);
+    if (chunk < 1) chunk = 1;
+    if (chunk > n_sel) chunk = n_sel;
+    chunk = (chunk + kUB - 1) / kUB * kUB;
+    const size_t cells = (size_t)chunk * n_cand;
+    if (cells >= ((size_t)1 << 32)) return mfx::fail(MFX_E_ARG, "mfx_topn: n_cand too large");
+    double *k_in, *k_out;
+    int32_t *v_in, *v_out;
+    unsigned int *d_seg;
+    TOPN_TRY(B.get(&k_in, cells)); TOPN_TRY(B.get(&k_out, cells)); TOPN_TRY(B.get(&v_in, cells)); TOPN_TRY(B.get(&v_out, cells));
+    TOPN_TRY(B.get(&d_seg, (size_t)chunk + 1));
+    k_iota_offsets<<<(chunk + 256) / 256, 256, 0, st>>>(d_seg, chunk, (unsigned int)n_cand);
+    size_t tmp_bytes = 0;
+    TOPN_TRY(rocprim::segmented_radix_sort_pairs_desc(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, (unsigned int)cells,
+                                                      (unsigned int)chunk, d_seg, d_seg + 1, 0u, 64u, st));
+    char *tmp;
+    TOPN_TRY(B.get(&tmp, tmp_bytes));
+    for (int jb = 0; jb < n_sel; jb += chunk) {
+        const int nc = n_sel - jb < chunk ? n_sel - jb : chunk;
+        k_scores<<<dim3((n_cand + 255) / 256, (nc + kUB - 1) / kUB), 256, 0, st>>>(kind, dim, S.dU, dv, S.dib, dubs, S.mu, d_label,
+                                                                                   n_sel, n_pad, jb, nc, ni, n_cand, k_in, v_in);
+        if (d_lo) k_clear_rated<<<dim3(4, nc), 256, 0, st>>>(d_lo, d_lo + n_sel, S.d_rated, jb, nc, n_cand, k_in);
+        TOPN_TRY(rocprim::segmented_radix_sort_pairs_desc(tmp, tmp_bytes, k_in, k_out, v_in, v_out, (unsigned int)((size_t)nc * n_cand),
+                                                          (unsigned int)nc, d_seg, d_seg + 1, 0u, 64u, st));
+        k_take_top<<<nc, 64, 0, st>>>(k_out, v_out, n_cand, N, jb, d_items, d_scores);
+    }
+    TOPN_TRY(hipGetLastError());
+    TOPN_TRY(hipMemcpyAsync(out_items, d_items, (size_t)n_sel * N * 4, hipMemcpyDeviceToHost, st));
+    TOPN_TRY(hipMemcpyAsync(out_scores, d_scores, (size_t)n_sel * N * 8, hipMemcpyDeviceToHost, st));
+    TOPN_TRY(hipStreamSynchronize(st));
+    return MFX_OK;
+}
+
+extern "C" int mfx_topn_batch(int kind, int dim, const double *u, const double *v_sel, const double *ib,
+                              const double *ub_sel, double mu, int ni, const int32_t *users, int n_sel, int n_cand,
+                              int N, const int64_t *rated_off, const int32_t *rated_items, int32_t *out_items,
+                              double *out_scores)
 {
     if (!u || !v_sel || !users || !out_items || !out_scores || dim < 1 || ni <= 0 || n_sel < 0 || n_cand < 1 ||
         n_cand > ni || N < 1 || kind < 0 || kind > 4 || ((kind >= 1 && kind <= 3) && (!ib || !ub_sel)) ||
@@ -636,129 +892,46 @@ static int topn_impl(int kind, int dim, const double *u, const double *v_sel, co
         for (int j = 0; j < n_sel; ++j)
             if (rated_off[j + 1] < rated_off[j]) return mfx::fail(MFX_E_ARG, "mfx_topn_batch: rated_off must ascend");
     }
-    hipStream_t st = mfx::stream();
-    DevBufs B;
-#define TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (void)hipGetLastError(); \
-        return mfx::fail(e_ == hipErrorOutOfMemory ? MFX_E_NOMEM : MFX_E_HIP, "mfx_topn_batch: %s -> %s", #call, hipGetErrorString(e_)); } } while (0)
-    double *du, *dv, *dib = nullptr, *dub = nullptr, *d_scores;
-    int32_t *d_users, *d_rated = nullptr, *d_items;
-    int64_t *d_off = nullptr;
-    const int n_pad = (n_sel + 4 * kUB - 1) / (4 * kUB) * (4 * kUB);       // vs rows padded: eight users are one uniform load
-    TRY(B.get(&du, (size_t)dim * ni)); TRY(B.get(&dv, (size_t)dim * n_pad)); TRY(B.get(&d_users, (size_t)n_sel));
-    TRY(B.get(&d_items, (size_t)n_sel * N)); TRY(B.get(&d_scores, (size_t)n_sel * N));
-    TRY(hipMemcpyAsync(du, u, (size_t)dim * ni * 8, hipMemcpyHostToDevice, st));
-    if (n_pad != n_sel) TRY(hipMemsetAsync(dv, 0, (size_t)dim * n_pad * 8, st));
-    TRY(hipMemcpy2DAsync(dv, (size_t)n_pad * 8, v_sel, (size_t)n_sel * 8, (size_t)n_sel * 8, (size_t)dim, hipMemcpyHostToDevice, st));
-    TRY(hipMemcpyAsync(d_users, users, (size_t)n_sel * 4, hipMemcpyHostToDevice, st));
-    if (ib) { TRY(B.get(&dib, (size_t)ni)); TRY(hipMemcpyAsync(dib, ib, (size_t)ni * 8, hipMemcpyHostToDevice, st)); }
-    if (ub_sel) { TRY(B.get(&dub, (size_t)n_sel)); TRY(hipMemcpyAsync(dub, ub_sel, (size_t)n_sel * 8, hipMemcpyHostToDevice, st)); }
-    const int64_t n_rated = rated_off ? rated_off[n_sel] : 0;
-    if (n_rated > 0) {
-        TRY(B.get(&d_off, (size_t)n_sel + 1)); TRY(B.get(&d_rated, (size_t)n_rated));
-        TRY(hipMemcpyAsync(d_off, rated_off, ((size_t)n_sel + 1) * 8, hipMemcpyHostToDevice, st));
-        TRY(hipMemcpyAsync(d_rated, rated_items, (size_t)n_rated * 4, hipMemcpyHostToDevice, st));
-    }
-
-    // ---- fused path (N <= 16, every rated list ascending): no score matrix at all ---------------------------
-    const char *ef = getenv("MFX_TOPN_FUSED");
-    if (allow_fused && N <= kTopMaxN && !(ef && ef[0] == '0')) {
-        bool ascending = true;
-        for (int j = 0; j < n_sel && ascending && n_rated > 0; ++j)
-            for (int64_t q = rated_off[j] + 1; q < rated_off[j + 1]; ++q)
-                if (rated_items[q] <= rated_items[q - 1]) { ascending = false; break; }
-        if (ascending) {
-            int32_t *d_unsafe;
-            TRY(B.get(&d_unsafe, (size_t)n_sel));
-            const char *fu = getenv("MFX_TOPN_FORCE_UNSAFE");          // test hook: every third user goes the long way
-            const char *tv = getenv("MFX_TOPN_KERNEL");                 // "strided": the first fused kernel (A/B, tests)
-            if (tv && tv[0] == 's')
-                k_topn_fused<<<(n_sel + kUB - 1) / kUB, 256, 0, st>>>(kind, dim, du, dv, dib, dub, mu, d_users, n_sel, n_pad, ni, n_cand,
-                                                                       N, n_rated > 0 ? d_off : nullptr, d_rated,
-                                                                       (fu && fu[0] == '1') ? 1 : 0, d_items, d_scores, d_unsafe);
-            else
-                k_topn_tiled<<<n_pad / (4 * kUB), 256, 0, st>>>(kind, dim, du, dv, dib, dub, mu, d_users, n_sel, n_pad, ni, n_cand, N,
-                                                                n_rated > 0 ? d_off : nullptr, d_rated,
-                                                                (fu && fu[0] == '1') ? 1 : 0, d_items, d_scores, d_unsafe);
-            TRY(hipGetLastError());
-            std::vector<int32_t> flag((size_t)n_sel);
-            TRY(hipMemcpyAsync(flag.data(), d_unsafe, (size_t)n_sel * 4, hipMemcpyDeviceToHost, st));
-            TRY(hipMemcpyAsync(out_items, d_items, (size_t)n_sel * N * 4, hipMemcpyDeviceToHost, st));
-            TRY(hipMemcpyAsync(out_scores, d_scores, (size_t)n_sel * N * 8, hipMemcpyDeviceToHost, st));
-            TRY(hipStreamSynchronize(st));
-            std::vector<int> redo;
-            for (int j = 0; j < n_sel; ++j) if (flag[(size_t)j]) redo.push_back(j);
-            g_topn_stats[0] += n_sel - (int64_t)redo.size();
-            g_topn_stats[1] += (int64_t)redo.size();
-            if (redo.empty()) return MFX_OK;
-            // the flagged users once more, through the sort path, as a batch of their own
-            const int m = (int)redo.size();
-            std::vector<double> v2((size_t)dim * m), ub2(ub_sel ? (size_t)m : 0), sc2((size_t)m * N);
-            std::vector<int32_t> us2((size_t)m), it2((size_t)m * N), ra2;
-            std::vector<int64_t> off2((size_t)m + 1, 0);
-            for (int a = 0; a < m; ++a) {
-                const int j = redo[(size_t)a];
-                for (int f = 0; f < dim; ++f) v2[(size_t)f * m + a] = v_sel[(size_t)f * n_sel + j];
-                if (ub_sel) ub2[(size_t)a] = ub_sel[j];
-                us2[(size_t)a] = users[j];
-                if (rated_off) {
-                    ra2.insert(ra2.end(), rated_items + rated_off[j], rated_items + rated_off[j + 1]);
-                    off2[(size_t)a + 1] = (int64_t)ra2.size();
-                }
-            }
-            if (ra2.empty()) ra2.push_back(0);
-            int rc2 = topn_impl(kind, dim, u, v2.data(), ib, ub_sel ? ub2.data() : nullptr, mu, ni, us2.data(), m, n_cand, N,
-                                rated_off ? off2.data() : nullptr, ra2.data(), it2.data(), sc2.data(), false);
-            if (rc2) return rc2;
-            for (int a = 0; a < m; ++a) {
-                memcpy(out_items + (size_t)redo[(size_t)a] * N, it2.data() + (size_t)a * N, (size_t)N * 4);
-                memcpy(out_scores + (size_t)redo[(size_t)a] * N, sc2.data() + (size_t)a * N, (size_t)N * 8);
-            }
-            return MFX_OK;
-        }
-    }
-
-    // ---- sort path: score matrix by chunks of users (it and its sorted copy stay below ~3 GB) -----------------
-    int chunk = (int)(((size_t)1 << 27) / (size_t)n_cand);
-    if (chunk < 1) chunk = 1;
-    if (chunk > n_sel) chunk = n_sel;
-    chunk = (chunk + kUB - 1) / kUB * kUB;
-    const size_t cells = (size_t)chunk * n_cand;
-    if (cells >= ((size_t)1 << 32)) return mfx::fail(MFX_E_ARG, "mfx_topn_batch: n_cand too large");
-    double *k_in, *k_out;
-    int32_t *v_in, *v_out;
-    unsigned int *d_seg;
-    TRY(B.get(&k_in, cells)); TRY(B.get(&k_out, cells)); TRY(B.get(&v_in, cells)); TRY(B.get(&v_out, cells));
-    TRY(B.get(&d_seg, (size_t)chunk + 1));
-    k_iota_offsets<<<(chunk + 256) / 256, 256, 0, st>>>(d_seg, chunk, (unsigned int)n_cand);
-    size_t tmp_bytes = 0;
-    TRY(rocprim::segmented_radix_sort_pairs_desc(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, (unsigned int)cells,
-                                                 (unsigned int)chunk, d_seg, d_seg + 1, 0u, 64u, st));
-    char *tmp;
-    TRY(B.get(&tmp, tmp_bytes));
-    for (int jb = 0; jb < n_sel; jb += chunk) {
-        const int nc = n_sel - jb < chunk ? n_sel - jb : chunk;
-        k_scores<<<dim3((n_cand + 255) / 256, (nc + kUB - 1) / kUB), 256, 0, st>>>(kind, dim, du, dv, dib, dub, mu, d_users,
-                                                                                   n_sel, n_pad, jb, nc, ni, n_cand, k_in, v_in);
-        if (n_rated > 0) k_clear_rated<<<dim3(4, nc), 256, 0, st>>>(d_off, d_rated, jb, nc, n_cand, k_in);
-        TRY(rocprim::segmented_radix_sort_pairs_desc(tmp, tmp_bytes, k_in, k_out, v_in, v_out, (unsigned int)((size_t)nc * n_cand),
-                                                     (unsigned int)nc, d_seg, d_seg + 1, 0u, 64u, st));
-        k_take_top<<<nc, 64, 0, st>>>(k_out, v_out, n_cand, N, jb, d_items, d_scores);
-    }
-    TRY(hipGetLastError());
-    TRY(hipMemcpyAsync(out_items, d_items, (size_t)n_sel * N * 4, hipMemcpyDeviceToHost, st));
-    TRY(hipMemcpyAsync(out_scores, d_scores, (size_t)n_sel * N * 8, hipMemcpyDeviceToHost, st));
-    TRY(hipStreamSynchronize(st));
-#undef TRY
-    return MFX_OK;
+    mfx_topn_plan S;                                           // for this call: the batch's users are "all users"
+    if ((rc = topn_state_init(S, kind, dim, u, v_sel, ib, ub_sel, mu, n_sel, ni, rated_off, rated_items))) return rc;
+    std::vector<int32_t> pos((size_t)n_sel);
+    for (int j = 0; j < n_sel; ++j) pos[(size_t)j] = j;
+    return topn_query(S, pos.data(), users, n_sel, n_cand, N, out_items, out_scores, true);
 }
 
-extern "C" int mfx_topn_batch(int kind, int dim, const double *u, const double *v_sel, const double *ib,
-                              const double *ub_sel, double mu, int ni, const int32_t *users, int n_sel, int n_cand,
-                              int N, const int64_t *rated_off, const int32_t *rated_items, int32_t *out_items,
-                              double *out_scores)
+extern "C" mfx_topn_plan *mfx_topn_plan_create(int kind, int dim, const double *u, const double *v, const double *ib,
+                                               const double *ub, double mu, int nu, int ni, const int64_t *rated_off,
+                                               const int32_t *rated_items)
 {
-    return topn_impl(kind, dim, u, v_sel, ib, ub_sel, mu, ni, users, n_sel, n_cand, N, rated_off, rated_items, out_items,
-                     out_scores, true);
+    if (!u || !v || dim < 1 || nu <= 0 || ni <= 0 || kind < 0 || kind > 4 || ((kind >= 1 && kind <= 3) && (!ib || !ub)) ||
+        (rated_off && (rated_off[0] != 0 || (!rated_items && rated_off[nu] > 0)))) {
+        mfx::fail(MFX_E_ARG, "mfx_topn_plan_create: bad argument");
+        return nullptr;
+    }
+    if (rated_off)
+        for (int j = 0; j < nu; ++j)
+            if (rated_off[j + 1] < rated_off[j]) { mfx::fail(MFX_E_ARG, "mfx_topn_plan_create: rated_off must ascend"); return nullptr; }
+    if (mfx::ensure_init()) return nullptr;
+    mfx_topn_plan *p = new (std::nothrow) mfx_topn_plan();
+    if (!p) { mfx::fail(MFX_E_NOMEM, "mfx_topn_plan_create: out of host memory"); return nullptr; }
+    if (topn_state_init(*p, kind, dim, u, v, ib, ub, mu, nu, ni, rated_off, rated_items)) { delete p; return nullptr; }
+    return p;
+}
+
+extern "C" int mfx_topn_plan_query(mfx_topn_plan *p, const int32_t *users, int n_sel, int n_cand, int N, int32_t *out_items,
+                                   double *out_scores)
+{
+    if (!p || n_sel < 0 || (n_sel > 0 && (!users || !out_items || !out_scores)) || n_cand < 1 || n_cand > p->ni || N < 1)
+        return mfx::fail(MFX_E_ARG, "mfx_topn_plan_query: bad argument");
+    for (int j = 0; j < n_sel; ++j)
+        if (users[j] < 0 || users[j] >= p->nu) return mfx::fail(MFX_E_RANGE, "mfx_topn_plan_query: user %d outside [0,%d)", users[j], p->nu);
+    return topn_query(*p, users, users, n_sel, n_cand, N, out_items, out_scores, true);
+}
+
+extern "C" void mfx_topn_plan_destroy(mfx_topn_plan *p)
+{
+    if (p && mfx::ready()) (void)hipStreamSynchronize(mfx::stream());
+    delete p;
 }
 
 // stats[0] = users answered by the fused kernel, stats[1] = users it flagged and the sort path redid (process totals)

@@ -78,6 +78,67 @@ def topn_batch(recommender, users, n_candidates, nbr_recommendations, predictor=
     return items, scores
 
 
+class TopNPlan(object):
+    """Serving form of the batched top-N (mfx_topn_plan_*): the recommender's model and every user's rated list are
+    uploaded once; query(users, N) then ranks without touching the host copies again.  A snapshot of the model at
+    construction time -- after another train() build a new one.  Rows equal find_recommended_items_batch's."""
+
+    def __init__(self, recommender, predictor="predict"):
+        kind = _kind(recommender, predictor)
+        u, v = recommender.svd_u, recommender.svd_v
+        nu, ni = v.shape[1], u.shape[1]
+        ib = recommender.items_bias if kind in (1, 2, 3) else None
+        ub = recommender.users_bias if kind in (1, 2, 3) else None
+        rel = recommender.relationship_matrix.tocsr()
+        rel.eliminate_zeros()
+        rel.sort_indices()
+        counts = np.zeros(nu, dtype=np.int64)                   # folded-in users have no row in the ratings matrix
+        m = min(nu, rel.shape[0])
+        counts[:m] = np.diff(rel.indptr)[:m]
+        off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        rated = np.ascontiguousarray(rel.indices[:rel.indptr[m]], dtype=np.int32)
+        if rated.shape[0] == 0:
+            rated = np.zeros(1, dtype=np.int32)
+        self.neighborhood = int(min(recommender.neighborhood, recommender.nbr_items))
+        self.nu = nu
+        self._h = S.lib().mfx_topn_plan_create(kind, u.shape[0], S.f64(u, "svd_u", 2), S.f64(v, "svd_v", 2),
+                                               S.f64(ib, "items_bias", 1, allow_none=True),
+                                               S.f64(ub, "users_bias", 1, allow_none=True),
+                                               float(recommender.overall_bias or 0.0), nu, ni,
+                                               off.ctypes.data_as(S._lp), S.i32(rated, "rated", 1))
+        if not self._h:
+            raise S.MfxError(S.last_error())
+
+    def query(self, users, nbr_recommendations=5, n_candidates=None):
+        users = np.ascontiguousarray(users, dtype=np.int32)
+        if users.shape[0] and (users.min() < 0 or users.max() >= self.nu):
+            raise IndexError("user outside the model")
+        n = users.shape[0]
+        items = np.full((n, nbr_recommendations), -1, dtype=np.int32)
+        scores = np.zeros((n, nbr_recommendations))
+        S.check(S.lib().mfx_topn_plan_query(self._h, S.i32(users, "users", 1), n,
+                                            int(n_candidates or self.neighborhood), int(nbr_recommendations),
+                                            S.i32(items, "items", 2), S.f64(scores, "scores", 2)))
+        return items, scores
+
+    def close(self):
+        if getattr(self, "_h", None):
+            S.lib().mfx_topn_plan_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def rmse_on(recommender, ratings_index, ratings, predictor="predict"):
     return predict_batch(recommender, ratings_index, predictor, ratings)[1]
 

@@ -437,10 +437,14 @@ def test_fused_top_n_proves_or_falls_back(monkeypatch, kernel):
         R.svd_u[:, it] = 0.0
         R.items_bias[it] = 50.0 + it / 1000.0
         R.relationship_matrix[9, it] = 0
+    monkeypatch.setenv("MFX_TOPN_SPLITS", "1")     # one workgroup walks all candidates: the four items meet in one lane
     f0, r0 = stats()
     gi, gs = R.find_recommended_items_batch([9, 10], 6, "predict_linear")
     f1, r1 = stats()
+    monkeypatch.delenv("MFX_TOPN_SPLITS")
     assert r1 - r0 >= 1                                                     # noticed, redone
+    si, ss = R.find_recommended_items_batch([9, 10], 6, "predict_linear")  # candidates split over workgroups: same rows
+    assert np.array_equal(si, gi) and np.array_equal(ss, gs)
     for row, user in zip(range(2), (9, 10)):
         wi, wsc = R.find_recommended_items(user_index=user, nbr_recommendations=6, predictor="predict_linear")
         assert list(gi[row]) == wi and np.array_equal(gs[row], np.array(wsc))
@@ -526,3 +530,29 @@ def test_reference_example_flow_runs_end_to_end():
     assert "Precision @ 5" in out.stdout and "F-Measure" in out.stdout and "Epoch : 29" in out.stdout
     lines = [l for l in out.stdout.splitlines() if l.startswith("(")]
     assert len(lines) == 2 and lines[0] == lines[1]                  # per-user loop == batched evaluation
+
+
+def test_serving_plan_answers_like_the_batch_call():
+    """metrics.TopNPlan (mfx_topn_plan_*): model uploaded once, users queried by id, several queries -- every row equal
+    to find_recommended_items_batch's (items and score bits), folded-in user and sort path (N > 16) included."""
+    import ctypes as C
+    from mfrec_amd import _shim as S
+    from mfrec_amd.recommendation import KMFRecommender, metrics
+    nu, ni, k = 200, 700, 10
+    R = _fill(KMFRecommender(nu, ni, {"nbr_epochs": 3, "nbr_features": k}), nu, ni, 6000, 31)
+    np.random.seed(6)
+    R.train(kernel="train_linear_kernel")
+    R.add_user("late", np.array([4, 5, 6], dtype=np.int32), np.array([5.0, 2.0, 3.0]))
+    R.neighborhood = ni
+    with metrics.TopNPlan(R, "predict_linear") as plan:
+        for users, N in (([0, 5, 199, 200, 7, 7], 6), (list(range(0, 201, 3)), 16), ([200, 1], 20), ([], 3)):
+            a_i, a_s = plan.query(users, N)
+            b_i, b_s = R.find_recommended_items_batch(users, N, "predict_linear")
+            assert np.array_equal(a_i, b_i) and np.array_equal(a_s, b_s)
+        a_i, _ = plan.query([3, 4], 5, n_candidates=100)
+        R.neighborhood = 100
+        b_i, _ = R.find_recommended_items_batch([3, 4], 5, "predict_linear")
+        assert np.array_equal(a_i, b_i)
+        with pytest.raises(IndexError):
+            plan.query([201], 3)
+    assert S.lib().mfx_topn_plan_query(None, None, 0, 1, 1, None, None) != 0

@@ -22,6 +22,23 @@ for U in (1000, 10000, 100000):
     items, scores = R.find_recommended_items_batch(users, 10, "predict_linear")
     out[U] = {"seconds": time.time() - t0, "users_per_s": U / (time.time() - t0)}
     print(U, out[U], flush=True)
+from mfrec_amd.recommendation import metrics
+t0 = time.time()
+plan = metrics.TopNPlan(R, "predict_linear")
+out["plan_create_s"] = time.time() - t0
+for U in (1, 64, 1000, 100000):
+    users = np.arange(U, dtype=np.int32)
+    plan.query(users, 10)
+    reps = 20 if U <= 1000 else 2
+    t0 = time.time()
+    for _ in range(reps):
+        pi, ps = plan.query(users, 10)
+    dt = (time.time() - t0) / reps
+    out["plan_query_%d_users_ms" % U] = dt * 1e3
+    if U == 100000:
+        assert np.array_equal(pi, items)
+print({k: v for k, v in out.items() if str(k).startswith("plan")}, flush=True)
+plan.close()
 t0 = time.time()
 for user in range(50):
     a, b = R.find_recommended_items(user_index=user, nbr_recommendations=10, predictor="predict_linear")

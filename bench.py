@@ -425,6 +425,21 @@ def also_topn(idx, r, nu, ni, k, with_cpu):
                         "unit": "TFLOP/s (unfused mul + add)", "frac": flops / wall / (F64_MFMA_PEAK / 2),
                         "kernel": "k_topn_tiled", "traffic": None,
                         "note": "whole-call rate; the kernel alone: 90 ms (DESIGN section 1)"}}
+    # the serving form: model resident (mfx_topn_plan_*), users queried by id
+    from mfrec_amd.recommendation import metrics as _metrics
+    t = time.perf_counter()
+    plan = _metrics.TopNPlan(R, "predict_linear")
+    serving = {"plan_create_s": time.perf_counter() - t}
+    for U in (1, 1000):
+        q = np.arange(U, dtype=np.int32)
+        plan.query(q, N)
+        t = time.perf_counter()
+        for _ in range(20):
+            pi, _ps = plan.query(q, N)
+        serving["query_%d_users_ms" % U] = (time.perf_counter() - t) / 20 * 1e3
+        assert np.array_equal(pi, items[:U])
+    plan.close()
+    out["serving_plan"] = serving
     if with_cpu:
         t = time.perf_counter()
         done = 0

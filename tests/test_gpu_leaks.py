@@ -66,6 +66,10 @@ def _round():
     R.neighborhood = ni
     R.find_recommended_items_batch(np.arange(2000), 10, "predict_linear")
     R.find_recommended_items_batch(np.arange(500), 20, "predict_linear")
+    from mfrec_amd.recommendation import metrics
+    with metrics.TopNPlan(R, "predict_linear") as plan:
+        plan.query(np.arange(3), 10)
+        plan.query(np.arange(4000), 10)
     # ALS: tuned kernel and the k > 128 scratch kernel
     M = sp.csr_matrix((np.ones(200000), (idx[s, 0] % 5000, idx[s, 1] % 3000)), shape=(5000, 3000))
     M.sum_duplicates()

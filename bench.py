@@ -60,12 +60,16 @@ def host_info():
     return {"cpu_model": model, "nproc": os.cpu_count(), "cpu_share": share}
 
 
-def load_reference():
-    """The reference's own Cython kernels (oracle/_ref, built where /root/reference exists and shipped
-    as binaries) or None."""
+def port_vs_reference():
+    """Speed of oracle/mfx_oracle.c relative to the reference's own compiled Cython kernels, recorded ONCE in the
+    build container by tools/port_vs_reference.py (the reference never travels to the GPU box)."""
     try:
-        from oracle import build_ref
-        return build_ref.load()
+        with open(os.path.join(ROOT, "profiles", "r03_port_vs_reference.json")) as f:
+            d = json.load(f)
+        return {"k1_port_over_reference": d["k1"]["port_over_reference"],
+                "funk_port_over_reference": d["funk"]["port_over_reference"],
+                "als_port_over_reference": d["als"]["port_over_reference"],
+                "measured_on": d.get("host", {}).get("cpu_model"), "source": "profiles/r03_port_vs_reference.json"}
     except Exception:
         return None
 
@@ -85,8 +89,8 @@ def timed_prefix(fn, n_total, budget_s, n_probe=200000):
 def cpu_baseline_k1(idx, r, nu, ni, k, budget_s=10.0, replicas=True):
     """train_linear_kernel (kmf_train.pyx:195-277), 1 thread (the reference is single-threaded: GIL held,
     no OpenMP), on a bounded prefix of the same workload with the full-size factor arrays allocated.
-    kind "reference" = the reference's own compiled Cython kernel when oracle/_ref travelled with the
-    snapshot, else "port" = oracle/mfx_oracle.c (bit-identical output)."""
+    kind "port" = oracle/mfx_oracle.c, whose output is bit-identical to the reference's Cython kernel
+    (oracle/make_golden.py); `port_vs_reference` = the speed ratio of the two measured in the build container."""
     from oracle import oracle as O
     from mfrec_amd import synth
     u, v = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
@@ -95,27 +99,14 @@ def cpu_baseline_k1(idx, r, nu, ni, k, budget_s=10.0, replicas=True):
     def port(n):
         O.train_linear_kernel(1, k, 0.1, LR, 0, 0, KU, KI, KB, 0.0, u, v, idx[:n], r[:n], ib, ub)
 
-    ref = load_reference()
-    ref_fn = None
-    if ref is not None:
-        def ref_fn(n):
-            ref["kmf_train"].train_linear_kernel(1, k, 0.1, LR, 0.0, 0.0, KU, KI, KB, 0.0, u, v,
-                                                 idx[:n], r[:n], ib, ub, 1, 1, 0)
-    p_rate, p_n, p_dt = timed_prefix(port, idx.shape[0], budget_s if ref_fn is None else 4.0)
+    p_rate, p_n, p_dt = timed_prefix(port, idx.shape[0], budget_s)
     out = {"value": p_rate, "unit": "rating-updates/s", "cores": 1, "kind": "port", "host": host_info(),
            "sample": "first %d of %d ratings (bench order), 1 epoch, full-size factors, "
-                     "oracle/mfx_oracle.c single thread, %.1f s" % (p_n, idx.shape[0], p_dt)}
-    if ref_fn is not None:
-        try:
-            r_rate, r_n, r_dt = timed_prefix(ref_fn, idx.shape[0], budget_s)
-            out = {"value": r_rate, "unit": "rating-updates/s", "cores": 1, "kind": "reference",
-                   "host": host_info(),
-                   "sample": "first %d of %d ratings (bench order), 1 epoch, full-size factors, the "
-                             "reference's Cython train_linear_kernel (oracle/_ref), single thread, "
-                             "%.1f s" % (r_n, idx.shape[0], r_dt),
-                   "port_value": p_rate}
-        except Exception as e:      # never let the reference leg break the bench line
-            out["reference_error"] = repr(e)
+                     "oracle/mfx_oracle.c single thread, %.1f s" % (p_n, idx.shape[0], p_dt),
+           "port_vs_reference": port_vs_reference()}
+    pv = out["port_vs_reference"]
+    if pv:      # what the reference's own Cython kernel would run at on this host, by the recorded ratio
+        out["reference_estimate"] = p_rate / pv["k1_port_over_reference"]
     if replicas:
         try:
             out["replicas"] = cpu_replica_aggregate(nu, ni, k)
@@ -124,29 +115,44 @@ def cpu_baseline_k1(idx, r, nu, ni, k, budget_s=10.0, replicas=True):
     return out
 
 
-def cpu_replica_aggregate(nu, ni, k, n_ratings=1500000):
-    """SURVEY 8(d) "N-process replica aggregate": N independent single-thread replicas of the same kernel
-    (one per CPU this job may use, at most 16), each on its own copy of the factors and the first
-    n_ratings ratings, started together; aggregate = N * n_ratings / slowest replica.  A generous upper
-    bound for "the reference on all host cores" (the reference itself has no parallel path)."""
+def physical_cores():
+    """Physical cores this job may use: distinct (package, core) pairs among the allowed CPUs."""
     try:
-        share = len(os.sched_getaffinity(0))
+        allowed = sorted(os.sched_getaffinity(0))
     except (AttributeError, OSError):
-        share = os.cpu_count() or 1
-    n = max(1, min(16, share))
-    start = time.time() + 12.0
+        allowed = list(range(os.cpu_count() or 1))
+    seen = set()
+    for c in allowed:
+        try:
+            base = "/sys/devices/system/cpu/cpu%d/topology/" % c
+            seen.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))
+        except OSError:
+            seen.add(("?", str(c)))
+    return max(1, len(seen)), len(allowed)
+
+
+def cpu_replica_aggregate(nu, ni, k, n_ratings=1500000):
+    """SURVEY 8(d) "N-process replica aggregate": N independent single-thread replicas of the same kernel, N =
+    the PHYSICAL cores this job may use (capped at 128 processes and by host memory: a replica holds ~120 MB at
+    cfg 2), each on its own copy of the factors and the first n_ratings ratings, started together; aggregate =
+    N * n_ratings / slowest replica.  A generous upper bound for "the reference on all host cores" (the
+    reference itself has no parallel path)."""
+    cores, threads = physical_cores()
+    n = max(1, min(128, cores))
+    start = time.time() + 12.0 + 0.05 * n
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-replica", str(n_ratings),
                                "--users", str(nu), "--items", str(ni), "--k", str(k), "--start-at", repr(start)],
                               stdout=subprocess.PIPE, env=dict(os.environ, OMP_NUM_THREADS="1"))
              for _ in range(n)]
     res = []
     for p in procs:
-        o, _ = p.communicate(timeout=180)
+        o, _ = p.communicate(timeout=240)
         res.append(json.loads(o.decode().strip().splitlines()[-1]))
     slowest = max(x["seconds"] for x in res)
     late = max(x["late_s"] for x in res)
     return {"value": n * n_ratings / slowest, "unit": "rating-updates/s", "processes": n,
-            "kind": res[0]["kind"], "ratings_per_replica": n_ratings, "slowest_replica_s": slowest,
+            "physical_cores": cores, "hw_threads": threads,
+            "kind": "port", "ratings_per_replica": n_ratings, "slowest_replica_s": slowest,
             "start_skew_s": late,
             "note": "N independent single-thread replicas run side by side; not a parallel algorithm"}
 
@@ -159,17 +165,12 @@ def cpu_replica_main(a):
     idx, r = synth.make_ratings(nu, ni, n, workers=1)
     u, v = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
     ib, ub = np.zeros(ni), np.zeros(nu)
-    ref = load_reference()
     late = max(0.0, time.time() - a.start_at)
     while time.time() < a.start_at:
         time.sleep(0.001)
     t0 = time.perf_counter()
-    if ref is not None:
-        ref["kmf_train"].train_linear_kernel(1, k, 0.1, LR, 0.0, 0.0, KU, KI, KB, 0.0, u, v, idx, r, ib, ub, 1, 1, 0)
-    else:
-        O.train_linear_kernel(1, k, 0.1, LR, 0, 0, KU, KI, KB, 0.0, u, v, idx, r, ib, ub)
-    print(json.dumps({"seconds": time.perf_counter() - t0, "late_s": late,
-                      "kind": "reference" if ref is not None else "port"}))
+    O.train_linear_kernel(1, k, 0.1, LR, 0, 0, KU, KI, KB, 0.0, u, v, idx, r, ib, ub)
+    print(json.dumps({"seconds": time.perf_counter() - t0, "late_s": late, "kind": "port"}))
 
 
 def cpu_baseline_funk(idx, r, nu, ni, budget_s=8.0):
@@ -178,22 +179,15 @@ def cpu_baseline_funk(idx, r, nu, ni, budget_s=8.0):
     from oracle import oracle as O
     from mfrec_amd import synth
     kk = 8
-    ref = load_reference()
 
     def run(n):
         u, v = synth.init_const(kk, ni, FUNK_INIT), synth.init_const(kk, nu, FUNK_INIT)
-        if ref is not None:
-            ref["gd_estimator"].estimator_loop_without_bias(1, 1, 1e9, kk, FUNK_INIT, FUNK_LR, FUNK_K, u, v,
-                                                            idx[:n], r[:n], nu, ni, 0)
-        else:
-            O.estimator_loop_without_bias(1, 1, 1e9, kk, FUNK_INIT, FUNK_LR, FUNK_K, u, v, idx[:n], r[:n], nu, ni)
+        O.estimator_loop_without_bias(1, 1, 1e9, kk, FUNK_INIT, FUNK_LR, FUNK_K, u, v, idx[:n], r[:n], nu, ni)
 
     rate, n, dt = timed_prefix(run, idx.shape[0], budget_s / 2.0, n_probe=500000)
-    return {"value": rate * kk, "unit": "scalar-updates/s", "cores": 1,
-            "kind": "reference" if ref is not None else "port",
-            "sample": "first %d of %d ratings, 8 features x 1 epoch (+ commit passes), %s, single thread, %.1f s"
-                      % (n, idx.shape[0], "the reference's Cython estimator_loop_without_bias (oracle/_ref)"
-                         if ref is not None else "oracle/mfx_oracle.c", dt)}
+    return {"value": rate * kk, "unit": "scalar-updates/s", "cores": 1, "kind": "port",
+            "sample": "first %d of %d ratings, 8 features x 1 epoch (+ commit passes), oracle/mfx_oracle.c, "
+                      "single thread, %.1f s" % (n, idx.shape[0], dt)}
 
 
 def als_flops(k, nz, nu, ni):
@@ -217,7 +211,6 @@ def cpu_baseline_als(k):
     views = create_bool_sparse_row(M) + create_bool_sparse_col(M)
     rs = np.random.RandomState(0)
     u, v = rs.normal(0, 0.1, (k, ni)), rs.normal(0, 0.1, (k, nu))
-    ref = load_reference()
     # ONE thread, as the reference runs: its per-row np.linalg.inv would otherwise fan a 128 x 128 LAPACK
     # call out over every core of the host (measured: 13x slower on a 256-thread box)
     try:
@@ -227,21 +220,16 @@ def cpu_baseline_als(k):
         limit = None
     t0 = time.perf_counter()
     try:
-        if ref is not None:
-            m, m_inv = np.zeros((k, k)), np.zeros((k, k))
-            ref["als_implicit"].als_wrmf(1, k, u, v, m, m_inv, *views, nu, ni, 1, 0.015, 0)
-        else:
-            O.als_wrmf(1, k, u, v, None, None, *views, nu, ni, 1, 0.015)
+        O.als_wrmf(1, k, u, v, None, None, *views, nu, ni, 1, 0.015)
     finally:
         if limit is not None:
             limit.restore_original_limits()
     dt = time.perf_counter() - t0
     F = als_flops(k, nz, nu, ni)
-    return {"value": (nu + ni) / dt, "unit": "rows/s", "cores": 1, "kind": "reference" if ref is not None else "port",
+    return {"value": (nu + ni) / dt, "unit": "rows/s", "cores": 1, "kind": "port",
             "model_gflops": F / dt / 1e9, "seconds": dt,
-            "sample": "cfg 4 / 200: %d x %d, %d distinct ratings, k=%d, 1 epoch, %s, single thread"
-                      % (nu, ni, nz, k, "the reference's Cython als_wrmf (oracle/_ref)" if ref is not None
-                         else "oracle/mfx_oracle.c")}
+            "sample": "cfg 4 / 200: %d x %d, %d distinct ratings, k=%d, 1 epoch, oracle/mfx_oracle.c, single thread"
+                      % (nu, ni, nz, k)}
 
 
 # ------------------------------------------------------------------------------------------------

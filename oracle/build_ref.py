@@ -1,21 +1,23 @@
 #!/usr/bin/env python3
-"""TEST INFRASTRUCTURE ONLY -- builds the *reference's own* Cython kernels into oracle/_ref/.
+"""TEST INFRASTRUCTURE ONLY -- builds the *reference's own* Cython kernels OUTSIDE the repository.
 
 The three hot-path modules of mlaprise/mfrec are Cython (.pyx -> C -> extension
 module).  This recipe compiles them *from the sources where they lie* under
-/root/reference (nothing is copied into the repository):
+/root/reference, into $MFX_REF_OUT (default /tmp/mfx_ref) -- never into /root/repo:
+the reference is Python/Cython and must not travel to the GPU box in any form (SURVEY 8(c)
+usage rule), and everything under /root/repo does travel.
 
-    cython -2 <ref>/mfrec/lib/X.pyx -o oracle/_ref/X.c
-    gcc -O2 -fPIC -shared -ffp-contract=off oracle/_ref/X.c -o oracle/_ref/X.so
-    rm oracle/_ref/X.c                       # only the binary stays
+    cython -2 <ref>/mfrec/lib/X.pyx -o $MFX_REF_OUT/X.c
+    gcc -O2 -fPIC -shared -ffp-contract=off $MFX_REF_OUT/X.c -o $MFX_REF_OUT/X.so
+    rm $MFX_REF_OUT/X.c
 
-oracle/_ref/ is git-ignored (binaries only, never history).  The resulting
-modules are used to
-  * pin oracle/mfx_oracle.c (our plain-C restatement) bit-for-bit, and
-  * generate tests/golden/*.npz via oracle/make_golden.py,
-  * optionally serve as cpu_baseline.kind == "reference" in bench.py.
-
-It is a no-op (returns False) when /root/reference is absent (GPU box).
+The resulting modules are used, in the build container only, to
+  * pin oracle/mfx_oracle.c (our plain-C restatement) bit-for-bit,
+  * generate tests/golden/*.npz via oracle/make_golden.py, and
+  * record the port-vs-reference speed ratio (tools/port_vs_reference.py ->
+    profiles/r03_port_vs_reference.json).
+On the GPU box neither /root/reference nor $MFX_REF_OUT exists: build() is a no-op (returns
+False), load() returns None, and bench.py's cpu_baseline is the plain-C port.
 """
 import os
 import subprocess
@@ -23,7 +25,9 @@ import sys
 import sysconfig
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-OUT = os.path.join(HERE, "_ref")
+OUT = os.environ.get("MFX_REF_OUT", "/tmp/mfx_ref")
+if os.path.realpath(OUT).startswith(os.path.realpath(os.path.dirname(HERE)) + os.sep):
+    raise RuntimeError("MFX_REF_OUT must lie outside the repository (the reference must not travel)")
 REF = os.environ.get("MFX_REFERENCE_ROOT", "/root/reference")
 MODULES = ("kmf_train", "gd_estimator", "als_implicit")
 

@@ -227,6 +227,25 @@ mfx_sgd_plan *mfx_sgd_plan_create(const int32_t *ratings_index, const double *ra
 enum { MFX_SCHED_AUTO = 0, MFX_SCHED_HOST = 1, MFX_SCHED_DEVICE = 2 };
 mfx_sgd_plan *mfx_sgd_plan_create2(const int32_t *ratings_index, const double *ratings,
                                    int64_t nnz, int nu, int ni, int dim, int sched);
+/* The same with the kernel of a plain full-k epoch (mfx_sgd_run_kmf, both sides trained, f64 rows) chosen:
+ *   MFX_EPOCH_LEVELS  one launch per dependency level (k1_level / k1_tail): every order, every size.
+ *   MFX_EPOCH_TICKET  ONE persistent launch per epoch with the USER rows resident in registers: for ratings grouped
+ *                     by user (every user one contiguous run: get_ratings(randomize_order=False), base.py:1115-1126);
+ *                     a wave takes the next user runs by ticket and keeps their rows and biases for the whole run,
+ *                     only the item rows travel (behind per-item chain counters).  Any number of users.
+ *   MFX_EPOCH_STATIC  the same with FIXED owners: every row of the smaller side (users or items) lives in the
+ *                     registers of one wave for the whole epoch -- any rating order, but the side must fit the
+ *                     register file (65 536 rows at k = 64) and the whole grid must be co-resident; if it is not,
+ *                     nothing is modified and the plan goes back to MFX_EPOCH_LEVELS by itself.
+ *   MFX_EPOCH_AUTO    by the measured cost model (chain depth x step against ratings / rate); what create/create2 use.
+ * All three give the level schedule's bits (= the reference loop's).  TICKET / STATIC on a plan that is not eligible:
+ * NULL, MFX_E_ARG.  Even k in 18..128 only; other k: AUTO means LEVELS. */
+enum { MFX_EPOCH_AUTO = 0, MFX_EPOCH_LEVELS = 1, MFX_EPOCH_TICKET = 2, MFX_EPOCH_STATIC = 3 };
+mfx_sgd_plan *mfx_sgd_plan_create3(const int32_t *ratings_index, const double *ratings,
+                                   int64_t nnz, int nu, int ni, int dim, int sched, int epoch);
+/* info[0] = the epoch kernel in use (MFX_EPOCH_LEVELS / _TICKET / _STATIC), [1] = the one prepared at creation
+ * (differs after a failed co-residency check), [2] = device bytes of its records, [3] = squared-error slots */
+int mfx_sgd_plan_res_info(const mfx_sgd_plan *p, int64_t info[4]);
 /* MFX_SCHED_HOST or MFX_SCHED_DEVICE: which builder produced this plan's schedule */
 int mfx_sgd_plan_schedule_builder(const mfx_sgd_plan *p);
 void mfx_sgd_plan_destroy(mfx_sgd_plan *p);

@@ -73,6 +73,8 @@ SIGNATURES = {
                                  C.c_int, C.c_int, _lp, _ip, _ip, _dp]),
     "mfx_sgd_plan_create": (C.c_void_p, [_ip, _dp, C.c_int64, C.c_int, C.c_int, C.c_int]),
     "mfx_sgd_plan_create2": (C.c_void_p, [_ip, _dp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mfx_sgd_plan_create3": (C.c_void_p, [_ip, _dp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mfx_sgd_plan_res_info": (C.c_int, [C.c_void_p, _lp]),
     "mfx_sgd_plan_schedule_builder": (C.c_int, [C.c_void_p]),
     "mfx_sgd_plan_destroy": (None, [C.c_void_p]),
     "mfx_sgd_plan_info": (C.c_int, [C.c_void_p, _lp]),

@@ -210,7 +210,7 @@ mfx_dsgd *mfx_dsgd_create(const int32_t *idx, const double *r, int64_t nnz, int 
                         borig[b].swap(no2);
                     }
                 }
-                R.plans[j] = mfx_sgd_plan_create(bidx[b].data(), br[b].data(), cnt[b], nul, nil, dim);
+                R.plans[j] = plan_create_ex(bidx[b].data(), br[b].data(), cnt[b], nul, nil, dim, MFX_SCHED_AUTO, MFX_EPOCH_LEVELS);
                 if (!R.plans[j] || (j > 0 && plan_alias_users(R.plans[j], R.plans[0])) ||
                     hipEventCreateWithFlags(&R.trained[j], hipEventDisableTiming) != hipSuccess ||
                     hipEventCreateWithFlags(&R.arrived[j], hipEventDisableTiming) != hipSuccess) {

@@ -77,6 +77,10 @@ struct mfx_sgd_plan {
     hipGraphExec_t graph = nullptr;
     K1Params graph_params{};
     int graph_mode = -1;
+    bool graph_res = false;              // the cached epoch is the resident-side launch
+    // resident-side epoch (mfx_sgd_res.hip): prepared at creation when its cost model beats the level schedule
+    mfx::ResPlan *res = nullptr;
+    int res_state = 0;                   // 1 = ready, -1 = registration failed once: stay on the level schedule
 };
 
 namespace {
@@ -114,6 +118,7 @@ void drop_graph(mfx_sgd_plan *p)
     if (p->graph) (void)hipGraphExecDestroy(p->graph);
     p->graph = nullptr;
     p->graph_mode = -1;
+    p->graph_res = false;
     if (p->graph2) (void)hipGraphExecDestroy(p->graph2);
     p->graph2 = nullptr;
 }
@@ -389,8 +394,24 @@ K1Params k1_params(mfx_sgd_plan *p, double lr, double Ku, double Ki, double Kb, 
 
 // run `epochs` full-k epochs; hook (nullable) is called after each epoch's launches have
 // been enqueued (sharded mode enqueues its all-reduce there).
+// one resident-side epoch + its squared-error reduction (mfx_sgd_res.hip)
+int enqueue_res_epoch(mfx_sgd_plan *p, int mode, const K1Params &P)
+{
+    int rc = res_enqueue_epoch(p->res, mode, (double *)P.U, (double *)P.V, P.ib, P.ub, P.lr, P.Ku, P.Ki, P.Kb);
+    if (rc) return rc;
+    return enqueue_reduce(p, res_se_slots(p->res), res_se_partials(p->res));
+}
+
+// the resident-side epoch serves the plain linear / logistic run: f64 rows, ordered dot, both sides trained
+bool res_applies(const mfx_sgd_plan *p, int mode, const K1Params &P)
+{
+    return p->res && p->res_state == 1 && (mode == K1_LINEAR || mode == K1_LOGISTIC) && !p->f32 && !p->dot &&
+           P.upd_u && P.upd_i && p->owns_users;
+}
+
 template <typename Hook>
-int run_k1_epochs(mfx_sgd_plan *p, int mode, int epochs, const K1Params &P, Hook &&hook, bool reset_se = true)
+int run_k1_epochs(mfx_sgd_plan *p, int mode, int epochs, const K1Params &P, Hook &&hook, bool reset_se = true,
+                  bool allow_res = false)
 {
     int rc = reset_se ? ensure_se_cap(p, epochs) : MFX_OK;
     if (rc) return rc;
@@ -398,13 +419,15 @@ int run_k1_epochs(mfx_sgd_plan *p, int mode, int epochs, const K1Params &P, Hook
     if (rc) return rc;
     p->km_current = false;
     if (reset_se) MFX_HIP(hipMemsetAsync(p->d_counter, 0, sizeof(int), stream()));
+    const bool res = allow_res && res_applies(p, mode, P);
+    if (res && (rc = res_begin_batch(p->res))) return rc;
     // very long launch sequences (power-law data without the tail kernel) are not worth a graph
-    const bool graph = use_graph() && p->segs.size() <= kMaxGraphNodes;
-    if (graph && !(p->graph && p->graph_mode == mode && same_params(p->graph_params, P))) {
+    const bool graph = use_graph() && (res || p->segs.size() <= kMaxGraphNodes);
+    if (graph && !(p->graph && p->graph_mode == mode && p->graph_res == res && same_params(p->graph_params, P))) {
         drop_graph(p);
         hipGraph_t g = nullptr;
         MFX_HIP(hipStreamBeginCapture(stream(), hipStreamCaptureModeThreadLocal));
-        rc = enqueue_k1_epoch(p, mode, P, nullptr);
+        rc = res ? enqueue_res_epoch(p, mode, P) : enqueue_k1_epoch(p, mode, P, nullptr);
         hipError_t e = hipStreamEndCapture(stream(), &g);
         if (rc) {
             if (g) (void)hipGraphDestroy(g);
@@ -420,16 +443,29 @@ int run_k1_epochs(mfx_sgd_plan *p, int mode, int epochs, const K1Params &P, Hook
             return fail(MFX_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
         }
         p->graph_mode = mode;
+        p->graph_res = res;
         p->graph_params = P;
     }
     for (int ep = 0; ep < epochs; ++ep) {
         if (graph) MFX_HIP(hipGraphLaunch(p->graph, stream()));
         else {
-            rc = enqueue_k1_epoch(p, mode, P, nullptr);
+            rc = res ? enqueue_res_epoch(p, mode, P) : enqueue_k1_epoch(p, mode, P, nullptr);
             if (rc) return rc;
         }
         rc = hook(ep);
         if (rc) return rc;
+    }
+    if (res) {
+        // the resident-side launch reports through a status word: 1 = the static grid was not co-resident and
+        // NOTHING was modified by any epoch of this batch (the word is sticky) -> the level schedule, from now on
+        MFX_HIP(hipStreamSynchronize(stream()));
+        unsigned status = 0;
+        if ((rc = res_status(p->res, &status))) return rc;
+        if (status == 1) {
+            p->res_state = -1;
+            return run_k1_epochs(p, mode, epochs, P, hook, reset_se, false);
+        }
+        if (status) return fail(MFX_E_HIP, "mfx_sgd_run_kmf: the resident-side epoch timed out waiting for a chain counter");
     }
     return MFX_OK;
 }
@@ -570,9 +606,23 @@ mfx_sgd_plan *mfx_sgd_plan_create(const int32_t *idx, const double *r, int64_t n
 mfx_sgd_plan *mfx_sgd_plan_create2(const int32_t *idx, const double *r, int64_t nnz, int nu, int ni,
                                    int dim, int sched)
 {
+    return mfx::plan_create_ex(idx, r, nnz, nu, ni, dim, sched, MFX_EPOCH_AUTO);
+}
+
+mfx_sgd_plan *mfx_sgd_plan_create3(const int32_t *idx, const double *r, int64_t nnz, int nu, int ni,
+                                   int dim, int sched, int epoch)
+{
+    return mfx::plan_create_ex(idx, r, nnz, nu, ni, dim, sched, epoch);
+}
+
+}  // extern "C"
+
+mfx_sgd_plan *mfx::plan_create_ex(const int32_t *idx, const double *r, int64_t nnz, int nu, int ni,
+                                  int dim, int sched, int epoch)
+{
     mfx::TraceRange trace_("mfx:plan_create (schedule + upload)");
     if (!idx || !r || nnz < 0 || nu <= 0 || ni <= 0 || dim < 1 || dim > kMaxK ||
-        sched < MFX_SCHED_AUTO || sched > MFX_SCHED_DEVICE) {
+        sched < MFX_SCHED_AUTO || sched > MFX_SCHED_DEVICE || epoch < MFX_EPOCH_AUTO || epoch > MFX_EPOCH_STATIC) {
         fail(MFX_E_ARG, "mfx_sgd_plan_create: bad argument (nnz=%lld nu=%d ni=%d k=%d sched=%d; 1 <= k <= %d)",
              (long long)nnz, nu, ni, dim, sched, kMaxK);
         return nullptr;
@@ -720,12 +770,18 @@ mfx_sgd_plan *mfx_sgd_plan_create2(const int32_t *idx, const double *r, int64_t 
             return bail();
         }
         if (ensure_se_cap(p, 64)) return bail();
+        if (epoch != MFX_EPOCH_LEVELS) {
+            if (res_prepare(&p->res, idx, r, nnz, nu, ni, dim, p->n_levels, epoch)) return bail();
+            if (p->res) { p->res_state = 1; p->dev_bytes += res_dev_bytes(p->res); }
+        }
     } catch (const std::bad_alloc &) {
         mfx::fail(MFX_E_NOMEM, "mfx_sgd_plan_create: out of host memory");
         return bail();
     }
     return p;
 }
+
+extern "C" {
 
 void mfx_sgd_plan_destroy(mfx_sgd_plan *p)
 {
@@ -738,6 +794,7 @@ void mfx_sgd_plan_destroy(mfx_sgd_plan *p)
                     p->d_ib_start};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
+    res_destroy(p->res);
     delete p;
 }
 
@@ -766,6 +823,17 @@ int mfx_sgd_plan_info(const mfx_sgd_plan *p, int64_t info[8])
     return MFX_OK;
 }
 
+int mfx_sgd_plan_res_info(const mfx_sgd_plan *p, int64_t info[4])
+{
+    if (!p || !info) return MFX_E_ARG;
+    const bool on = p->res && p->res_state == 1;
+    info[0] = on ? res_kind(p->res) + 1 : MFX_EPOCH_LEVELS;          // (kind 1 = ticket, 2 = static)
+    info[1] = p->res ? res_kind(p->res) + 1 : MFX_EPOCH_LEVELS;      // prepared (switched off by a failed registration?)
+    info[2] = p->res ? (int64_t)res_dev_bytes(p->res) : 0;
+    info[3] = p->res ? res_se_slots(p->res) : 0;
+    return MFX_OK;
+}
+
 int mfx_sgd_plan_kernel_name(const mfx_sgd_plan *p, int mode, char *buf, int buflen)
 {
     if (!p || !buf || buflen < 1 || mode < 0 || mode > 3) return fail(MFX_E_ARG, "mfx_sgd_plan_kernel_name: bad argument");
@@ -774,6 +842,7 @@ int mfx_sgd_plan_kernel_name(const mfx_sgd_plan *p, int mode, char *buf, int buf
         else snprintf(buf, (size_t)buflen, "k2_level<%d threads>%s", kK2Block, p->k2x_state == 0 ? " (undecided: no Funk run yet)" : "");
         return MFX_OK;
     }
+    if (mode < 2 && p->res && p->res_state == 1 && !p->f32 && !p->dot) return res_describe(p->res, mode, buf, buflen);
     static const char *const mode_name[] = {"linear", "logistic", "learned"};
     snprintf(buf, (size_t)buflen, "k1_level<%s,%s%s>", k1_select<false>(p->k, mode, p->batch, p->f32, p->dot).tag,
              mode_name[mode], p->f32 == 1 ? ",f32" : "");
@@ -848,7 +917,7 @@ int mfx_sgd_run_kmf(mfx_sgd_plan *p, int mode, int nbr_epochs, double lr, double
     }
     if (nbr_epochs <= 0) return MFX_OK;
     K1Params P = k1_params(p, lr, Ku, Ki, Kb, upd_u, upd_i);
-    rc = run_k1_epochs(p, mode, nbr_epochs, P, [](int) { return MFX_OK; });
+    rc = run_k1_epochs(p, mode, nbr_epochs, P, [](int) { return MFX_OK; }, true, true);
     if (rc) return rc;
     return fetch_rmse(p, nbr_epochs, rmse_out, nullptr);
 }
@@ -1165,7 +1234,8 @@ int mfx_kmf_train(int mode, int nbr_epochs, int dim, double lr, double Ku, doubl
         if (rmse_out) for (int e = 0; e < nbr_epochs; ++e) rmse_out[e] = NAN;
         return MFX_OK;
     }
-    mfx_sgd_plan *p = mfx_sgd_plan_create(idx, r, nnz, nu, ni, dim);
+    // (the resident-side preparation pays for itself over a few epochs with both sides trained)
+    mfx_sgd_plan *p = mfx::plan_create_ex(idx, r, nnz, nu, ni, dim, MFX_SCHED_AUTO, (upd_u && upd_i && nbr_epochs >= 3) ? MFX_EPOCH_AUTO : MFX_EPOCH_LEVELS);
     if (!p) return last_code();
     int rc = mfx_sgd_set_factors(p, u, v, ib, ub);
     if (!rc) rc = mfx_sgd_run_kmf(p, mode, nbr_epochs, lr, Ku, Ki, Kb, upd_u, upd_i, rmse_out);
@@ -1199,7 +1269,7 @@ int mfx_funk(int min_epochs, double min_improvement, int dim, double f_init, dou
     }
     if (n_hist) *n_hist = 0;
     if (nnz == 0) return empty_history(min_epochs, dim, epoch_cap, rmse_hist, hist_cap, n_hist);
-    mfx_sgd_plan *p = mfx_sgd_plan_create(idx, r, nnz, nu, ni, dim);
+    mfx_sgd_plan *p = mfx::plan_create_ex(idx, r, nnz, nu, ni, dim, MFX_SCHED_AUTO, MFX_EPOCH_LEVELS);
     if (!p) return last_code();
     int rc = mfx_sgd_set_factors(p, u, v, ib, ub);
     if (!rc) rc = mfx_sgd_run_funk(p, min_epochs, min_improvement, f_init, lr, K, mu, ib != nullptr,
@@ -1220,7 +1290,7 @@ int mfx_learned_bias(int min_epochs, double min_improvement, int dim, double f_i
     }
     if (n_hist) *n_hist = 0;
     if (nnz == 0) return empty_history(min_epochs, dim, epoch_cap, rmse_hist, hist_cap, n_hist);
-    mfx_sgd_plan *p = mfx_sgd_plan_create(idx, r, nnz, nu, ni, dim);
+    mfx_sgd_plan *p = mfx::plan_create_ex(idx, r, nnz, nu, ni, dim, MFX_SCHED_AUTO, MFX_EPOCH_LEVELS);
     if (!p) return last_code();
     int rc = mfx_sgd_set_factors(p, u, v, ib, ub);
     if (!rc) rc = mfx_sgd_run_learned_bias(p, min_epochs, min_improvement, f_init, lr, lr_users,
@@ -1259,7 +1329,7 @@ int dense_setup(DenseCtx &c, double *u, double *v, const int32_t *idx, const dou
                 int nu, int ni, int dim, double lr, double K)
 {
     if (nnz > 0x7fffffff) return fail(MFX_E_ARG, "dense-cache variants: nnz too large");
-    c.p = mfx_sgd_plan_create(idx, r, nnz, nu, ni, dim);
+    c.p = mfx::plan_create_ex(idx, r, nnz, nu, ni, dim, MFX_SCHED_AUTO, MFX_EPOCH_LEVELS);
     if (!c.p) return last_code();
     mfx_sgd_plan *p = c.p;
     int rc = mfx_sgd_set_factors(p, u, v, nullptr, nullptr);

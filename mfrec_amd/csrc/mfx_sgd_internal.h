@@ -42,6 +42,23 @@ int plan_download_items(mfx_sgd_plan *p, double *u_km, double *ib);
 int plan_download_users(mfx_sgd_plan *p, double *v_km, double *ub);
 void plan_mark_ready(mfx_sgd_plan *p);
 
+// ---- resident-side full-k epoch (mfx_sgd_res.hip) -------------------------------------------
+struct ResPlan;
+int res_prepare(ResPlan **out, const int32_t *idx, const double *r, int64_t nnz, int nu, int ni, int k, int64_t n_levels, int want);
+void res_destroy(ResPlan *rp);
+int res_kind(const ResPlan *rp);                 // 0 none, 1 ticket (users resident, runs by ticket), 2 static owners
+size_t res_dev_bytes(const ResPlan *rp);
+int64_t res_se_slots(const ResPlan *rp);
+const double *res_se_partials(const ResPlan *rp);
+int res_describe(const ResPlan *rp, int mode, char *buf, int buflen);
+int res_begin_batch(ResPlan *rp);
+int res_enqueue_epoch(ResPlan *rp, int mode, double *U_nk, double *V_nk, double *ib, double *ub, double lr, double Ku,
+                      double Ki, double Kb);
+int res_status(ResPlan *rp, unsigned *status);
+// plan creation with the epoch kernel chosen (MFX_EPOCH_*); the Funk / learned-bias / dense-cache drop-ins and the
+// DSGD sub-plans pass MFX_EPOCH_LEVELS: they never run a plain full-k epoch
+mfx_sgd_plan *plan_create_ex(const int32_t *idx, const double *r, int64_t nnz, int nu, int ni, int dim, int sched, int epoch);
+
 // ---- Funk hooks (user-sharded Funk pass) ---------------------------------------------------
 struct FunkHooks {
     int (*pre)(void *ctx, double *uf, int ni);

@@ -1,0 +1,536 @@
+// Resident-side full-k SGD epoch (round 3): train_linear_kernel / train_logistic_kernel
+// (kmf_train.pyx:195-277, :103-189) as ONE persistent launch per epoch instead of one launch per
+// dependency level.
+//
+// The sequential loop's result is fixed by two orders only: the ratings of a user in input order, the
+// ratings of an item in input order.  Here ONE side of every rating is RESIDENT: a
+// wave keeps the factor rows and biases of its entities (users or items) in registers for a whole run of
+// their ratings and walks each run in input order, so that side's order needs no synchronisation at all
+// and its rows move once per run instead of twice per rating.  The other side TRAVELS: its rows go
+// through the coherent path (16-byte sc1 loads and write-through stores, the level kernel's accesses), and
+// a rating waits until a per-entity chain counter says that its predecessor in that entity's input order
+// has been applied.  Counter and bias share one 16-byte granule: the poll returns the bias, the publish
+// stores both behind the wave's `s_waitcnt vmcnt(0)` (every row store acknowledged: MI355X_MICROARCH.md,
+// hand-offs with sc1 loads in place of the acquire).  Arithmetic per rating is k1_body's, operation for
+// operation: the factors come out bit-identical to the level schedule and to the reference loop.
+//
+// Two bindings of entities to waves:
+//   TICKET  (input grouped by user, e.g. get_ratings(randomize_order=False), base.py:1115-1126: north_star's
+//           "ratings streamed in CSR blocks, hot rows staged"): a wave takes the next B user runs by ticket.
+//           Tickets go out in input order, so the earliest unfinished rating always belongs to a running
+//           wave: no deadlock for any grid size, any residency.  Any number of users.
+//   STATIC  (ANY input order): every entity of the smaller side has a fixed owner (wave, slot) for the whole
+//           epoch; the ratings are grouped by owner entity (stable).  Needs the whole side in registers
+//           (<= waves x B rows) and the whole grid co-resident: the launch opens with a registration barrier
+//           and NOTHING is modified unless every wave has arrived (status word -> the host falls back to
+//           the level schedule and stays there).
+// Every spin is bounded; a time-out mid-epoch sets the status word and the host returns MFX_E_HIP.
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <chrono>
+#include <vector>
+#include "mfx_common.h"
+#include "mfx_sgd_internal.h"
+
+namespace mfx {
+
+struct __attribute__((aligned(16))) URec { int32_t trav; int32_t seq; double r; };   // travelling entity, its chain rank
+struct __attribute__((aligned(16))) THdr { double bias; int32_t cnt; int32_t pad; };  // travelling entity: bias + chain counter
+
+struct ResParams {
+    const URec *recs;
+    const int64_t *run_off;     // [n_runs + 1]
+    const int32_t *run_ent;     // [n_runs] resident entity of a run
+    double *Tm, *Rm;            // travelling / resident rows, [n][k]
+    THdr *hdr;                  // [n_trav]
+    double *rb;                 // resident biases
+    unsigned *ctl;              // [0] ticket, [32] status, [64] registration
+    double *se_run;             // squared error per run (fixed layout: deterministic epoch RMSE)
+    int n_runs, k, res_item;
+    double lr, Kres, Ktrav, Kb;
+};
+
+namespace {
+
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+constexpr int kCtlStatus = 32, kCtlReg = 64, kCtlWords = 96;
+constexpr unsigned kRegFail = 0x80000000u;
+constexpr int kSpinRun = 1 << 22;        // polls of ~1 us: seconds
+constexpr int kSpinReg = 1 << 15;        // registration: tens of milliseconds
+
+// 16-byte agent-scope (sc1) accesses the compiler can see and count
+__device__ __forceinline__ v4u ld16c(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16); }
+__device__ __forceinline__ void st16c(v4u v, __amdgpu_buffer_rsrc_t r, unsigned off) { __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 16); }
+__device__ __forceinline__ unsigned ldc_u32(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ double shfl64(double x, int src)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __shfl(lo, src, 64);
+    hi = __shfl(hi, src, 64);
+    return __hiloint2double(hi, lo);
+}
+
+// One step of a wave: the slots in `mask` apply their head rating.  FULL: every slot (no branches around
+// memory operations: one basic block of loads, one of stores).  Lane s < B owns slot s's scalar state.
+template <int KP, int NR, int MODE, bool FULL>
+__device__ __forceinline__ void res_step(const ResParams &P, unsigned long long mask, bool ready, const URec &rec, double tbv,
+                                         double &rbv, double &se, d2 (&vv)[NR], double *prod, __amdgpu_buffer_rsrc_t rT,
+                                         int lane, int g, int q, double &tbn)
+{
+    constexpr int SPW = 64 / KP, B = NR * SPW;
+    constexpr int stride = 2 * KP + 2;                       // rows 16-B aligned, stride / 2 odd (k1_stride at k = 2 KP)
+    const int k = P.k;
+    const bool fl = 2 * q < k;                               // this lane holds a feature pair
+    bool rdy[NR];
+    d2 uu[NR];
+    const unsigned qoff = (unsigned)q * 16u, rowb = (unsigned)(k * 8);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int src = j * SPW + g;
+        rdy[j] = fl && (FULL || ((mask >> src) & 1ull));
+        uu[j] = d2{0.0, 0.0};
+        // (the cross-lane read stays OUTSIDE the branch: ds_bpermute returns 0 for a source lane that is masked off)
+        const unsigned o = (unsigned)__shfl(rec.trav, src, 64) * rowb + qoff;
+        if (rdy[j]) uu[j] = __builtin_bit_cast(d2, ld16c(rT, o));
+    }
+#pragma unroll
+    for (int j = 0; j < NR; ++j)
+        if (rdy[j]) *reinterpret_cast<d2 *>(prod + (j * SPW + g) * stride + 2 * q) = d2{uu[j].x * vv[j].x, uu[j].y * vv[j].y};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    double grad = 0.0;
+    if (FULL ? (lane < B) : ready) {
+        // kmf_train.pyx:92: 0 + item bias + user bias, then the products left to right
+        double sum = P.res_item ? (0.0 + rbv + tbv) : (0.0 + tbv + rbv);
+        const double *row = prod + lane * stride;
+        int f = 0;
+        for (; f + 8 <= k; f += 8) {
+            const d2 a = *reinterpret_cast<const d2 *>(row + f), b = *reinterpret_cast<const d2 *>(row + f + 2);
+            const d2 c = *reinterpret_cast<const d2 *>(row + f + 4), d = *reinterpret_cast<const d2 *>(row + f + 6);
+            sum += a.x; sum += a.y; sum += b.x; sum += b.y; sum += c.x; sum += c.y; sum += d.x; sum += d.y;
+        }
+        for (; f < k; ++f) sum += row[f];
+        double err;
+        if constexpr (MODE == 0) {
+            err = rec.r - sum;                               // kmf_train.pyx:251-256
+            grad = err;
+        } else {
+            const double sig = 1.0 / (1.0 + exp(-sum));      // kmf_train.pyx:159-165
+            const double p = 1.0 + sig * 4.0;
+            err = rec.r - p;
+            grad = err * sig * (1.0 - sig) * 4.0;
+        }
+        se += err * err;
+        rbv = rbv + P.lr * (grad - P.Kb * rbv);              // :259-260 (both gates on in this path)
+        tbn = tbv + P.lr * (grad - P.Kb * tbv);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const double gr = shfl64(grad, j * SPW + g);
+        const unsigned o = (unsigned)__shfl(rec.trav, j * SPW + g, 64) * rowb + qoff;    // formed again rather than kept: a register per slot pair less
+        if (rdy[j]) {
+            const d2 mf = uu[j], cf = vv[j];
+            d2 un, vn;
+            un.x = mf.x + P.lr * (gr * cf.x - P.Ktrav * mf.x);   // :267-270, both rows from the OLD values
+            un.y = mf.y + P.lr * (gr * cf.y - P.Ktrav * mf.y);
+            vn.x = cf.x + P.lr * (gr * mf.x - P.Kres * cf.x);
+            vn.y = cf.y + P.lr * (gr * mf.y - P.Kres * cf.y);
+            st16c(__builtin_bit_cast(v4u, un), rT, o);
+            vv[j] = vn;
+        }
+    }
+}
+
+// KP lanes per row (16 bytes = one feature pair per lane: k <= 2 KP), NR register sets per lane, B = NR * 64/KP slots
+template <int KP, int NR, int MODE, bool STATIC>
+__global__ __launch_bounds__(64, STATIC ? 2 : 4) void k1_res(ResParams P)
+{
+    constexpr int SPW = 64 / KP, B = NR * SPW;
+    extern __shared__ __attribute__((aligned(16))) double prod[];       // [B][stride]
+    const int lane = threadIdx.x, g = lane / KP, q = lane % KP;
+    const int k = P.k;
+    const bool fl = 2 * q < k;
+    const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc(P.Tm, 0, 0x7fffffff, 0x27000);
+    const __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc(P.hdr, 0, 0x7fffffff, 0x27000);
+    constexpr unsigned long long ALL = (B == 64) ? ~0ull : ((1ull << B) - 1ull);
+    if (STATIC) {
+        // ---- registration: nothing is modified unless every wave of the grid is running ----------------
+        int ok = 1;
+        if (lane == 0) {
+            if (ldc_u32(P.ctl + kCtlStatus)) ok = 0;
+            else {
+                unsigned v = atomicAdd(P.ctl + kCtlReg, 1u) + 1u;
+                int spins = 0;
+                while (v != gridDim.x) {
+                    if (v & kRegFail) { ok = 0; break; }
+                    if (++spins > kSpinReg) {
+                        const unsigned old = atomicOr(P.ctl + kCtlReg, kRegFail);
+                        if (old != gridDim.x) { ok = 0; atomicOr(P.ctl + kCtlStatus, 1u); }   // (complete before the flag: go on)
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(8);
+                    v = ldc_u32(P.ctl + kCtlReg);
+                }
+            }
+        }
+        if (!__builtin_amdgcn_readfirstlane(ok)) return;
+    }
+    for (int pass = 0;; ++pass) {
+        int64_t run = -1;
+        if (STATIC) {
+            if (pass) break;
+            run = (int64_t)lane * gridDim.x + blockIdx.x;
+        } else {
+            unsigned b = 0;
+            if (lane == 0) b = ldc_u32(P.ctl + kCtlStatus) ? 0x7fffffffu : atomicAdd(P.ctl, 1u);   // a timed-out wave stops everyone
+            b = __builtin_amdgcn_readfirstlane(b);
+            if ((int64_t)b * B >= P.n_runs) break;
+            run = (int64_t)b * B + lane;
+        }
+        int pos = 0, end = 0;                               // relative to the run's first record
+        int64_t base = 0;
+        int my_ent = 0;
+        bool have = false;
+        if (lane < B && run < P.n_runs) { base = P.run_off[run]; end = (int)(P.run_off[run + 1] - base); my_ent = P.run_ent[run]; have = true; }
+        const URec *rp = P.recs + base;
+        URec rec{0, 0, 0.0}, nxt{0, 0, 0.0};
+        // records are read once per epoch: non-temporal
+        if (pos < end) rec = __builtin_bit_cast(URec, __builtin_nontemporal_load(reinterpret_cast<const v4i *>(rp + pos)));
+        if (pos + 1 < end) nxt = __builtin_bit_cast(URec, __builtin_nontemporal_load(reinterpret_cast<const v4i *>(rp + pos + 1)));
+        double rbv = have ? P.rb[my_ent] : 0.0;
+        d2 vv[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int ent = __shfl(my_ent, j * SPW + g, 64);
+            const int hv = __shfl((int)have, j * SPW + g, 64);
+            vv[j] = d2{0.0, 0.0};
+            if (hv && fl) vv[j] = *reinterpret_cast<const d2 *>(P.Rm + (size_t)ent * k + 2 * q);
+        }
+        double se = 0.0;
+        int spins = 0;
+        bool bail = false;
+        THdr h; h.bias = 0.0; h.cnt = -1; h.pad = 0;
+        if (pos < end) h = __builtin_bit_cast(THdr, ld16c(rH, (unsigned)rec.trav * 16u));
+        while (__any(pos < end)) {
+            const bool act = pos < end;
+            const bool ready = act && h.cnt == rec.seq;
+            const unsigned long long mask = __ballot(ready);
+            if (!mask) {
+                if (++spins > kSpinRun || ((spins & 1023) == 0 && ldc_u32(P.ctl + kCtlStatus))) {
+                    if (lane == 0) atomicOr(P.ctl + kCtlStatus, 3u);
+                    bail = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                if (act) h = __builtin_bit_cast(THdr, ld16c(rH, (unsigned)rec.trav * 16u));
+                continue;
+            }
+            double tbn = 0.0;
+            if (!STATIC && mask == ALL) res_step<KP, NR, MODE, true>(P, mask, ready, rec, h.bias, rbv, se, vv, prod, rT, lane, g, q, tbn);
+            else res_step<KP, NR, MODE, false>(P, mask, ready, rec, h.bias, rbv, se, vv, prod, rT, lane, g, q, tbn);
+            // publish: every row store of this wave has been acknowledged, then bias + chain counter in one granule
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const bool more = ready ? (pos + 1 < end) : act;
+            const int ntrav = ready ? nxt.trav : rec.trav;
+            if (ready) {
+                THdr nh; nh.bias = tbn; nh.cnt = rec.seq + 1; nh.pad = 0;
+                st16c(__builtin_bit_cast(v4u, nh), rH, (unsigned)rec.trav * 16u);
+                ++pos;
+                rec = nxt;
+                if (pos + 1 < end) nxt = __builtin_bit_cast(URec, __builtin_nontemporal_load(reinterpret_cast<const v4i *>(rp + pos + 1)));
+            }
+            h.cnt = -1;
+            if (more) h = __builtin_bit_cast(THdr, ld16c(rH, (unsigned)ntrav * 16u));
+            spins = 0;
+        }
+        if (bail) break;
+        // the runs are over: resident rows and biases go back (nobody else touches them this epoch)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int ent = __shfl(my_ent, j * SPW + g, 64);
+            const int hv = __shfl((int)have, j * SPW + g, 64);
+            if (hv && fl) *reinterpret_cast<d2 *>(P.Rm + (size_t)ent * k + 2 * q) = vv[j];
+        }
+        if (have) { P.rb[my_ent] = rbv; P.se_run[run] = se; }
+    }
+}
+
+__global__ void k_hdr_reset(THdr *hdr, const double *tb, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { THdr h; h.bias = tb[i]; h.cnt = 0; h.pad = 0; hdr[i] = h; }
+}
+__global__ void k_hdr_finish(const THdr *hdr, double *tb, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) tb[i] = hdr[i].bias;
+}
+
+int env_i(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+
+struct Sel { void *fn; int kp, nr; };
+
+template <int MODE, bool STATIC>
+Sel pick(int k)
+{
+    constexpr int NR = STATIC ? 16 : 4;
+    if (k <= 32) return {(void *)k1_res<16, NR, MODE, STATIC>, 16, NR};
+    if (k <= 64) return {(void *)k1_res<32, NR, MODE, STATIC>, 32, NR};
+    return {(void *)k1_res<64, NR, MODE, STATIC>, 64, NR};
+}
+Sel select(int k, int mode, bool stat)
+{
+    if (mode == 0) return stat ? pick<0, true>(k) : pick<0, false>(k);
+    return stat ? pick<1, true>(k) : pick<1, false>(k);
+}
+
+}  // namespace
+
+struct ResPlan {
+    int kind = 0;               // 1 = ticket, 2 = static
+    bool res_item = false;
+    int k = 0, nu = 0, ni = 0, n_res = 0, n_trav = 0, n_runs = 0;
+    int kp = 0, nr = 0, B = 0, waves = 0;
+    int64_t nnz = 0, se_slots = 0;
+    URec *d_recs = nullptr;
+    int64_t *d_run_off = nullptr;
+    int32_t *d_run_ent = nullptr;
+    THdr *d_hdr = nullptr;
+    unsigned *d_ctl = nullptr;
+    double *d_se_run = nullptr;
+    size_t dev_bytes = 0;
+    double est_ms = 0.0, build_ms = 0.0;
+};
+
+void res_destroy(ResPlan *rp)
+{
+    if (!rp) return;
+    void *ptrs[] = {rp->d_recs, rp->d_run_off, rp->d_run_ent, rp->d_hdr, rp->d_ctl, rp->d_se_run};
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    delete rp;
+}
+
+namespace {
+template <typename T>
+int ralloc(ResPlan *rp, T **ptr, size_t n)
+{
+    *ptr = nullptr;
+    const size_t bytes = (n ? n : 1) * sizeof(T);
+    hipError_t e = hipMalloc((void **)ptr, bytes);
+    if (e != hipSuccess) return fail(MFX_E_NOMEM, "hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
+    rp->dev_bytes += bytes;
+    return MFX_OK;
+}
+}  // namespace
+
+// Cost model (measured, DESIGN.md section 4 "K1 resident"): a chain of `levels` dependent steps of ~4.1 us
+// against a stream of nnz ratings at the coherent path's rate; the level schedule costs ~3.7 us per level
+// plus 20 line operations per rating at ~67 G lines/s.
+static double est_level_ms(int64_t nnz, int64_t levels) { return levels * 3.7e-3 + nnz * 0.30e-6; }
+static double est_res_ms(int64_t nnz, int64_t levels, bool stat)
+{
+    const double chain = levels * (stat ? 4.6e-3 : 4.15e-3), stream = nnz * (stat ? 0.30e-6 : 0.265e-6);
+    return chain > stream ? chain : stream;
+}
+
+// Decide whether a resident-side epoch applies to this plan and prepare it.  *out stays nullptr when it does
+// not.  want: MFX_EPOCH_AUTO (cost model; the environment variable MFX_K1_RES = levels / ticket / static overrides
+// it: tuning hook), MFX_EPOCH_LEVELS (never), MFX_EPOCH_TICKET / MFX_EPOCH_STATIC (that binding, or MFX_E_ARG
+// when the plan is not eligible for it).
+int res_prepare(ResPlan **out, const int32_t *idx, const double *r, int64_t nnz, int nu, int ni, int k, int64_t n_levels, int want)
+{
+    *out = nullptr;
+    bool forced = want == MFX_EPOCH_TICKET || want == MFX_EPOCH_STATIC;
+    if (want == MFX_EPOCH_AUTO) {
+        if (const char *e = getenv("MFX_K1_RES")) {
+            if (e[0] == 'l' || e[0] == '0') want = MFX_EPOCH_LEVELS;
+            else if (e[0] == 't') want = MFX_EPOCH_TICKET;
+            else if (e[0] == 's') want = MFX_EPOCH_STATIC;
+        }
+    }
+    if (want == MFX_EPOCH_LEVELS) return MFX_OK;
+    const bool shape_ok = nnz > 0 && nnz < ((int64_t)1 << 31) - 1 && n_levels > 0 && k % 2 == 0 && k > 16 && k <= 128;
+    if (!shape_ok) {
+        if (forced) return fail(MFX_E_ARG, "mfx_sgd_plan_create3: the resident-side epoch needs an even k in 18..128 and 0 < nnz < 2^31 (k=%d, nnz=%lld)", k, (long long)nnz);
+        return MFX_OK;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    hipDeviceProp_t prop;
+    int dev = 0;
+    MFX_HIP(hipGetDevice(&dev));
+    MFX_HIP(hipGetDeviceProperties(&prop, dev));
+    const int cus = prop.multiProcessorCount;
+    // ---- ticket: is the input grouped by user (every user one contiguous run)? ---------------------------
+    bool grouped = true;
+    int64_t n_runs_u = 0;
+    {
+        std::vector<unsigned char> seen((size_t)nu, 0);
+        int32_t prev = -1;
+        for (int64_t t = 0; t < nnz; ++t) {
+            const int32_t u = idx[2 * t];
+            if (u != prev) {
+                if (seen[(size_t)u]) { grouped = false; break; }
+                seen[(size_t)u] = 1;
+                ++n_runs_u;
+                prev = u;
+            }
+        }
+    }
+    const bool ticket_ok = grouped && (int64_t)ni * k * 8 < ((int64_t)1 << 31) && nnz / (n_runs_u ? n_runs_u : 1) >= 4;
+    // ---- static: the smaller side in registers, the whole grid resident -----------------------------------
+    const bool res_item = ni <= nu;
+    const int n_res = res_item ? ni : nu, n_trav = res_item ? nu : ni;
+    const Sel ss = select(k, 0, true), st = select(k, 0, false);
+    const int Bs = ss.nr * (64 / ss.kp), Bt = st.nr * (64 / st.kp);
+    int occ = 0;
+    const size_t lds_s = (size_t)Bs * (2 * ss.kp + 2) * 8, lds_t = (size_t)Bt * (2 * st.kp + 2) * 8;
+    MFX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ss.fn, 64, lds_s));
+    const int waves_s = occ * cus;
+    const bool static_ok = occ > 0 && (int64_t)waves_s * Bs >= n_res && (int64_t)n_trav * k * 8 < ((int64_t)1 << 31);
+    const double e_level = est_level_ms(nnz, n_levels);
+    const double e_ticket = ticket_ok ? est_res_ms(nnz, n_levels, false) : 1e30;
+    const double e_static = static_ok ? est_res_ms(nnz, n_levels, true) : 1e30;
+    int kind = 0;
+    if (want == MFX_EPOCH_TICKET) kind = ticket_ok ? 1 : 0;
+    else if (want == MFX_EPOCH_STATIC) kind = static_ok ? 2 : 0;
+    else if (e_ticket <= e_static && e_ticket < 0.9 * e_level) kind = 1;
+    else if (e_static < e_ticket && e_static < 0.9 * e_level) kind = 2;
+    if (!kind) {
+        if (forced && want == MFX_EPOCH_TICKET)
+            return fail(MFX_E_ARG, "mfx_sgd_plan_create3: MFX_EPOCH_TICKET needs ratings grouped by user (every user one contiguous run of >= 4 ratings on average) and item rows below 2 GB");
+        if (forced)
+            return fail(MFX_E_ARG, "mfx_sgd_plan_create3: MFX_EPOCH_STATIC needs the smaller side in registers (min(users, items) = %d > %lld rows at k = %d) and the other side's rows below 2 GB",
+                        n_res, (long long)waves_s * Bs, k);
+        return MFX_OK;
+    }
+
+    ResPlan *rp = new (std::nothrow) ResPlan();
+    if (!rp) return fail(MFX_E_NOMEM, "mfx_sgd_plan_create: out of host memory");
+    rp->kind = kind;
+    rp->k = k; rp->nu = nu; rp->ni = ni; rp->nnz = nnz;
+    rp->est_ms = kind == 1 ? e_ticket : e_static;
+    auto bail = [&](int rc) { res_destroy(rp); return rc; };
+    try {
+        std::vector<URec> recs((size_t)nnz);
+        std::vector<int64_t> run_off;
+        std::vector<int32_t> run_ent;
+        if (kind == 1) {
+            rp->res_item = false; rp->n_res = nu; rp->n_trav = ni;
+            rp->kp = st.kp; rp->nr = st.nr; rp->B = Bt;
+            std::vector<int32_t> ctr((size_t)ni, 0);
+            run_off.reserve((size_t)n_runs_u + 1); run_ent.reserve((size_t)n_runs_u);
+            int32_t prev = -1;
+            for (int64_t t = 0; t < nnz; ++t) {
+                const int32_t u = idx[2 * t], i = idx[2 * t + 1];
+                if (u != prev) { run_off.push_back(t); run_ent.push_back(u); prev = u; }
+                recs[(size_t)t] = URec{i, ctr[(size_t)i]++, r[t]};
+            }
+            run_off.push_back(nnz);
+            // enough waves to fill the chip at the kernel's residency; the grid size is free in this mode
+            int occ_t = 0;
+            MFX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_t, st.fn, 64, lds_t));
+            rp->waves = (occ_t > 0 ? occ_t : 8) * cus;
+            const int64_t tickets = ceil_div((int64_t)run_ent.size(), (int64_t)Bt);
+            if (rp->waves > tickets) rp->waves = (int)tickets;
+            rp->se_slots = (int64_t)run_ent.size();
+        } else {
+            rp->res_item = res_item; rp->n_res = n_res; rp->n_trav = n_trav;
+            rp->kp = ss.kp; rp->nr = ss.nr; rp->B = Bs; rp->waves = waves_s;
+            const int rc_ = res_item ? 1 : 0, tc_ = res_item ? 0 : 1;
+            std::vector<int64_t> cnt((size_t)n_res + 1, 0);
+            for (int64_t t = 0; t < nnz; ++t) ++cnt[(size_t)idx[2 * t + rc_] + 1];
+            for (int e = 0; e < n_res; ++e) cnt[(size_t)e + 1] += cnt[(size_t)e];
+            std::vector<int64_t> fill(cnt.begin(), cnt.end() - 1);
+            std::vector<int32_t> ctr((size_t)n_trav, 0);
+            for (int64_t t = 0; t < nnz; ++t) {
+                const int32_t tr = idx[2 * t + tc_];
+                recs[(size_t)fill[(size_t)idx[2 * t + rc_]]++] = URec{tr, ctr[(size_t)tr]++, r[t]};
+            }
+            run_off.assign(cnt.begin(), cnt.end());          // every entity is a run (possibly empty); run = entity id
+            run_ent.resize((size_t)n_res);
+            for (int e = 0; e < n_res; ++e) run_ent[(size_t)e] = e;
+            rp->se_slots = (int64_t)rp->waves * rp->B;
+        }
+        rp->n_runs = (int)run_ent.size();
+        if (ralloc(rp, &rp->d_recs, (size_t)nnz) || ralloc(rp, &rp->d_run_off, run_off.size()) || ralloc(rp, &rp->d_run_ent, run_ent.size()) ||
+            ralloc(rp, &rp->d_hdr, (size_t)rp->n_trav) || ralloc(rp, &rp->d_ctl, (size_t)kCtlWords) || ralloc(rp, &rp->d_se_run, (size_t)rp->se_slots))
+            return bail(last_code());
+        if (hipMemcpy(rp->d_recs, recs.data(), (size_t)nnz * sizeof(URec), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(rp->d_run_off, run_off.data(), run_off.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(rp->d_run_ent, run_ent.data(), run_ent.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemset(rp->d_ctl, 0, kCtlWords * sizeof(unsigned)) != hipSuccess ||
+            hipMemset(rp->d_se_run, 0, (size_t)(rp->se_slots ? rp->se_slots : 1) * sizeof(double)) != hipSuccess)
+            return bail(fail(MFX_E_HIP, "mfx_sgd_plan_create: upload of the resident-side records failed: %s", hipGetErrorString(hipGetLastError())));
+    } catch (const std::bad_alloc &) {
+        return bail(fail(MFX_E_NOMEM, "mfx_sgd_plan_create: out of host memory"));
+    }
+    rp->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    *out = rp;
+    return MFX_OK;
+}
+
+int res_kind(const ResPlan *rp) { return rp ? rp->kind : 0; }
+size_t res_dev_bytes(const ResPlan *rp) { return rp ? rp->dev_bytes : 0; }
+int64_t res_se_slots(const ResPlan *rp) { return rp->se_slots; }
+const double *res_se_partials(const ResPlan *rp) { return rp->d_se_run; }
+int res_describe(const ResPlan *rp, int mode, char *buf, int buflen)
+{
+    static const char *const mode_name[] = {"linear", "logistic"};
+    snprintf(buf, (size_t)buflen, "k1_res<%d lanes/row,%d slots,%s,%s: %s rows resident,%d waves>", rp->kp, rp->B,
+             mode_name[mode & 1], rp->kind == 1 ? "ticket" : "static", rp->res_item ? "item" : "user", rp->waves);
+    return MFX_OK;
+}
+
+// clear the sticky status word: once per batch of epochs
+int res_begin_batch(ResPlan *rp)
+{
+    MFX_HIP(hipMemsetAsync(rp->d_ctl + kCtlStatus, 0, sizeof(unsigned), stream()));
+    return MFX_OK;
+}
+
+// enqueue ONE epoch on the library stream (capturable): counters, granules, the persistent launch, biases back
+int res_enqueue_epoch(ResPlan *rp, int mode, double *U_nk, double *V_nk, double *ib, double *ub, double lr, double Ku,
+                      double Ki, double Kb)
+{
+    ResParams P;
+    memset(&P, 0, sizeof(P));
+    P.recs = rp->d_recs; P.run_off = rp->d_run_off; P.run_ent = rp->d_run_ent;
+    P.Tm = rp->res_item ? V_nk : U_nk;
+    P.Rm = rp->res_item ? U_nk : V_nk;
+    double *tb = rp->res_item ? ub : ib;
+    P.rb = rp->res_item ? ib : ub;
+    P.hdr = rp->d_hdr; P.ctl = rp->d_ctl; P.se_run = rp->d_se_run;
+    P.n_runs = rp->n_runs; P.k = rp->k; P.res_item = rp->res_item ? 1 : 0;
+    P.lr = lr; P.Kres = rp->res_item ? Ki : Ku; P.Ktrav = rp->res_item ? Ku : Ki; P.Kb = Kb;
+    const Sel s = select(rp->k, mode, rp->kind == 2);
+    MFX_HIP(hipMemsetAsync(rp->d_ctl, 0, sizeof(unsigned), stream()));                          // ticket
+    MFX_HIP(hipMemsetAsync(rp->d_ctl + kCtlReg, 0, sizeof(unsigned), stream()));                // registration
+    hipLaunchKernelGGL(k_hdr_reset, dim3(ceil_div(rp->n_trav, 256)), dim3(256), 0, stream(), rp->d_hdr, (const double *)tb, rp->n_trav);
+    void *args[] = {&P};
+    MFX_HIP(hipLaunchKernel(s.fn, dim3(rp->waves), dim3(64), args, (size_t)rp->B * (2 * rp->kp + 2) * 8, stream()));
+    hipLaunchKernelGGL(k_hdr_finish, dim3(ceil_div(rp->n_trav, 256)), dim3(256), 0, stream(), (const THdr *)rp->d_hdr, tb, rp->n_trav);
+    MFX_HIP(hipGetLastError());
+    return MFX_OK;
+}
+
+// after a stream sync: 0 = fine, 1 = the static grid was not resident (NOTHING was modified by any epoch of the
+// batch), 3 = a spin timed out mid-epoch (state undefined)
+int res_status(ResPlan *rp, unsigned *status)
+{
+    MFX_HIP(hipMemcpy(status, rp->d_ctl + kCtlStatus, sizeof(unsigned), hipMemcpyDeviceToHost));
+    return MFX_OK;
+}
+
+}  // namespace mfx

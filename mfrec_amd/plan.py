@@ -13,20 +13,28 @@ LINEAR, LOGISTIC = 0, 1
 
 class SgdPlan(object):
     SCHEDULE = {"auto": 0, "host": 1, "device": 2}
+    EPOCH = {"auto": 0, "levels": 1, "ticket": 2, "static": 3}
 
     def __init__(self, ratings_index, ratings, nbr_users, nbr_items, dim, storage="f64", schedule="auto",
-                 dot="ordered"):
+                 dot="ordered", epoch="auto"):
         """schedule: who builds the dependency-level schedule -- "host" (sequential pass + threaded
         counting sort), "device" (radix sorts + one frontier launch per level in HBM) or "auto"
-        (device for >= 2^20 ratings unless the data needs more than nnz/1000 levels).  Same result."""
+        (device for >= 2^20 ratings unless the data needs more than nnz/1000 levels).  Same result.
+        epoch: the kernel of a plain full-k epoch (include/mfx.h MFX_EPOCH_*): "levels" (one launch per dependency
+        level), "ticket" (user rows resident, runs by ticket: input grouped by user), "static" (the smaller side's
+        rows owned by fixed waves: any order, must fit the register file) or "auto" (cost model).  Same bits."""
+        if epoch not in self.EPOCH:
+            raise ValueError("epoch must be 'auto', 'levels', 'ticket' or 'static'")
         if schedule not in self.SCHEDULE:
             raise ValueError("schedule must be 'auto', 'host' or 'device'")
         pi, pr, nnz = S.ratings_args(ratings_index, ratings)
         self.nu, self.ni, self.k, self.nnz = int(nbr_users), int(nbr_items), int(dim), nnz
-        self._h = S.lib().mfx_sgd_plan_create2(pi, pr, nnz, self.nu, self.ni, self.k, self.SCHEDULE[schedule])
+        self._h = S.lib().mfx_sgd_plan_create3(pi, pr, nnz, self.nu, self.ni, self.k, self.SCHEDULE[schedule],
+                                               self.EPOCH[epoch])
         if not self._h:
             msg = S.last_error()
-            raise (ValueError if ("outside" in msg or "bad argument" in msg) else S.MfxError)(msg)
+            raise (ValueError if ("outside" in msg or "bad argument" in msg or "MFX_EPOCH" in msg
+                                  or "resident-side" in msg) else S.MfxError)(msg)
         if storage not in ("f64", "f32", "bf16"):
             raise ValueError("storage must be 'f64' (exact), 'f32' (fast mode) or 'bf16' (measured option)")
         self.storage = storage
@@ -64,6 +72,10 @@ class SgdPlan(object):
                 "device_bytes", "schedule_us", "funk_launches_per_epoch")
         d = dict(zip(keys, [int(x) for x in a]))
         d["schedule_builder"] = {1: "host", 2: "device"}.get(S.lib().mfx_sgd_plan_schedule_builder(self._h), "?")
+        b = (C.c_int64 * 4)()
+        S.check(S.lib().mfx_sgd_plan_res_info(self._h, b))
+        names = {1: "levels", 2: "ticket", 3: "static"}
+        d["epoch_kernel"], d["epoch_kernel_prepared"] = names.get(int(b[0]), "?"), names.get(int(b[1]), "?")
         return d
 
     def kernel_name(self, mode=LINEAR):

@@ -1,0 +1,166 @@
+"""GPU parity of the resident-side full-k epoch (mfx_sgd_res.hip: MFX_EPOCH_TICKET / MFX_EPOCH_STATIC)
+against the oracle: train_linear_kernel / train_logistic_kernel (kmf_train.pyx:195-277, :103-189).
+
+The resident-side launch must give the level schedule's bits -- i.e. the sequential loop's -- whatever
+the binding: user rows resident with runs taken by ticket (ratings grouped by user), or the smaller
+side's rows owned by fixed waves (any order)."""
+import numpy as np
+import pytest
+
+from mfrec_amd import synth
+from mfrec_amd.plan import LINEAR, LOGISTIC, SgdPlan
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+LR, KU, KI, KB = 0.01, 0.1, 0.1, 0.007
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    from mfrec_amd import _shim as S
+    from mfrec_amd import build as B
+    B.build(verbose=False)
+    S.init(0)            # raises if the HIP library or the GPU is missing: no fallback
+    yield
+
+
+def _run_plan(idx, r, nu, ni, k, u0, v0, epochs, mode, epoch, ib0=None, ub0=None, calls=1):
+    u, v = u0.copy(), v0.copy()
+    ib = np.zeros(ni) if ib0 is None else ib0.copy()
+    ub = np.zeros(nu) if ub0 is None else ub0.copy()
+    with SgdPlan(idx, r, nu, ni, k, epoch=epoch) as p:
+        info = p.info()
+        p.set_factors(u, v, ib, ub)
+        rm = []
+        for _ in range(calls):
+            rm.append(p.run_kmf(mode, epochs, LR, KU, KI, KB))
+        p.get_factors(u, v, ib, ub)
+        name = p.kernel_name(mode)
+        info_after = p.info()
+    return u, v, ib, ub, np.concatenate(rm), info, info_after, name
+
+
+def _oracle(idx, r, nu, ni, k, u0, v0, epochs, mode, ib0=None, ub0=None):
+    u, v = u0.copy(), v0.copy()
+    ib = np.zeros(ni) if ib0 is None else ib0.copy()
+    ub = np.zeros(nu) if ub0 is None else ub0.copy()
+    fn = O.train_linear_kernel if mode == LINEAR else O.train_logistic_kernel
+    fn(epochs, k, 0.1, LR, 0, 0, KU, KI, KB, 0.0, u, v, idx, r, ib, ub)
+    return u, v, ib, ub
+
+
+def _check(got, want, mode):
+    if mode == LINEAR:
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+    else:       # logistic: device exp() is within 1 ulp of libm's (tests/test_gpu_parity.py)
+        for a, b in zip(got, want):
+            np.testing.assert_allclose(a, b, rtol=1e-11, atol=1e-14)
+
+
+@pytest.mark.parametrize("k", [18, 32, 64, 66, 128])
+@pytest.mark.parametrize("mode", [LINEAR, LOGISTIC])
+def test_ticket_user_major_vs_oracle(k, mode):
+    nu, ni, nnz, E = 700, 300, 30000, 3
+    idx, r = synth.make_ratings(nu, ni, nnz, seed=5)
+    idx, r = synth.user_major(idx, r)                        # get_ratings(randomize_order=False)
+    u0, v0 = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
+    rs = np.random.RandomState(3)
+    ib0, ub0 = rs.normal(0, 0.05, ni), rs.normal(0, 0.05, nu)
+    u, v, ib, ub, rm, info, _, name = _run_plan(idx, r, nu, ni, k, u0, v0, E, mode, "ticket", ib0, ub0)
+    assert info["epoch_kernel"] == "ticket" and "ticket" in name
+    _check((u, v, ib, ub), _oracle(idx, r, nu, ni, k, u0, v0, E, mode, ib0, ub0), mode)
+    assert np.all(np.isfinite(rm)) and rm.shape == (E,)
+
+
+@pytest.mark.parametrize("shape", [(900, 250), (250, 900)])     # items resident / users resident
+@pytest.mark.parametrize("k", [20, 64, 128])
+@pytest.mark.parametrize("mode", [LINEAR, LOGISTIC])
+def test_static_any_order_vs_oracle(shape, k, mode):
+    nu, ni = shape
+    nnz, E = 40000, 3
+    idx, r = synth.make_ratings(nu, ni, nnz, seed=9)          # generation order = a shuffled order, duplicates kept
+    u0, v0 = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
+    u, v, ib, ub, rm, info, _, name = _run_plan(idx, r, nu, ni, k, u0, v0, E, mode, "static")
+    assert info["epoch_kernel"] == "static" and ("item rows" if ni <= nu else "user rows") in name
+    _check((u, v, ib, ub), _oracle(idx, r, nu, ni, k, u0, v0, E, mode), mode)
+
+
+def test_static_on_user_major_and_repeated_calls():
+    """The static binding takes any order, also a grouped one; a second call continues from the first."""
+    nu, ni, nnz, k = 400, 600, 25000, 64
+    idx, r = synth.user_major(*synth.make_ratings(nu, ni, nnz, seed=2))
+    u0, v0 = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
+    got = _run_plan(idx, r, nu, ni, k, u0, v0, 2, LINEAR, "static", calls=2)
+    _check(got[:4], _oracle(idx, r, nu, ni, k, u0, v0, 4, LINEAR), LINEAR)
+    got = _run_plan(idx, r, nu, ni, k, u0, v0, 2, LINEAR, "ticket", calls=2)
+    _check(got[:4], _oracle(idx, r, nu, ni, k, u0, v0, 4, LINEAR), LINEAR)
+
+
+def test_rmse_matches_level_schedule():
+    """Per-epoch online RMSE: a deterministic fixed-association sum in every kernel (1e-12 relative)."""
+    nu, ni, nnz, k = 500, 400, 30000, 64
+    idx, r = synth.user_major(*synth.make_ratings(nu, ni, nnz, seed=4))
+    u0, v0 = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
+    rms = {e: _run_plan(idx, r, nu, ni, k, u0, v0, 3, LINEAR, e)[4] for e in ("levels", "ticket", "static")}
+    np.testing.assert_allclose(rms["ticket"], rms["levels"], rtol=1e-12)
+    np.testing.assert_allclose(rms["static"], rms["levels"], rtol=1e-12)
+    again = _run_plan(idx, r, nu, ni, k, u0, v0, 3, LINEAR, "ticket")[4]
+    assert np.array_equal(again, rms["ticket"])              # same bits run to run, whatever the placement
+
+
+def test_edge_cases():
+    """One user holding every rating (a single run), users without ratings, trailing unrated ids, a run of one."""
+    k = 64
+    u0 = synth.init_normal(k, 50, 1)
+    # one user, 300 ratings over 50 items (each item's chain is this user's own order)
+    idx = np.stack([np.zeros(300, dtype=np.int32), (np.arange(300) * 7 % 50).astype(np.int32)], axis=1)
+    r = (1.0 + np.arange(300) % 5).astype(np.float64)
+    v0 = synth.init_normal(k, 3, 2)
+    for e in ("ticket", "static"):
+        got = _run_plan(np.ascontiguousarray(idx), r, 3, 50, k, u0, v0, 2, LINEAR, e)
+        _check(got[:4], _oracle(idx, r, 3, 50, k, u0, v0, 2, LINEAR), LINEAR)
+    # users 1 and 3 unrated, user 9 (last id) unrated, user 5 has one rating
+    users = np.array([0] * 40 + [2] * 30 + [4] * 50 + [5] + [7] * 60, dtype=np.int32)
+    items = (np.arange(users.size) * 11 % 37).astype(np.int32)
+    idx = np.ascontiguousarray(np.stack([users, items], axis=1))
+    r = (1.0 + np.arange(users.size) % 5).astype(np.float64)
+    u0, v0 = synth.init_normal(k, 40, 1), synth.init_normal(k, 10, 2)
+    for e in ("ticket", "static"):
+        got = _run_plan(idx, r, 10, 40, k, u0, v0, 3, LINEAR, e)
+        _check(got[:4], _oracle(idx, r, 10, 40, k, u0, v0, 3, LINEAR), LINEAR)
+
+
+def test_not_eligible_is_an_argument_error():
+    nu, ni, nnz = 300, 200, 5000
+    idx, r = synth.make_ratings(nu, ni, nnz, seed=1)          # not grouped by user
+    with pytest.raises(ValueError):
+        SgdPlan(idx, r, nu, ni, 64, epoch="ticket")
+    with pytest.raises(ValueError):
+        SgdPlan(idx, r, nu, ni, 7, epoch="static")            # odd k
+    big = 70000                                               # more rows than the register file holds at k = 64
+    idx2 = np.stack([np.arange(big, dtype=np.int32) % big, np.arange(big, dtype=np.int32)], axis=1)
+    with pytest.raises(ValueError):
+        SgdPlan(np.ascontiguousarray(idx2), np.ones(big), big, big, 64, epoch="static")
+    # AUTO never fails: it falls back to the level schedule
+    with SgdPlan(idx, r, nu, ni, 7) as p:
+        assert p.info()["epoch_kernel"] == "levels"
+
+
+def test_gated_and_narrow_runs_take_the_level_schedule():
+    """update_users/items gates, f32 storage and the butterfly dot are served by the level kernels of the same plan."""
+    nu, ni, nnz, k = 300, 500, 20000, 64
+    idx, r = synth.user_major(*synth.make_ratings(nu, ni, nnz, seed=8))
+    u0, v0 = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
+    u, v, ib, ub = u0.copy(), v0.copy(), np.zeros(ni), np.zeros(nu)
+    with SgdPlan(idx, r, nu, ni, k, epoch="ticket") as p:
+        p.set_factors(u, v, ib, ub)
+        p.run_kmf(LINEAR, 2, LR, KU, KI, KB)                              # resident
+        p.run_kmf(LINEAR, 1, LR, KU, KI, KB, update_users=1, update_items=0)   # levels
+        p.run_kmf(LINEAR, 1, LR, KU, KI, KB)                              # resident again
+        p.get_factors(u, v, ib, ub)
+    u2, v2, ib2, ub2 = u0.copy(), v0.copy(), np.zeros(ni), np.zeros(nu)
+    O.train_linear_kernel(2, k, 0.1, LR, 0, 0, KU, KI, KB, 0.0, u2, v2, idx, r, ib2, ub2)
+    O.train_linear_kernel(1, k, 0.1, LR, 0, 0, KU, KI, KB, 0.0, u2, v2, idx, r, ib2, ub2, 1, 0)
+    O.train_linear_kernel(1, k, 0.1, LR, 0, 0, KU, KI, KB, 0.0, u2, v2, idx, r, ib2, ub2)
+    _check((u, v, ib, ub), (u2, v2, ib2, ub2), LINEAR)

@@ -35,11 +35,13 @@ __device__ __forceinline__ void st16c(v4u v, __amdgpu_buffer_rsrc_t r, unsigned 
 constexpr int K = 64, KP = 32, SPW = 2, STRIDE = 66;
 constexpr int SPIN_LIMIT = 1 << 18;
 
+// "resident" side R (rows + biases in registers for a whole run), "travelling" side T (rows through the coherent path,
+// bias + chain counter in one 16-byte granule).  RES_ITEM: the resident side is the item side.
 // one step of the B slots of a wave.  FULL: every slot advances (no branches around memory operations).
-template <int B, bool FULL>
-__device__ __forceinline__ void ur_step(unsigned long long mask, bool ready, const URec &rec, double ibv, double &ubv, double &se,
-                                        d2 (&vv)[B / SPW], double *prod, __amdgpu_buffer_rsrc_t rU, int lane, int g, int q,
-                                        double lr, double Ku, double Ki, double Kb, double &ibn)
+template <int B, bool FULL, bool RES_ITEM>
+__device__ __forceinline__ void res_step(unsigned long long mask, bool ready, const URec &rec, double tbv, double &rbv, double &se,
+                                         d2 (&vv)[B / SPW], double *prod, __amdgpu_buffer_rsrc_t rT, int lane, int g, int q,
+                                         double lr, double Kres, double Ktrav, double Kb, double &tbn)
 {
     constexpr int NR = B / SPW;
     unsigned uoff[NR];
@@ -55,19 +57,20 @@ __device__ __forceinline__ void ur_step(unsigned long long mask, bool ready, con
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
         uu[j] = d2{0.0, 0.0};
-        if (FULL || rdy[j]) uu[j] = __builtin_bit_cast(d2, ld16c(rU, uoff[j]));
+        if (FULL || rdy[j]) uu[j] = __builtin_bit_cast(d2, ld16c(rT, uoff[j]));
     }
 #pragma unroll
     for (int j = 0; j < NR; ++j)
-        *reinterpret_cast<d2 *>(prod + (j * SPW + g) * STRIDE + 2 * q) = d2{uu[j].x * vv[j].x, uu[j].y * vv[j].y};
+        if (FULL || rdy[j])
+            *reinterpret_cast<d2 *>(prod + (j * SPW + g) * STRIDE + 2 * q) = d2{uu[j].x * vv[j].x, uu[j].y * vv[j].y};
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     double grad = 0.0;
     if (FULL ? (lane < B) : ready) {
-        double sum = 0.0 + ibv + ubv;                        // kmf_train.pyx:92
+        double sum = RES_ITEM ? (0.0 + rbv + tbv) : (0.0 + tbv + rbv);   // kmf_train.pyx:92: item bias first
         const double *row = prod + lane * STRIDE;
-#pragma unroll
+#pragma unroll 2
         for (int f = 0; f < K; f += 8) {
             const d2 a = *reinterpret_cast<const d2 *>(row + f), b = *reinterpret_cast<const d2 *>(row + f + 2);
             const d2 c = *reinterpret_cast<const d2 *>(row + f + 4), d = *reinterpret_cast<const d2 *>(row + f + 6);
@@ -76,8 +79,8 @@ __device__ __forceinline__ void ur_step(unsigned long long mask, bool ready, con
         const double e = rec.r - sum;                        // kmf_train.pyx:251-256
         grad = e;
         se += e * e;
-        ubv = ubv + lr * (grad - Kb * ubv);                  // :259-260
-        ibn = ibv + lr * (grad - Kb * ibv);
+        rbv = rbv + lr * (grad - Kb * rbv);                  // :259-260
+        tbn = tbv + lr * (grad - Kb * tbv);
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -86,86 +89,104 @@ __device__ __forceinline__ void ur_step(unsigned long long mask, bool ready, con
         if (FULL || rdy[j]) {
             const d2 mf = uu[j], cf = vv[j];
             d2 un, vn;
-            un.x = mf.x + lr * (gr * cf.x - Ki * mf.x);      // :267-270
-            un.y = mf.y + lr * (gr * cf.y - Ki * mf.y);
-            vn.x = cf.x + lr * (gr * mf.x - Ku * cf.x);
-            vn.y = cf.y + lr * (gr * mf.y - Ku * cf.y);
-            st16c(__builtin_bit_cast(v4u, un), rU, uoff[j]);
+            un.x = mf.x + lr * (gr * cf.x - Ktrav * mf.x);   // :267-270
+            un.y = mf.y + lr * (gr * cf.y - Ktrav * mf.y);
+            vn.x = cf.x + lr * (gr * mf.x - Kres * cf.x);
+            vn.y = cf.y + lr * (gr * mf.y - Kres * cf.y);
+            st16c(__builtin_bit_cast(v4u, un), rT, uoff[j]);
             vv[j] = vn;
         }
     }
 }
 
-template <int B, bool NOPOLL>
-__global__ __launch_bounds__(64) void k1_ur(const URec *__restrict__ recs, const int64_t *__restrict__ run_off,
-                                            const int *__restrict__ run_user, int n_runs, double *U, double *V, IHdr *hdr,
-                                            double *ub, int *ticket, double *se_run, int *err, double lr, double Ku,
-                                            double Ki, double Kb)
+// STATIC: every wave owns fixed entities for the whole epoch (run index = slot * waves + wave): any input order, needs the
+// whole grid resident.  !STATIC: runs taken by ticket in input order (input grouped by the resident side).
+// OVL: the polls of the next heads are issued before the wait for the row stores' acknowledgement.
+template <int B, bool STATIC, bool RES_ITEM, bool OVL, bool NOPOLL, int MINW>
+__global__ __launch_bounds__(64, MINW) void k1_res(const URec *__restrict__ recs, const int64_t *__restrict__ run_off,
+                                            const int *__restrict__ run_ent, int n_runs, double *Tm, double *Rm, IHdr *hdr,
+                                            double *rb, int *ticket, double *se_run, int *err, double lr, double Kres, double Ktrav,
+                                            double Kb)
 {
     constexpr int NR = B / SPW;
     __shared__ __attribute__((aligned(16))) double prod[B * STRIDE];
     const int lane = threadIdx.x, g = lane / KP, q = lane % KP;
-    const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc(U, 0, 0x7fffffff, 0x27000);
+    const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc(Tm, 0, 0x7fffffff, 0x27000);
     const __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc(hdr, 0, 0x7fffffff, 0x27000);
     constexpr unsigned long long ALL = (B == 64) ? ~0ull : ((1ull << B) - 1ull);
-    for (;;) {
-        int b = 0;
-        if (lane == 0) b = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0x7fffffff : atomicAdd(ticket, 1);
-        b = __builtin_amdgcn_readfirstlane(b);
-        if ((int64_t)b * B >= n_runs) break;
-        int64_t pos = 0, end = 0;
-        int my_user = 0;
+    for (int pass = 0;; ++pass) {
+        int64_t run = -1;
+        if (STATIC) {
+            if (pass) break;
+            run = (int64_t)lane * gridDim.x + blockIdx.x;
+        } else {
+            int b = 0;
+            if (lane == 0) b = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0x7fffffff : atomicAdd(ticket, 1);
+            b = __builtin_amdgcn_readfirstlane(b);
+            if ((int64_t)b * B >= n_runs) break;
+            run = (int64_t)b * B + lane;
+        }
+        int pos = 0, end = 0;                              // relative to the run's first record
+        int64_t base = 0;
+        int my_ent = 0;
         bool have = false;
-        if (lane < B && b * B + lane < n_runs) { pos = run_off[b * B + lane]; end = run_off[b * B + lane + 1]; my_user = run_user[b * B + lane]; have = true; }
+        if (lane < B && run < n_runs) { base = run_off[run]; end = (int)(run_off[run + 1] - base); my_ent = run_ent[run]; have = true; }
+        const URec *rp = recs + base;
         URec rec{0, 0, 0.0}, nxt{0, 0, 0.0};
-        if (pos < end) rec = __builtin_bit_cast(URec, __builtin_nontemporal_load(reinterpret_cast<const v4i32 *>(recs + pos)));
-        if (pos + 1 < end) nxt = __builtin_bit_cast(URec, __builtin_nontemporal_load(reinterpret_cast<const v4i32 *>(recs + pos + 1)));
-        double ubv = have ? ub[my_user] : 0.0;
+        if (pos < end) rec = __builtin_bit_cast(URec, __builtin_nontemporal_load(reinterpret_cast<const v4i32 *>(rp + pos)));
+        if (pos + 1 < end) nxt = __builtin_bit_cast(URec, __builtin_nontemporal_load(reinterpret_cast<const v4i32 *>(rp + pos + 1)));
+        double rbv = have ? rb[my_ent] : 0.0;
         d2 vv[NR];
-        int usr[NR], hv[NR];
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
-            usr[j] = __shfl(my_user, j * SPW + g, 64);
-            hv[j] = __shfl((int)have, j * SPW + g, 64);
+            const int ent = __shfl(my_ent, j * SPW + g, 64);
+            const int hv = __shfl((int)have, j * SPW + g, 64);
             vv[j] = d2{0.0, 0.0};
-            if (hv[j]) vv[j] = *reinterpret_cast<const d2 *>(V + (size_t)usr[j] * K + 2 * q);
+            if (hv) vv[j] = *reinterpret_cast<const d2 *>(Rm + (size_t)ent * K + 2 * q);
         }
         double se = 0.0;
         int spins = 0;
         bool bail = false;
+        IHdr h; h.ib = 0.0; h.cnt = -1; h.pad = 0;
+        if (pos < end) h = __builtin_bit_cast(IHdr, ld16c(rH, (unsigned)rec.item * 16u));
         while (__any(pos < end)) {
-            bool ready = false;
-            double ibv = 0.0;
-            if (pos < end) {
-                const IHdr h = __builtin_bit_cast(IHdr, ld16c(rH, (unsigned)rec.item * 16u));
-                ibv = h.ib;
-                ready = NOPOLL || (h.cnt == rec.seq);
-            }
+            const bool act = pos < end;
+            const bool ready = act && (NOPOLL || h.cnt == rec.seq);
             const unsigned long long mask = __ballot(ready);
             if (!mask) {
                 if (++spins > SPIN_LIMIT) { if (lane == 0) atomicOr(err, 1); bail = true; break; }
                 __builtin_amdgcn_s_sleep(1);
+                if (act) h = __builtin_bit_cast(IHdr, ld16c(rH, (unsigned)rec.item * 16u));
                 continue;
             }
-            double ibn = 0.0;
-            if (mask == ALL) ur_step<B, true>(mask, ready, rec, ibv, ubv, se, vv, prod, rU, lane, g, q, lr, Ku, Ki, Kb, ibn);
-            else ur_step<B, false>(mask, ready, rec, ibv, ubv, se, vv, prod, rU, lane, g, q, lr, Ku, Ki, Kb, ibn);
+            double tbn = 0.0;
+            if (!STATIC && mask == ALL) res_step<B, true, RES_ITEM>(mask, ready, rec, h.ib, rbv, se, vv, prod, rT, lane, g, q, lr, Kres, Ktrav, Kb, tbn);
+            else res_step<B, false, RES_ITEM>(mask, ready, rec, h.ib, rbv, se, vv, prod, rT, lane, g, q, lr, Kres, Ktrav, Kb, tbn);
+            IHdr hn; hn.ib = 0.0; hn.cnt = -1; hn.pad = 0;
+            const bool more = ready ? (pos + 1 < end) : act;
+            const int nitem = ready ? nxt.item : rec.item;
+            if (OVL) { if (more) hn = __builtin_bit_cast(IHdr, ld16c(rH, (unsigned)nitem * 16u)); }
             // publish: every row store of this wave has completed, then bias + chain counter in one granule
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (ready) {
-                IHdr nh; nh.ib = ibn; nh.cnt = rec.seq + 1; nh.pad = 0;
+                IHdr nh; nh.ib = tbn; nh.cnt = rec.seq + 1; nh.pad = 0;
                 st16c(__builtin_bit_cast(v4u, nh), rH, (unsigned)rec.item * 16u);
                 ++pos;
                 rec = nxt;
-                if (pos + 1 < end) nxt = __builtin_bit_cast(URec, __builtin_nontemporal_load(reinterpret_cast<const v4i32 *>(recs + pos + 1)));
+                if (pos + 1 < end) nxt = __builtin_bit_cast(URec, __builtin_nontemporal_load(reinterpret_cast<const v4i32 *>(rp + pos + 1)));
             }
+            if (!OVL) { if (more) hn = __builtin_bit_cast(IHdr, ld16c(rH, (unsigned)nitem * 16u)); }
+            h = hn;
             spins = 0;
         }
         if (bail) break;
 #pragma unroll
-        for (int j = 0; j < NR; ++j)
-            if (hv[j]) *reinterpret_cast<d2 *>(V + (size_t)usr[j] * K + 2 * q) = vv[j];
-        if (have) { ub[my_user] = ubv; se_run[b * B + lane] = se; }
+        for (int j = 0; j < NR; ++j) {
+            const int ent = __shfl(my_ent, j * SPW + g, 64);
+            const int hv = __shfl((int)have, j * SPW + g, 64);
+            if (hv) *reinterpret_cast<d2 *>(Rm + (size_t)ent * K + 2 * q) = vv[j];
+        }
+        if (have) { rb[my_ent] = rbv; se_run[run] = se; }
     }
 }
 
@@ -180,38 +201,68 @@ __global__ void k_hdr_finish(const IHdr *hdr, double *ib, int ni)
     if (i < ni) ib[i] = hdr[i].ib;
 }
 
-template <int B, bool NOPOLL>
-static int run_variant(const char *name, int wpc, int epochs, int64_t nnz, int nu, int ni, int n_runs, const URec *d_in, const int64_t *d_run,
-                       const int *d_ruser, double *dU, double *dV, double *dib, double *dub, IHdr *d_hdr, int *d_ticket, double *d_se,
-                       int *d_err, const std::vector<double> &U0, const std::vector<double> &V0, const std::vector<double> &a,
-                       const std::vector<double> &c, float ms_ref)
+struct Dev {
+    URec *d_in; int64_t *d_run; int *d_rent; int n_runs;       // grouped records of one (order, side)
+    double *dU, *dV, *dib, *dub, *d_se; IHdr *d_hdr; int *d_ticket, *d_err;
+    int nu, ni; int64_t nnz;
+};
+
+template <int B, bool STATIC, bool RES_ITEM, bool OVL, bool NOPOLL, int MINW>
+static int run_variant(const char *name, int waves, int epochs, const Dev &D, const std::vector<double> &U0, const std::vector<double> &V0,
+                       const std::vector<double> &a, const std::vector<double> &c, float ms_ref)
 {
     const double lr = 0.01, Ku = 0.1, Ki = 0.1, Kb = 0.007;
+    const int n_trav = RES_ITEM ? D.nu : D.ni;
+    double *Tm = RES_ITEM ? D.dV : D.dU, *Rm = RES_ITEM ? D.dU : D.dV, *tb = RES_ITEM ? D.dub : D.dib, *rb = RES_ITEM ? D.dib : D.dub;
+    if (STATIC && (int64_t)waves * B < D.n_runs) { printf("%-34s skipped: %d waves x %d slots < %d entities\n", name, waves, B, D.n_runs); return 0; }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    CK(hipMemcpy(dU, U0.data(), U0.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dV, V0.data(), V0.size() * 8, hipMemcpyHostToDevice));
-    CK(hipMemset(dib, 0, (size_t)ni * 8)); CK(hipMemset(dub, 0, (size_t)nu * 8)); CK(hipMemset(d_err, 0, 4));
+    CK(hipMemcpy(D.dU, U0.data(), U0.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(D.dV, V0.data(), V0.size() * 8, hipMemcpyHostToDevice));
+    CK(hipMemset(D.dib, 0, (size_t)D.ni * 8)); CK(hipMemset(D.dub, 0, (size_t)D.nu * 8)); CK(hipMemset(D.d_err, 0, 4));
     float ms = 0;
     for (int ep = 0; ep < epochs; ++ep) {
-        CK(hipMemsetAsync(d_ticket, 0, 4));
+        CK(hipMemsetAsync(D.d_ticket, 0, 4));
         if (ep == epochs - 1) CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(k_hdr_reset, dim3((ni + 255) / 256), dim3(256), 0, 0, d_hdr, dib, ni);
-        hipLaunchKernelGGL((k1_ur<B, NOPOLL>), dim3(256 * wpc), dim3(64), 0, 0, d_in, d_run, d_ruser, n_runs, dU, dV, d_hdr, dub, d_ticket, d_se, d_err, lr, Ku, Ki, Kb);
-        hipLaunchKernelGGL(k_hdr_finish, dim3((ni + 255) / 256), dim3(256), 0, 0, d_hdr, dib, ni);
+        hipLaunchKernelGGL(k_hdr_reset, dim3((n_trav + 255) / 256), dim3(256), 0, 0, D.d_hdr, tb, n_trav);
+        hipLaunchKernelGGL((k1_res<B, STATIC, RES_ITEM, OVL, NOPOLL, MINW>), dim3(waves), dim3(64), 0, 0, D.d_in, D.d_run, D.d_rent, D.n_runs, Tm, Rm,
+                           D.d_hdr, rb, D.d_ticket, D.d_se, D.d_err, lr, RES_ITEM ? Ki : Ku, RES_ITEM ? Ku : Ki, Kb);
+        hipLaunchKernelGGL(k_hdr_finish, dim3((n_trav + 255) / 256), dim3(256), 0, 0, D.d_hdr, tb, n_trav);
         if (ep == epochs - 1) { CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1)); }
     }
     CK(hipDeviceSynchronize());
-    int err = 0; CK(hipMemcpy(&err, d_err, 4, hipMemcpyDeviceToHost));
+    int err = 0; CK(hipMemcpy(&err, D.d_err, 4, hipMemcpyDeviceToHost));
     size_t diffU = 0, diffV = 0;
     if (!NOPOLL) {
         std::vector<double> U1(U0.size()), V1(V0.size());
-        CK(hipMemcpy(U1.data(), dU, U1.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(V1.data(), dV, V1.size() * 8, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(U1.data(), D.dU, U1.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(V1.data(), D.dV, V1.size() * 8, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < a.size(); ++i) diffU += (memcmp(&a[i], &U1[i], 8) != 0);
         for (size_t i = 0; i < c.size(); ++i) diffV += (memcmp(&c[i], &V1[i], 8) != 0);
     }
-    printf("%-22s %2d waves/CU: %8.3f ms/epoch = %.3f G/s (level-per-launch %.3f ms = %.3f G/s) | timeout %d | differing U %zu V %zu%s\n",
-           name, wpc, ms, nnz / ms / 1e6, ms_ref, nnz / ms_ref / 1e6, err, diffU, diffV, NOPOLL ? "  [no waits: WRONG results, throughput bound only]" : "");
+    printf("%-34s %5d waves: %8.3f ms/epoch = %.3f G/s (level-per-launch %.3f ms = %.3f G/s) | timeout %d | differing U %zu V %zu%s\n",
+           name, waves, ms, D.nnz / ms / 1e6, ms_ref, D.nnz / ms_ref / 1e6, err, diffU, diffV, NOPOLL ? "  [no waits: WRONG results, throughput bound only]" : "");
     fflush(stdout);
     return err ? 2 : 0;
+}
+
+// group the ratings by the resident side (stable), rank them in the travelling side's chains (input order)
+static void prep(const std::vector<int32_t> &idx, const std::vector<double> &r, int64_t nnz, int nu, int ni, bool res_item, bool all_entities,
+                 std::vector<URec> &recs, std::vector<int64_t> &run_off, std::vector<int32_t> &run_ent)
+{
+    const int n_res = res_item ? ni : nu, n_trav = res_item ? nu : ni;
+    const int rc = res_item ? 1 : 0, tc = res_item ? 0 : 1;
+    std::vector<int64_t> cnt((size_t)n_res + 1, 0);
+    for (int64_t t = 0; t < nnz; ++t) ++cnt[idx[2 * t + rc] + 1];
+    for (int e = 0; e < n_res; ++e) cnt[e + 1] += cnt[e];
+    std::vector<int64_t> fill(cnt.begin(), cnt.end() - 1);
+    std::vector<int32_t> ctr((size_t)n_trav, 0);
+    recs.resize((size_t)nnz);
+    for (int64_t t = 0; t < nnz; ++t) {
+        const int tr = idx[2 * t + tc];
+        recs[(size_t)fill[idx[2 * t + rc]]++] = URec{tr, ctr[tr]++, r[t]};
+    }
+    run_off.clear(); run_ent.clear();
+    for (int e = 0; e < n_res; ++e)
+        if (all_entities || cnt[e + 1] > cnt[e]) { run_off.push_back(cnt[e]); run_ent.push_back(e); }
+    run_off.push_back(nnz);
 }
 
 int main(int argc, char **argv)
@@ -219,11 +270,14 @@ int main(int argc, char **argv)
     const int nu = argc > 1 ? atoi(argv[1]) : 100000, ni = argc > 2 ? atoi(argv[2]) : 50000;
     const int64_t nnz = argc > 3 ? atoll(argv[3]) : 10000000;
     const int epochs = argc > 4 ? atoi(argv[4]) : 2;
+    const int shuffled = argc > 5 ? atoi(argv[5]) : 0;
     std::vector<int32_t> idx((size_t)nnz * 2);
     std::vector<double> r((size_t)nnz);
     uint64_t st = 88172645463325252ull;
     auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
-    {   // get_ratings(randomize_order=False): user-major, ascending items inside a user
+    if (shuffled) {
+        for (int64_t t = 0; t < nnz; ++t) { idx[2 * t] = (int32_t)(rnd() % nu); idx[2 * t + 1] = (int32_t)(rnd() % ni); }
+    } else {   // get_ratings(randomize_order=False): user-major, ascending items inside a user
         std::vector<int32_t> uu((size_t)nnz), ii((size_t)nnz);
         std::vector<int64_t> cnt((size_t)nu + 1, 0);
         for (int64_t t = 0; t < nnz; ++t) { uu[t] = (int32_t)(rnd() % nu); ii[t] = (int32_t)(rnd() % ni); ++cnt[uu[t] + 1]; }
@@ -236,8 +290,8 @@ int main(int argc, char **argv)
             std::sort(tmp.begin(), tmp.end());
             for (int64_t p = cnt[u]; p < cnt[u + 1]; ++p) idx[2 * p + 1] = tmp[p - cnt[u]];
         }
-        for (int64_t t = 0; t < nnz; ++t) r[t] = 1.0 + (double)(rnd() % 5);
     }
+    for (int64_t t = 0; t < nnz; ++t) r[t] = 1.0 + (double)(rnd() % 5);
     std::vector<int32_t> level((size_t)nnz);
     int64_t n_levels = 0;
     if (mfx_schedule_levels(idx.data(), nnz, nu, ni, level.data(), &n_levels)) return 1;
@@ -245,32 +299,22 @@ int main(int argc, char **argv)
     if (mfx_schedule_permutation(level.data(), nnz, n_levels, perm.data(), off.data())) return 1;
     std::vector<Rec> recs_lvl((size_t)nnz);
     for (int64_t j = 0; j < nnz; ++j) { const int64_t t = perm[j]; recs_lvl[j] = {idx[2 * t], idx[2 * t + 1], r[t]}; }
-    std::vector<URec> recs_in((size_t)nnz);
-    std::vector<int32_t> ci((size_t)ni, 0), ruser;
-    std::vector<int64_t> run_off;
-    for (int64_t t = 0; t < nnz; ++t) {
-        recs_in[t] = {idx[2 * t + 1], ci[idx[2 * t + 1]]++, r[t]};
-        if (t == 0 || idx[2 * t] != idx[2 * (t - 1)]) { run_off.push_back(t); ruser.push_back(idx[2 * t]); }
-    }
-    const int n_runs = (int)run_off.size();
-    run_off.push_back(nnz);
-    printf("nu %d ni %d nnz %lld: levels (= DAG depth) %lld, runs %d\n", nu, ni, (long long)nnz, (long long)n_levels, n_runs);
+    for (int64_t l = 0; l < n_levels; ++l)
+        std::sort(recs_lvl.begin() + off[l], recs_lvl.begin() + off[l + 1], [](const Rec &a, const Rec &b) { return a.item < b.item; });
+    printf("nu %d ni %d nnz %lld %s: levels (= DAG depth) %lld\n", nu, ni, (long long)nnz, shuffled ? "shuffled" : "user-major", (long long)n_levels);
 
     std::vector<double> U0((size_t)ni * K), V0((size_t)nu * K);
     for (auto &x : U0) x = ((double)(rnd() % 2001) - 1000.0) * 1e-4;
     for (auto &x : V0) x = ((double)(rnd() % 2001) - 1000.0) * 1e-4;
-    Rec *d_lvl; URec *d_in; int64_t *d_run; int *d_ruser; double *dU[2], *dV[2], *dib[2], *dub[2], *d_se; IHdr *d_hdr; int *d_err, *d_ticket;
-    CK(hipMalloc(&d_lvl, nnz * sizeof(Rec))); CK(hipMalloc(&d_in, nnz * sizeof(URec))); CK(hipMalloc(&d_run, run_off.size() * 8)); CK(hipMalloc(&d_ruser, ruser.size() * 4));
+    Rec *d_lvl; double *dU[2], *dV[2], *dib[2], *dub[2], *d_se; IHdr *d_hdr; int *d_err, *d_ticket;
+    CK(hipMalloc(&d_lvl, nnz * sizeof(Rec)));
     CK(hipMemcpy(d_lvl, recs_lvl.data(), nnz * sizeof(Rec), hipMemcpyHostToDevice));
-    CK(hipMemcpy(d_in, recs_in.data(), nnz * sizeof(URec), hipMemcpyHostToDevice));
-    CK(hipMemcpy(d_run, run_off.data(), run_off.size() * 8, hipMemcpyHostToDevice));
-    CK(hipMemcpy(d_ruser, ruser.data(), ruser.size() * 4, hipMemcpyHostToDevice));
     for (int v = 0; v < 2; ++v) {
         CK(hipMalloc(&dU[v], U0.size() * 8)); CK(hipMalloc(&dV[v], V0.size() * 8)); CK(hipMalloc(&dib[v], (size_t)ni * 8)); CK(hipMalloc(&dub[v], (size_t)nu * 8));
     }
     CK(hipMemcpy(dU[0], U0.data(), U0.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dV[0], V0.data(), V0.size() * 8, hipMemcpyHostToDevice));
     CK(hipMemset(dib[0], 0, (size_t)ni * 8)); CK(hipMemset(dub[0], 0, (size_t)nu * 8));
-    CK(hipMalloc(&d_se, ((size_t)nnz / 8 + (size_t)n_runs + 8192) * 8)); CK(hipMalloc(&d_hdr, (size_t)ni * 16)); CK(hipMalloc(&d_err, 4)); CK(hipMalloc(&d_ticket, 4));
+    CK(hipMalloc(&d_se, ((size_t)nnz / 8 + (size_t)nu + ni + 8192) * 8)); CK(hipMalloc(&d_hdr, (size_t)(nu > ni ? nu : ni) * 16)); CK(hipMalloc(&d_err, 4)); CK(hipMalloc(&d_ticket, 4));
     const double lr = 0.01, Ku = 0.1, Ki = 0.1, Kb = 0.007;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float ms_ref = 0;
@@ -291,9 +335,41 @@ int main(int argc, char **argv)
     }
     std::vector<double> a(U0.size()), c(V0.size());
     CK(hipMemcpy(a.data(), dU[0], a.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(c.data(), dV[0], c.size() * 8, hipMemcpyDeviceToHost));
-#define RUN(B, NP, W) if (run_variant<B, NP>(#B " slots" #NP, W, epochs, nnz, nu, ni, n_runs, d_in, d_run, d_ruser, dU[1], dV[1], dib[1], dub[1], d_hdr, d_ticket, d_se, d_err, U0, V0, a, c, ms_ref)) return 2
-    RUN(8, false, 8); RUN(8, false, 16); RUN(8, false, 24); RUN(8, false, 32);
-    RUN(16, false, 8); RUN(16, false, 16);
-    RUN(8, true, 16); RUN(16, true, 16);
+    (void)hipFree(d_lvl);
+
+    std::vector<URec> recs; std::vector<int64_t> run_off; std::vector<int32_t> run_ent;
+    Dev D{}; D.dU = dU[1]; D.dV = dV[1]; D.dib = dib[1]; D.dub = dub[1]; D.d_se = d_se; D.d_hdr = d_hdr; D.d_ticket = d_ticket; D.d_err = d_err;
+    D.nu = nu; D.ni = ni; D.nnz = nnz;
+    CK(hipMalloc(&D.d_in, nnz * sizeof(URec))); CK(hipMalloc(&D.d_run, ((size_t)(nu > ni ? nu : ni) + 1) * 8)); CK(hipMalloc(&D.d_rent, (size_t)(nu > ni ? nu : ni) * 4));
+    auto upload = [&](bool res_item, bool all) {
+        prep(idx, r, nnz, nu, ni, res_item, all, recs, run_off, run_ent);
+        D.n_runs = (int)run_ent.size();
+        if (hipMemcpy(D.d_in, recs.data(), nnz * sizeof(URec), hipMemcpyHostToDevice) != hipSuccess) return 1;
+        if (hipMemcpy(D.d_run, run_off.data(), run_off.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return 1;
+        if (hipMemcpy(D.d_rent, run_ent.data(), run_ent.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return 1;
+        return 0;
+    };
+#define RUN(B, ST, RI, OVL, NP, MINW, W) if (run_variant<B, ST, RI, OVL, NP, MINW>(#B " slots " #ST "/" #RI "/" #OVL "/" #NP "/" #MINW, W, epochs, D, U0, V0, a, c, ms_ref)) return 2
+    if (!shuffled) {
+        if (upload(false, false)) return 1;               // users resident, tickets
+        RUN(8, false, false, false, false, 1, 4096);
+        RUN(8, false, false, true, false, 1, 4096);
+        RUN(8, false, false, true, false, 4, 4096);
+        RUN(8, false, false, true, true, 4, 4096);
+    }
+    if ((int64_t)ni * 8 * K <= 64ll << 20) {               // items resident, static (any order)
+        if (upload(true, true)) return 1;
+        RUN(14, true, true, true, false, 4, 4096);
+        RUN(14, true, true, true, false, 1, 2048);
+        RUN(14, true, true, false, false, 4, 4096);
+        RUN(16, true, true, true, false, 4, 4096);
+        RUN(26, true, true, true, false, 2, 2048);
+        RUN(32, true, true, true, false, 2, 2048);
+        RUN(14, true, true, true, true, 4, 4096);
+    }
+    if ((int64_t)nu * 8 * K <= 64ll << 20) {               // users resident, static
+        if (upload(false, true)) return 1;
+        RUN(50, true, false, true, false, 2, 2048);
+    }
     return 0;
 }

@@ -235,6 +235,13 @@ def cpu_baseline_als(k):
 # ------------------------------------------------------------------------------------------------
 # GPU measurements
 # ------------------------------------------------------------------------------------------------
+def epoch_launches(info):
+    """Launches of the dominant kernel per epoch: one per dependency level (k1_level / k1_tail), or ONE persistent
+    launch (k1_res: MFX_EPOCH_TICKET / _STATIC; the two 16-byte-per-entity granule kernels and the two reduction
+    kernels around it are inside the timed region and count against it)."""
+    return 1 if info.get("epoch_kernel", "levels") != "levels" else info["launches_per_epoch"]
+
+
 def k1_measure(plan, nnz, nu, k, steps, warmup, run, label_plan=None):
     """Timed region of a full-k SGD plan: HIP events on the library stream + roofline of k1_level."""
     from mfrec_amd.plan import Timer, LINEAR
@@ -242,12 +249,12 @@ def k1_measure(plan, nnz, nu, k, steps, warmup, run, label_plan=None):
     run(max(warmup, 0))
     with Timer() as tm:
         run(steps)
-    launches = info["launches_per_epoch"]
+    launches = epoch_launches(info)
     b_read, b_total = algorithmic_bytes(k, nnz, nu)
     avg_launch_s = tm.ms * 1e-3 / (steps * launches)
     achieved = (b_read * nnz / launches) / avg_launch_s
     return {"device_ms_per_step": tm.ms / steps, "value": nnz * steps / (tm.ms * 1e-3),
-            "levels": info["n_levels"], "launches_per_epoch": launches,
+            "levels": info["n_levels"], "launches_per_epoch": launches, "epoch_kernel": info.get("epoch_kernel", "levels"),
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": None,
                          "algorithmic_bytes_per_launch": b_read * nnz / launches,
@@ -258,21 +265,24 @@ def k1_measure(plan, nnz, nu, k, steps, warmup, run, label_plan=None):
             "schedule_build_ms": info["schedule_us"] / 1e3}
 
 
-def also_k1_order(idx, r, nu, ni, k, u0, v0, steps, warmup, order):
+def also_k1_order(idx, r, nu, ni, k, u0, v0, steps, warmup, order, epoch="auto"):
     from mfrec_amd import synth
     from mfrec_amd.plan import SgdPlan, LINEAR
     if order == "user-major":
         i2, r2 = synth.user_major(idx, r)
-    else:
+    elif order == "balanced":
         from mfrec_amd.lib.datasets import balanced_order_gpu
         perm, _ = balanced_order_gpu(idx, nu, ni)
         i2, r2 = np.ascontiguousarray(idx[perm]), np.ascontiguousarray(r[perm])
-    with SgdPlan(i2, r2, nu, ni, k) as p:
+    else:
+        i2, r2 = idx, r
+    with SgdPlan(i2, r2, nu, ni, k, epoch=epoch) as p:
         p.set_factors(u0, v0, np.zeros(ni), np.zeros(nu))
         m = k1_measure(p, idx.shape[0], nu, k, steps, warmup,
                        lambda n: p.run_kmf(LINEAR, n, LR, KU, KI, KB, want_rmse=False))
     m["unit"] = "rating-updates/s"
-    m["workload"] = "cfg2 shape, %s order, exact level schedule, full-k SGD" % order
+    m["workload"] = "%dK x %dK, %dM ratings, %s order, exact, full-k SGD, epoch kernel: %s" % (
+        nu // 1000, ni // 1000, idx.shape[0] // 1000000, order, m["epoch_kernel"])
     return m
 
 
@@ -470,6 +480,8 @@ def main():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N>1: strong = the job's ratings are divided among the GPUs (default); weak = every "
                          "GPU gets a job-sized user shard of its own")
+    ap.add_argument("--epoch", choices=["auto", "levels", "ticket", "static"], default="auto",
+                    help="kernel of a full-k epoch (include/mfx.h MFX_EPOCH_*): auto = the library's cost model")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--no-also", action="store_true", help="skip the `also` block (secondary kernels)")
     ap.add_argument("--no-extra", action="store_true", help=argparse.SUPPRESS)   # accepted, no-op
@@ -541,7 +553,9 @@ def main():
         # one process per GPU: device = LOCAL_RANK; a launcher that narrows every rank's view to its own GPU
         # (HIP_VISIBLE_DEVICES per process) leaves a single visible device 0
         ndev = max(S.device_count(), 1)
-        S.init(int(os.environ.get("MFX_BENCH_DEVICE", local if local < ndev else local % ndev)))
+        if not (ndev == 1 or local < ndev):
+            raise SystemExit("LOCAL_RANK %d but only %d visible devices: two ranks would share a GPU" % (local, ndev))
+        S.init(int(os.environ.get("MFX_BENCH_DEVICE", local if local < ndev else 0)))
         if multi:
             def make_id():
                 idbuf = C.create_string_buffer(S.UNIQUE_ID_BYTES)
@@ -555,7 +569,12 @@ def main():
         fail_line(rank, world, "device / RCCL communicator init", e)
         raise
 
-    where[0] = "synthetic data + plan (schedule build, upload)"
+    def mark(what):            # MFX_BENCH_TRACE=1: one stderr line per stage (which stage a traced run died in)
+        where[0] = what
+        if os.environ.get("MFX_BENCH_TRACE") == "1":
+            sys.stderr.write("[bench] stage: %s\n" % what); sys.stderr.flush()
+
+    mark("synthetic data + plan (schedule build, upload)")
     # ---- data: the whole job's ratings are a pure function of the counter, so every rank generates them
     # and keeps its own users (strong scaling: same 100M ratings at every N) -------------------------
     if world > 1 and a.scaling == "weak":
@@ -588,7 +607,7 @@ def main():
     else:
         v0 = v0_full
     my_nnz = my_r.shape[0]
-    plan = SgdPlan(my_idx, my_r, max(nu_local, 1), ni, k, storage=a.storage)
+    plan = SgdPlan(my_idx, my_r, max(nu_local, 1), ni, k, storage=a.storage, epoch=a.epoch)
     plan.set_factors(u0, v0, np.zeros(ni), np.zeros(max(nu_local, 1)))
     info = plan.info()
     kernel_name = plan.kernel_name(LINEAR)          # the instantiation the library launches, from the library
@@ -616,7 +635,7 @@ def main():
         S.check(S.lib().mfx_comm_allreduce_max(C.byref(w)))
         return w.value
 
-    where[0] = "warmup / timed region (averaging mode: k1 epochs + ncclAllReduce)"
+    mark("warmup / timed region")
     try:
         run(max(a.warmup, 0))
         barrier()
@@ -639,11 +658,14 @@ def main():
     # epochs / (K * launches per epoch).  The epoch graph holds nothing else but two tiny reduction
     # kernels (and, at N > 1, the delta / all-reduce / combine step), so this is an upper bound of the
     # kernel's own duration and agrees with rocprofv3's average (profiles/).
-    launches = info["launches_per_epoch"]
+    mark("per-launch event pairs (profile_kmf)")
+    resident = (not multi) and info.get("epoch_kernel", "levels") != "levels" and a.storage == "f64"
+    launches = epoch_launches(info) if resident else info["launches_per_epoch"]
     b_read, b_total = algorithmic_bytes(k, nnz, nu)
     avg_launch_s = dev_ms * 1e-3 / (a.steps * launches)
     achieved = (b_read * my_nnz / launches) / avg_launch_s
-    kern_ms, _ = plan.profile_kmf(LINEAR, LR, KU, KI, KB)      # cross-check: an event pair around every launch
+    # cross-check on the level schedule: an event pair around every launch (the resident-side epoch IS one launch)
+    kern_ms = plan.profile_kmf(LINEAR, LR, KU, KI, KB)[0] if not resident else dev_ms / a.steps
 
     # HBM traffic per launch: from the committed rocprofv3 PMC summary of this same command
     # (profiles/rNN_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes)
@@ -653,8 +675,10 @@ def main():
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
         if cands and world == 1 and a.order == "shuffled" and a.storage == "f64" and (nu, ni, nnz, k) == CFG2:
             tj = json.load(open(cands[-1]))
-            traffic = (tj["read_bytes_per_rating"] + tj["write_bytes_per_rating"]) * nnz / launches
-            traffic_src = os.path.basename(cands[-1])
+            # the summary is stamped with the kernel it was taken on: a stale one (another kernel) is dropped
+            if tj.get("kernel") == kernel_name:
+                traffic = (tj["read_bytes_per_rating"] + tj["write_bytes_per_rating"]) * nnz / launches
+                traffic_src = os.path.basename(cands[-1])
     except Exception:
         traffic = None
 
@@ -671,14 +695,16 @@ def main():
             "dtype": "f64" if a.storage == "f64" else "f64 arithmetic on %s-stored rows (NOT the reference precision)" % a.storage,
             "data": "synthetic",
             "config": {"workload": "%s: synthetic %dK users x %dK items, %dM ratings%s, k=%d, full-k SGD "
-                                   "(train_linear_kernel), %s order, exact level schedule%s" % (
+                                   "(train_linear_kernel), %s order, exact (bit-identical to the sequential loop), epoch kernel: %s%s" % (
                                        cfg_name, nu // 1000, ni // 1000, nnz // 1000000,
                                        " per GPU" if (world > 1 and a.scaling == "weak") else "", k, a.order,
+                                       info.get("epoch_kernel", "levels") if not multi else "levels",
                                        "" if not multi else
                                        ", users sharded over %d GPUs, item factors replicated, RCCL all-reduce of the "
                                        "item deltas every epoch (parameter averaging, scale 1/%d)" % (world, world)),
                        "users": nu, "items": ni, "ratings": job_nnz, "ratings_this_gpu": my_nnz, "k": k,
                        "levels": info["n_levels"], "launches_per_epoch": launches,
+                       "epoch_kernel": info.get("epoch_kernel", "levels") if not multi else "levels",
                        "sharding": "users x%d, item-delta all-reduce (RCCL)" % world if multi else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
@@ -716,7 +742,7 @@ def main():
             also["dsgd_exact"] = {"error": "no result after %.0f s (watchdog): leg abandoned" % limit_s}
             fail_line(rank, world, "dsgd leg", "watchdog after %.0f s" % limit_s)
             emit()
-            os._exit(0)
+            os._exit(4)          # a hang in a GPU collective is a failure of the run, whatever was printed
 
         where[0] = "dsgd leg (block rotation: ncclSend/Recv ring)"
         dog = threading.Timer(limit_s, give_up)
@@ -769,6 +795,7 @@ def main():
 
         plan.close()
         plan = None
+        leg("k1_levels", lambda: also_k1_order(idx, r, nu, ni, k, u0, v0n, a.steps, a.warmup, "shuffled", epoch="levels"))
         leg("k1_user_major", lambda: also_k1_order(idx, r, nu, ni, k, u0, v0n, a.steps, a.warmup, "user-major"))
         leg("k1_balanced", lambda: also_k1_order(idx, r, nu, ni, k, u0, v0n, a.steps, a.warmup, "balanced"))
         leg("k1_tolerance_mode", lambda: also_k1_tolerance(idx, r, nu, ni, k, u0, v0n, a.steps, a.warmup, "shuffled"))
@@ -796,6 +823,22 @@ def main():
             m["workload"] = "cfg3 whole on ONE GPU (1M x 200K, 100M ratings, k=64): the N=1 point of the strong-scaling " \
                             "curve that `--gpus N` (N>1) continues"
             out["k1_cfg3_whole_1gpu"] = m
+            # the same 100 M ratings in get_ratings(randomize_order=False)'s order (base.py:1115-1126): user rows
+            # resident, one persistent launch per epoch (MFX_EPOCH_TICKET by the cost model)
+            try:
+                i3u, r3u = synth.user_major(idx3, r3)
+                with SgdPlan(i3u, r3u, nu3, ni3, k3) as p3:
+                    p3.set_factors(synth.init_normal(k3, ni3, synth.SEED_INIT), synth.init_normal(k3, nu3, synth.SEED_INIT + 1),
+                                   np.zeros(ni3), np.zeros(nu3))
+                    m2 = k1_measure(p3, nnz3, nu3, k3, a.steps, a.warmup,
+                                    lambda n: p3.run_kmf(LINEAR, n, LR, KU, KI, KB, want_rmse=False))
+                m2["unit"] = "rating-updates/s"
+                m2["workload"] = "cfg3 whole on ONE GPU, user-major order (get_ratings(randomize_order=False)): user rows " \
+                                 "resident in registers, item rows travel behind chain counters; epoch kernel: %s" % m2["epoch_kernel"]
+                out["k1_user_resident_cfg3"] = m2
+                del i3u, r3u
+            except Exception as e:
+                out["k1_user_resident_cfg3"] = {"error": repr(e)}
             del r3
             t = time.perf_counter()
             try:
@@ -805,7 +848,7 @@ def main():
                 out["k3_als_cfg4"] = {"error": repr(e)}
             return out
 
-        if not only or (only & {"k1_cfg3_whole_1gpu", "k3_als_cfg4"}):
+        if not only or (only & {"k1_cfg3_whole_1gpu", "k1_user_resident_cfg3", "k3_als_cfg4"}):
             if os.environ.get("MFX_BENCH_TRACE") == "1":
                 sys.stderr.write("[bench] leg cfg3 + als\n"); sys.stderr.flush()
             try:

@@ -150,7 +150,7 @@ __device__ __forceinline__ void res_step(const ResParams &P, unsigned long long 
 
 // KP lanes per row (16 bytes = one feature pair per lane: k <= 2 KP), NR register sets per lane, B = NR * 64/KP slots
 template <int KP, int NR, int MODE, bool STATIC>
-__global__ __launch_bounds__(64, STATIC ? 2 : 4) void k1_res(ResParams P)
+__global__ __launch_bounds__(64, STATIC ? (NR <= 9 ? 3 : 2) : 4) void k1_res(ResParams P)
 {
     constexpr int SPW = 64 / KP, B = NR * SPW;
     extern __shared__ __attribute__((aligned(16))) double prod[];       // [B][stride]
@@ -281,18 +281,19 @@ int env_i(const char *name, int dflt)
 
 struct Sel { void *fn; int kp, nr; };
 
-template <int MODE, bool STATIC>
+// ticket: 4 register sets (4 waves per SIMD); static: 9 sets at 3 waves per SIMD (18 slots x 3 072 waves at k = 64: measured 3 %
+// faster than 26 x 2 048 and 5 % faster than 32 x 2 048 on cfg 2) or 16 sets at 2 waves per SIMD (the largest side that fits)
+template <int MODE, int NR, bool STATIC>
 Sel pick(int k)
 {
-    constexpr int NR = STATIC ? 16 : 4;
     if (k <= 32) return {(void *)k1_res<16, NR, MODE, STATIC>, 16, NR};
     if (k <= 64) return {(void *)k1_res<32, NR, MODE, STATIC>, 32, NR};
     return {(void *)k1_res<64, NR, MODE, STATIC>, 64, NR};
 }
-Sel select(int k, int mode, bool stat)
+Sel select(int k, int mode, int nr)        // nr: 4 = ticket, 9 / 16 = static
 {
-    if (mode == 0) return stat ? pick<0, true>(k) : pick<0, false>(k);
-    return stat ? pick<1, true>(k) : pick<1, false>(k);
+    if (mode == 0) return nr == 4 ? pick<0, 4, false>(k) : (nr == 9 ? pick<0, 9, true>(k) : pick<0, 16, true>(k));
+    return nr == 4 ? pick<1, 4, false>(k) : (nr == 9 ? pick<1, 9, true>(k) : pick<1, 16, true>(k));
 }
 
 }  // namespace
@@ -392,13 +393,20 @@ int res_prepare(ResPlan **out, const int32_t *idx, const double *r, int64_t nnz,
     // ---- static: the smaller side in registers, the whole grid resident -----------------------------------
     const bool res_item = ni <= nu;
     const int n_res = res_item ? ni : nu, n_trav = res_item ? nu : ni;
-    const Sel ss = select(k, 0, true), st = select(k, 0, false);
-    const int Bs = ss.nr * (64 / ss.kp), Bt = st.nr * (64 / st.kp);
-    int occ = 0;
-    const size_t lds_s = (size_t)Bs * (2 * ss.kp + 2) * 8, lds_t = (size_t)Bt * (2 * st.kp + 2) * 8;
-    MFX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ss.fn, 64, lds_s));
-    const int waves_s = occ * cus;
-    const bool static_ok = occ > 0 && (int64_t)waves_s * Bs >= n_res && (int64_t)n_trav * k * 8 < ((int64_t)1 << 31);
+    const Sel st = select(k, 0, 4);
+    const int Bt = st.nr * (64 / st.kp);
+    const size_t lds_t = (size_t)Bt * (2 * st.kp + 2) * 8;
+    Sel ss = select(k, 0, 9);
+    int Bs = 0, waves_s = 0;
+    for (int nr : {9, 16}) {                                 // the smallest register image that holds the side
+        ss = select(k, 0, nr);
+        Bs = ss.nr * (64 / ss.kp);
+        int occ = 0;
+        MFX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ss.fn, 64, (size_t)Bs * (2 * ss.kp + 2) * 8));
+        waves_s = occ * cus;
+        if ((int64_t)waves_s * Bs >= n_res) break;
+    }
+    const bool static_ok = waves_s > 0 && (int64_t)waves_s * Bs >= n_res && (int64_t)n_trav * k * 8 < ((int64_t)1 << 31);
     const double e_level = est_level_ms(nnz, n_levels);
     const double e_ticket = ticket_ok ? est_res_ms(nnz, n_levels, false) : 1e30;
     const double e_static = static_ok ? est_res_ms(nnz, n_levels, true) : 1e30;
@@ -514,7 +522,7 @@ int res_enqueue_epoch(ResPlan *rp, int mode, double *U_nk, double *V_nk, double 
     P.hdr = rp->d_hdr; P.ctl = rp->d_ctl; P.se_run = rp->d_se_run;
     P.n_runs = rp->n_runs; P.k = rp->k; P.res_item = rp->res_item ? 1 : 0;
     P.lr = lr; P.Kres = rp->res_item ? Ki : Ku; P.Ktrav = rp->res_item ? Ku : Ki; P.Kb = Kb;
-    const Sel s = select(rp->k, mode, rp->kind == 2);
+    const Sel s = select(rp->k, mode, rp->nr);
     MFX_HIP(hipMemsetAsync(rp->d_ctl, 0, sizeof(unsigned), stream()));                          // ticket
     MFX_HIP(hipMemsetAsync(rp->d_ctl + kCtlReg, 0, sizeof(unsigned), stream()));                // registration
     hipLaunchKernelGGL(k_hdr_reset, dim3(ceil_div(rp->n_trav, 256)), dim3(256), 0, stream(), rp->d_hdr, (const double *)tb, rp->n_trav);

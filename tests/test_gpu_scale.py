@@ -9,7 +9,12 @@
   * cfg 5's per-GPU shard shape (1.25 M x 1 M, 125 M ratings, k=64; 1.15 GB of factors, beyond the
     Infinity Cache): size-independent properties -- schedule idempotence (level-major input with the
     levels internally shuffled gives the same bits), monotone online RMSE, device and host schedule
-    builders agree on the level structure."""
+    builders agree on the level structure;
+  * cfg 3 whole in get_ratings(randomize_order=False)'s order (user-major): the resident-side epoch with the user
+    rows in registers and runs taken by ticket (MFX_EPOCH_TICKET, chosen by the cost model), ONE epoch, bit for bit
+    against the oracle;
+  * cfg 5 WHOLE (10 M x 1 M, 1 B ratings, k=64) on one GPU: properties -- device-built schedule and its level
+    count, finite and strictly decreasing online RMSE, host and device builders agree on a 100 M-rating prefix."""
 import ctypes as C
 import time
 
@@ -56,6 +61,36 @@ def test_cfg3_whole_one_epoch_bitexact_vs_oracle(cfg3_data):
     assert np.array_equal(ib, ib2) and np.array_equal(ub, ub2)
     assert abs(rm[0] - rm2[0]) <= 1e-12 * rm2[0]
     assert info["schedule_builder"] == "device" and 900 < info["n_levels"] < 1500
+
+
+def test_cfg3_whole_user_major_resident_epoch_bitexact_vs_oracle(cfg3_data):
+    from mfrec_amd.plan import SgdPlan
+    from oracle import oracle as O
+    nu, ni, nnz, idx, r = cfg3_data
+    k = 64
+    # user-major, ascending items, generation order among duplicates: one stable sort of a combined key
+    order = np.argsort((idx[:, 0].astype(np.int64) << 32) | idx[:, 1].astype(np.int64), kind="stable")
+    iu, ru = np.ascontiguousarray(idx[order]), np.ascontiguousarray(r[order])
+    del order
+    u0, v0 = synth.init_normal(k, ni, 7), synth.init_normal(k, nu, 8)
+    u, v, ib, ub = u0.copy(), v0.copy(), np.zeros(ni), np.zeros(nu)
+    with SgdPlan(iu, ru, nu, ni, k) as p:
+        info = p.info()
+        name = p.kernel_name(0)
+        p.set_factors(u, v, ib, ub)
+        t0 = time.time()
+        rm = p.run_kmf(0, 1, *HP)
+        dt = time.time() - t0
+        p.get_factors(u, v, ib, ub)
+        assert p.info()["epoch_kernel"] == "ticket"            # no fallback happened
+    assert info["epoch_kernel"] == "ticket" and "user rows resident" in name, (info, name)
+    rm2 = np.zeros(1)
+    ib2, ub2 = np.zeros(ni), np.zeros(nu)
+    O.train_linear_kernel(1, k, 0.1, HP[0], 0, 0, HP[1], HP[2], HP[3], 0.0, u0, v0, iu, ru, ib2, ub2, 1, 1, 0, rm2)
+    assert np.array_equal(u, u0) and np.array_equal(v, v0)          # u0 / v0 now hold the oracle's result
+    assert np.array_equal(ib, ib2) and np.array_equal(ub, ub2)
+    assert abs(rm[0] - rm2[0]) <= 1e-12 * rm2[0]
+    assert dt < 1.0                         # ~30 ms on the device + the first launch; a regression guard
 
 
 def _sampled_residuals(Y, X, off, col, rows, c_pos, lam):
@@ -139,3 +174,36 @@ def test_cfg5_shard_shape_properties():
     assert infoa["n_levels"] == info["n_levels"]
     assert np.array_equal(ua, u) and np.array_equal(va, v) and np.array_equal(iba, ib) and np.array_equal(uba, ub)
     np.testing.assert_allclose(rma, rm, rtol=1e-12)
+
+
+def test_cfg5_whole_one_gpu_properties():
+    """BASELINE cfg 5 at its full size on ONE GPU (28 GB resident): no oracle at this size (10 minutes of CPU per
+    epoch) -- size-independent properties instead."""
+    from mfrec_amd import _shim as S
+    from mfrec_amd.plan import SgdPlan
+    nu, ni, nnz, k = 10000000, 1000000, 1000000000, 64
+    idx, r = synth.make_ratings(nu, ni, nnz)
+    u0, v0 = synth.init_normal(k, ni, 7), synth.init_normal(k, nu, 8)
+    with SgdPlan(idx, r, nu, ni, k) as p:
+        info = p.info()
+        p.set_factors(u0, v0, np.zeros(ni), np.zeros(nu))
+        rm = p.run_kmf(0, 2, *HP)
+        rm = np.concatenate([rm, p.run_kmf(0, 1, *HP)])
+        ib, ub = np.zeros(ni), np.zeros(nu)
+        p.get_factors(u0, v0, ib, ub)
+    assert info["schedule_builder"] == "device" and info["epoch_kernel"] == "levels"
+    # level count >= the largest degree (uniform data: ~1000 + a few sigma for items) and well below the device budget
+    assert 1200 < info["n_levels"] < 3000, info
+    assert np.all(np.isfinite(rm)) and np.all(np.diff(rm) < 0), rm
+    assert np.isfinite(u0).all() and np.isfinite(v0).all() and np.isfinite(ib).all() and np.isfinite(ub).all()
+    del u0, v0
+    # host and device builders on the first 100 M ratings of the same tables: same level structure
+    n = 100000000
+    pidx, pr = np.ascontiguousarray(idx[:n]), np.ascontiguousarray(r[:n])
+    del idx, r
+    lev = np.empty(n, dtype=np.int32); nl = C.c_int64(0)
+    S.check(S.lib().mfx_schedule_levels(S.i32(pidx, "idx", 2), n, nu, ni, lev.ctypes.data_as(S._ip), C.byref(nl)))
+    with SgdPlan(pidx, pr, nu, ni, k, schedule="device", epoch="levels") as p:
+        pinfo = p.info()
+    assert pinfo["schedule_builder"] == "device" and pinfo["n_levels"] == nl.value
+    assert pinfo["max_level"] == int(np.bincount(lev).max())

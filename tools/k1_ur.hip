@@ -102,7 +102,7 @@ __device__ __forceinline__ void res_step(unsigned long long mask, bool ready, co
 // STATIC: every wave owns fixed entities for the whole epoch (run index = slot * waves + wave): any input order, needs the
 // whole grid resident.  !STATIC: runs taken by ticket in input order (input grouped by the resident side).
 // OVL: the polls of the next heads are issued before the wait for the row stores' acknowledgement.
-template <int B, bool STATIC, bool RES_ITEM, bool OVL, bool NOPOLL, int MINW>
+template <int B, bool STATIC, bool RES_ITEM, bool OVL, bool NOPOLL, int MINW, int SLEEP = 1>
 __global__ __launch_bounds__(64, MINW) void k1_res(const URec *__restrict__ recs, const int64_t *__restrict__ run_off,
                                             const int *__restrict__ run_ent, int n_runs, double *Tm, double *Rm, IHdr *hdr,
                                             double *rb, int *ticket, double *se_run, int *err, double lr, double Kres, double Ktrav,
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(64, MINW) void k1_res(const URec *__restrict__ recs
             const unsigned long long mask = __ballot(ready);
             if (!mask) {
                 if (++spins > SPIN_LIMIT) { if (lane == 0) atomicOr(err, 1); bail = true; break; }
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(SLEEP);
                 if (act) h = __builtin_bit_cast(IHdr, ld16c(rH, (unsigned)rec.item * 16u));
                 continue;
             }
@@ -207,7 +207,7 @@ struct Dev {
     int nu, ni; int64_t nnz;
 };
 
-template <int B, bool STATIC, bool RES_ITEM, bool OVL, bool NOPOLL, int MINW>
+template <int B, bool STATIC, bool RES_ITEM, bool OVL, bool NOPOLL, int MINW, int SLEEP = 1>
 static int run_variant(const char *name, int waves, int epochs, const Dev &D, const std::vector<double> &U0, const std::vector<double> &V0,
                        const std::vector<double> &a, const std::vector<double> &c, float ms_ref)
 {
@@ -223,7 +223,7 @@ static int run_variant(const char *name, int waves, int epochs, const Dev &D, co
         CK(hipMemsetAsync(D.d_ticket, 0, 4));
         if (ep == epochs - 1) CK(hipEventRecord(e0));
         hipLaunchKernelGGL(k_hdr_reset, dim3((n_trav + 255) / 256), dim3(256), 0, 0, D.d_hdr, tb, n_trav);
-        hipLaunchKernelGGL((k1_res<B, STATIC, RES_ITEM, OVL, NOPOLL, MINW>), dim3(waves), dim3(64), 0, 0, D.d_in, D.d_run, D.d_rent, D.n_runs, Tm, Rm,
+        hipLaunchKernelGGL((k1_res<B, STATIC, RES_ITEM, OVL, NOPOLL, MINW, SLEEP>), dim3(waves), dim3(64), 0, 0, D.d_in, D.d_run, D.d_rent, D.n_runs, Tm, Rm,
                            D.d_hdr, rb, D.d_ticket, D.d_se, D.d_err, lr, RES_ITEM ? Ki : Ku, RES_ITEM ? Ku : Ki, Kb);
         hipLaunchKernelGGL(k_hdr_finish, dim3((n_trav + 255) / 256), dim3(256), 0, 0, D.d_hdr, tb, n_trav);
         if (ep == epochs - 1) { CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1)); }
@@ -349,27 +349,21 @@ int main(int argc, char **argv)
         if (hipMemcpy(D.d_rent, run_ent.data(), run_ent.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return 1;
         return 0;
     };
-#define RUN(B, ST, RI, OVL, NP, MINW, W) if (run_variant<B, ST, RI, OVL, NP, MINW>(#B " slots " #ST "/" #RI "/" #OVL "/" #NP "/" #MINW, W, epochs, D, U0, V0, a, c, ms_ref)) return 2
+#define RUN(B, ST, RI, OVL, NP, MINW, W, SL) if (run_variant<B, ST, RI, OVL, NP, MINW, SL>(#B " slots " #ST "/" #RI "/" #OVL "/" #NP "/" #MINW "/sleep" #SL, W, epochs, D, U0, V0, a, c, ms_ref)) return 2
     if (!shuffled) {
         if (upload(false, false)) return 1;               // users resident, tickets
-        RUN(8, false, false, false, false, 1, 4096);
-        RUN(8, false, false, true, false, 1, 4096);
-        RUN(8, false, false, true, false, 4, 4096);
-        RUN(8, false, false, true, true, 4, 4096);
+        RUN(8, false, false, false, false, 4, 4096, 1);
+        RUN(8, false, false, false, false, 4, 4096, 4);
+        RUN(8, false, false, false, false, 4, 4096, 16);
+        RUN(8, false, false, false, false, 4, 4096, 64);
     }
     if ((int64_t)ni * 8 * K <= 64ll << 20) {               // items resident, static (any order)
         if (upload(true, true)) return 1;
-        RUN(14, true, true, true, false, 4, 4096);
-        RUN(14, true, true, true, false, 1, 2048);
-        RUN(14, true, true, false, false, 4, 4096);
-        RUN(16, true, true, true, false, 4, 4096);
-        RUN(26, true, true, true, false, 2, 2048);
-        RUN(32, true, true, true, false, 2, 2048);
-        RUN(14, true, true, true, true, 4, 4096);
-    }
-    if ((int64_t)nu * 8 * K <= 64ll << 20) {               // users resident, static
-        if (upload(false, true)) return 1;
-        RUN(50, true, false, true, false, 2, 2048);
+        RUN(26, true, true, false, false, 2, 2048, 1);
+        RUN(18, true, true, false, false, 3, 3072, 1);
+        RUN(20, true, true, false, false, 3, 3072, 1);
+        RUN(32, true, true, false, false, 2, 2048, 1);
+        RUN(18, true, true, false, true, 3, 3072, 1);
     }
     return 0;
 }

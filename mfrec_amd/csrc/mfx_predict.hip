@@ -5,6 +5,7 @@
 #include <string.h>
 #include <cstring>
 #include <rocprim/rocprim.hpp>
+#include <atomic>
 #include <vector>
 #include "mfx_common.h"
 
@@ -376,6 +377,9 @@ __global__ __launch_bounds__(256) void k_topn_fused(int kind, int k, const doubl
             default: p = acc[q]; break;
             }
             if (p != p || p == 0.0 || item == users[j]) continue;          // never listed (mf.py:162,176-182)
+            // a score of -inf is listable (non-zero, not NaN) but cannot be told from the empty-slot sentinel: flag the
+            // user (best dropped score = +inf), the sort path ranks it
+            if (p == -INFINITY) { if (!is_rated(off, off_hi, rated, j, item)) dropped[q] = INFINITY; continue; }
             if (p > ks[q][kTM - 1]) {                                       // would be kept
                 if (is_rated(off, off_hi, rated, j, item)) continue;
                 double cs = p;                                              // sorted insertion by compare-and-swap
@@ -553,6 +557,8 @@ __global__ __launch_bounds__(256) void k_topn_tiled(int kind, int k, const doubl
                     default: p = acc[q]; break;
                     }
                     if (p != p || p == 0.0 || item == users[j]) continue;  // never listed (mf.py:162,176-182)
+                    // (-inf: listable, but indistinguishable from the empty-slot sentinel -> flag the user for the sort path)
+                    if (p == -INFINITY) { if (!is_rated(off, off_hi, rated, j, item)) dropped[q] = INFINITY; continue; }
                     if (p > ks[q][kTM - 1]) {                               // would be kept
                         if (is_rated(off, off_hi, rated, j, item)) continue;
                         double cs = p;
@@ -685,7 +691,7 @@ struct DevBufs {
 
 }  // namespace
 
-static int64_t g_topn_stats[2] = {0, 0};      // users served by the fused kernel / users redone by the sort path
+static std::atomic<int64_t> g_topn_stats[2];   // users served by the fused kernel / users redone by the sort path
 
 // Device-resident model for top-N queries: the one-shot mfx_topn_batch builds one for the call (V = the selected
 // users' columns, a user's position = its place in the batch), mfx_topn_plan_* keep one across calls (V = every
@@ -938,7 +944,7 @@ extern "C" void mfx_topn_plan_destroy(mfx_topn_plan *p)
 extern "C" int mfx_topn_stats(int64_t stats[2])
 {
     if (!stats) return mfx::fail(MFX_E_ARG, "mfx_topn_stats: NULL");
-    stats[0] = g_topn_stats[0];
-    stats[1] = g_topn_stats[1];
+    stats[0] = g_topn_stats[0].load();
+    stats[1] = g_topn_stats[1].load();
     return MFX_OK;
 }

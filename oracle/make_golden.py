@@ -67,7 +67,66 @@ def same(a, b, what):
         raise SystemExit("restatement != reference for %s (max abs diff %s)" % (what, d))
 
 
+def topn_fixture(save):
+    """Model + rated lists + queries -> the lists oracle.find_recommended_items gives, for every predictor family.
+    The cases the rules distinguish: rated items and the item whose id equals the user's id excluded, a folded-in
+    user (no row in the ratings matrix), exact zeros and NaN scores dropped, exact ties (identical item columns),
+    N larger than what qualifies, candidate windows (neighborhood) smaller than the catalogue, k above one 64-feature
+    chunk."""
+    out = {}
+    for tag, (nu, ni, k) in (("a", (150, 110, 8)), ("b", (90, 300, 70))):
+        rs = np.random.RandomState(12 if tag == "a" else 13)
+        u, v = rs.normal(0, 0.4, (k, ni)), rs.normal(0, 0.4, (k, nu + 1))       # user `nu` = folded in (no ratings row)
+        ib, ub = rs.normal(0, 0.2, ni), rs.normal(0, 0.2, nu + 1)
+        mu = 3.3
+        u[:, 40] = 0.0; ib[40] = 0.0                       # exact zero for the linear / plain-dot predictors
+        u[:, 41] = u[:, 42]; ib[41] = ib[42]               # exact tie
+        u[:, 50] = np.nan                                  # NaN -> 0 -> dropped
+        nnz = 25 * nu
+        ridx = np.stack([rs.randint(0, nu, nnz), rs.randint(0, ni, nnz)], axis=1)
+        lists = {}
+        for a, b in ridx:
+            lists.setdefault(int(a), set()).add(int(b))
+        off = np.zeros(nu + 1, dtype=np.int64)
+        flat = []
+        for usr in range(nu):
+            flat += sorted(lists.get(usr, ()))
+            off[usr + 1] = len(flat)
+        users = np.array([0, 7, nu - 1, nu, 33, min(ni, nu) - 1, 5, 5, 41], dtype=np.int32)
+        out.update({"in_%s_u" % tag: u, "in_%s_v" % tag: v, "in_%s_ib" % tag: ib, "in_%s_ub" % tag: ub,
+                    "p_%s_mu" % tag: mu, "in_%s_rated_off" % tag: off, "in_%s_rated" % tag: np.array(flat, dtype=np.int32),
+                    "in_%s_users" % tag: users, "p_%s_nu" % tag: nu, "p_%s_ni" % tag: ni, "p_%s_k" % tag: k})
+        cases = ((ni, 6), (64, 70), (17, 3))
+        out["p_%s_cases" % tag] = np.array(cases, dtype=np.int32)
+        for kind in (O.RMSE_GD, O.RMSE_KMF_LINEAR, O.RMSE_KMF_LOGISTIC, O.RMSE_GD_BIAS, O.RMSE_WRMF):
+            for ci, (n_cand, N) in enumerate(cases):
+                items = np.full((users.shape[0], N), -1, dtype=np.int32)
+                scores = np.zeros((users.shape[0], N))
+                for j, usr in enumerate(users):
+                    rated = flat[off[usr]:off[usr + 1]] if usr < nu else ()
+                    it, sc = O.find_recommended_items(kind, u, v, int(usr), rated, n_cand, N, ib, ub, mu)
+                    items[j, :len(it)] = it
+                    scores[j, :len(sc)] = sc
+                    # the fixture must not hinge on last-bit differences: neighbours in a list are either exactly
+                    # tied or clearly apart
+                    for x, y in zip(sc[:-1], sc[1:]):
+                        assert x == y or x - y > 1e-9 * max(1.0, abs(x)), (tag, kind, usr, x, y)
+                out["out_%s_items_kind%d_case%d" % (tag, kind, ci)] = items
+                out["out_%s_scores_kind%d_case%d" % (tag, kind, ci)] = scores
+        # precision / recall of a held-out set, kind GD (metrics.py:85-130)
+        test = np.stack([rs.randint(0, nu, 200), rs.randint(0, ni, 200), rs.randint(1, 6, 200)], axis=1).astype(np.float64)
+        rl = {usr: flat[off[usr]:off[usr + 1]] for usr in range(nu)}
+        out["in_%s_test" % tag] = test
+        out["out_%s_prf" % tag] = np.array(O.precision_recall(O.RMSE_GD, u, v, rl, test, 5, ni))
+    save("g12_topn", **out)
+
+
 def main():
+    if "--only=g12_topn" in sys.argv[1:] and not os.path.isdir(build_ref.REF):
+        # the one fixture that does not come from the reference can be regenerated anywhere
+        os.makedirs(GOLD, exist_ok=True)
+        topn_fixture(lambda name, **kw: np.savez_compressed(os.path.join(GOLD, name + ".npz"), **kw))
+        return
     if not build_ref.build():
         raise SystemExit("reference not present: cannot generate golden vectors here")
     ref = build_ref.load()
@@ -373,6 +432,11 @@ def main():
          in_rated=rated, in_rated_hash=rated_hash, in_ib=ib, in_ub=ub, out_u=u, out_v=v, out_y=y,
          out_rmse_hist=hist, p_b_min_epochs=2, p_b_min_improvement=1e-4, p_b_lr=0.02, out_b_u=ua, out_b_v=va,
          out_b_y=ya, out_b_rmse_hist=hist_b[:nb])
+
+    # ---------------- G12: top-N ranking (mf.py:144-193, gradient_descent.py:768-800) ----------------
+    # PARITY UNPINNED for this fixture: the reference's Python-2 harness cannot be imported, so
+    # the expected lists come from the cited restatement in oracle/oracle.py, not from the reference itself.
+    topn_fixture(save)
 
     for name, size in written:
         print("%-18s %8d B" % (name, size))

@@ -218,3 +218,76 @@ def rmse(kind, u, v, ratings_index, ratings, items_bias=None, users_bias=None, o
     return lib().mfxo_rmse(C.c_int(kind), C.c_int(u.shape[0]), _d(u), _d(v), _i(ratings_index),
                            _d(ratings), _d(items_bias), _d(users_bias), C.c_double(overall_avg),
                            C.c_int64(ratings.shape[0]), C.c_int(nu), C.c_int(ni))
+
+
+# ------------------------------------------------------------------------------------------------
+# Top-N (evaluation side).  PARITY UNPINNED: the reference's Python-2 harness (mf.py, gradient_descent.py,
+# metrics.py) cannot be imported here, so this restatement is checked by reading only; the
+# golden g12_topn.npz is generated FROM it (oracle/make_golden.py) and pins the HIP path to these rules.
+# ------------------------------------------------------------------------------------------------
+def predict_one(kind, u, v, item, user, items_bias=None, users_bias=None, overall_avg=0.0, min_rating=1.0,
+                max_rating=5.0):
+    """The families' predict(item, user): GD `dot + 1.0` (gradient_descent.py:621-634), GD with the BellKor baseline
+    (:637-648), KMF linear / logistic (kmf.py:79-94), WRMF plain dot (wrmf.py:67-69)."""
+    s = float(np.dot(u[:, item], v[:, user]))
+    if kind == RMSE_GD:
+        return s + 1.0
+    if kind == RMSE_WRMF:
+        return s
+    if kind == RMSE_GD_BIAS:
+        return s + (overall_avg + (items_bias[item] + users_bias[user]))
+    s += (items_bias[item] + users_bias[user])
+    if kind == RMSE_KMF_LINEAR:
+        return s
+    return min_rating + (1.0 / (1.0 + np.exp(-s))) * (max_rating - min_rating)      # RMSE_KMF_LOGISTIC
+
+
+def find_recommended_items(kind, u, v, user_index, rated_items, neighborhood, nbr_recommendations, items_bias=None,
+                           users_bias=None, overall_avg=0.0):
+    """MFRecommender.find_recommended_items (mf.py:144-193) = GDRecommender.find_user_top_match
+    (gradient_descent.py:768-800 with neighborhood = nbr_items), the loop as the reference runs it:
+
+      * candidates are the POSITIONS 0 .. neighborhood-1: the reference draws `test_items = get_items_subset(count)`
+        (one np.random.shuffle) and then enumerates it, predicting for the enumeration index, not for the drawn id
+        (mf.py:159-167) -- the draw only advances the RNG;
+      * already_rated = the user's rated items plus the item whose id equals user_index (`np.r_[already_rated,
+        user_index]`, mf.py:161-162): those score 0;
+      * NaN scores become 0 (mf.py:176); zero scores are dropped (`nonzero()`, mf.py:179);
+      * `sorted(top_results.iteritems(), key=itemgetter(1), reverse=True)` (mf.py:184): descending score; Python's sort
+        is stable also with reverse=True, and a CPython-2 dict keyed by small non-negative ints iterates in ascending key
+        order, so ties come out by ascending item (for ids beyond the dict's table size the reference's tie order is an
+        implementation detail of that dict; ascending is used here throughout).
+    -> (items list, scores list), at most nbr_recommendations long."""
+    n = int(min(neighborhood, u.shape[1]))
+    already = set(int(x) for x in rated_items)
+    already.add(int(user_index))
+    user_ratings = np.zeros(n)
+    for i in range(n):
+        if i not in already:
+            rating = predict_one(kind, u, v, i, user_index, items_bias, users_bias, overall_avg)
+        else:
+            rating = 0.0
+        user_ratings[i] = rating
+    user_ratings[np.where(np.isnan(user_ratings))] = 0.0
+    top = [(int(i), float(user_ratings[i])) for i in user_ratings.nonzero()[0]]       # ascending item
+    top = sorted(top, key=lambda kv: kv[1], reverse=True)[:nbr_recommendations]       # stable
+    return [i for i, _ in top], [s for _, s in top]
+
+
+def precision_recall(kind, u, v, rated_lists, test_triples, nbr_recommendations, neighborhood, items_bias=None,
+                     users_bias=None, overall_avg=0.0):
+    """metrics.precision_recall (metrics.py:85-130): test triples (user, item, rating) grouped by user; per user
+    hits = |top-N ∩ test items|, precision = hits / N, recall = hits / |test items|; averages over the users, and
+    F1 = 2PR / (P + R).  rated_lists[user] = the user's TRAINING items (excluded from the candidates)."""
+    by_user = {}
+    for row in test_triples:
+        by_user.setdefault(int(row[0]), []).append(int(row[1]))
+    P = R = 0.0
+    for user, items in by_user.items():
+        rec, _ = find_recommended_items(kind, u, v, user, rated_lists.get(user, ()), neighborhood, nbr_recommendations,
+                                        items_bias, users_bias, overall_avg)
+        hit = float(len(set(rec) & set(items)))
+        P += hit / nbr_recommendations
+        R += hit / len(set(items))
+    P, R = P / len(by_user), R / len(by_user)
+    return P, R, 2 * (P * R) / (P + R)          # (ZeroDivisionError when nothing was hit, as in the reference)

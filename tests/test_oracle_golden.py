@@ -172,3 +172,30 @@ def test_g11_implicit_feedback(golden):
                                                 g["in_ib"], g["in_ub"], 60, 40, 0, hist)
     assert np.array_equal(u, g["out_b_u"]) and np.array_equal(y, g["out_b_y"])
     assert np.array_equal(hist[:n], g["out_b_rmse_hist"])
+
+
+def test_topn_restatement_rules_and_fixture(golden):
+    """The ranking rules of mf.py:144-193 restated in oracle/oracle.py: a hand-checkable case, then the committed
+    fixture (generated from this restatement; parity unpinned -- the Python-2 harness cannot be run here)."""
+    from oracle import oracle as O
+    u = np.array([[1.0, 2.0, 2.0, 0.0, 5.0, np.nan, 3.0]])           # k = 1, 7 items
+    v = np.array([[1.0, 1.0]])
+    # user 1, rated {4}: item 1 = the user's own id (excluded), item 4 rated (excluded), item 3 scores 0 (dropped),
+    # item 5 NaN (dropped), items 0 / 2 / 6 qualify; WRMF predictor = plain dot
+    items, scores = O.find_recommended_items(O.RMSE_WRMF, u, v, 1, [4], 7, 5)
+    assert items == [6, 2, 0] and scores == [3.0, 2.0, 1.0]
+    # ties by ascending item; a window (neighborhood) of 3 only sees items 0..2; GD predictor adds 1.0
+    items, scores = O.find_recommended_items(O.RMSE_GD, u, v, 0, [], 3, 5)
+    assert items == [1, 2] and scores == [3.0, 3.0]
+    g = golden("g12_topn")
+    for tag in ("a", "b"):
+        um, vm, ib, ub = g["in_%s_u" % tag], g["in_%s_v" % tag], g["in_%s_ib" % tag], g["in_%s_ub" % tag]
+        off, flat, users, nu = g["in_%s_rated_off" % tag], g["in_%s_rated" % tag], g["in_%s_users" % tag], int(g["p_%s_nu" % tag])
+        for kind in range(5):
+            for ci, (n_cand, N) in enumerate(g["p_%s_cases" % tag]):
+                want_i, want_s = g["out_%s_items_kind%d_case%d" % (tag, kind, ci)], g["out_%s_scores_kind%d_case%d" % (tag, kind, ci)]
+                for j, usr in enumerate(users):
+                    rated = flat[off[usr]:off[usr + 1]] if usr < nu else ()
+                    it, sc = O.find_recommended_items(kind, um, vm, int(usr), rated, int(n_cand), int(N), ib, ub, float(g["p_%s_mu" % tag]))
+                    assert it == [int(x) for x in want_i[j] if x >= 0]
+                    assert np.array_equal(np.array(sc), want_s[j, :len(sc)])

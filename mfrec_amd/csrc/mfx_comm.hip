@@ -46,6 +46,12 @@ int load_rccl()
     // MFX_RCCL_LIB: a library with the same twelve entry points -- the tests' shared-memory stand-in that lets
     // several processes on ONE GPU rehearse the N > 1 paths (tests/mock_rccl); the product never sets it
     const char *over = getenv("MFX_RCCL_LIB");
+    if (over && over[0]) {
+        // a test hook, never a deployment knob: honoured only when the process says it is a test
+        const char *t = getenv("MFX_TESTING");
+        if (!(t && t[0] == '1'))
+            return mfx::fail(MFX_E_RCCL, "MFX_RCCL_LIB is a test hook (tests/mock_rccl) and needs MFX_TESTING=1; unset it to use librccl");
+    }
     const char *names[] = {over && over[0] ? over : "librccl.so.1", "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char *n : names) {
         R.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);

@@ -1052,8 +1052,13 @@ int funk_core(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_
         if (!rc) rc = dev_alloc(p, &p->d_k2dyn, 1);
         if (rc) return rc;
     }
-    rc = ensure_k2x(p);                  // may re-order the ratings inside their levels: before the cache is used
-    if (rc) return rc;
+    // may re-order the ratings inside their levels: before the cache is used.  The XCD-resident pass is an optional
+    // acceleration: if its preparation fails (scratch memory, attribute), the records are either untouched or fully
+    // re-ordered inside their levels -- both are valid inputs of the launch path -- so the run goes on there
+    if (ensure_k2x(p) != MFX_OK) {
+        (void)hipGetLastError();
+        p->k2x_state = -1;
+    }
     MFX_HIP(hipMemsetAsync(p->d_cache, 0, (size_t)(p->nnz ? p->nnz : 1) * sizeof(double), stream()));
     double rmse = 2.0, rmse_last = 0.0;
     int64_t nh = 0;

@@ -148,6 +148,10 @@ def estimator_loop_with_implicit_feedback(min_epochs, max_epochs, min_improvemen
     user with distinct pairs, `rated_hash` int32[nu, 2] (first row, count) -- gradient_descent.py:261-296.  The
     loop is sequential by nature (every rating rewrites y[f, :] for all items of its user): one workgroup walks the
     ratings in order; exact, not fast."""
+    import logging
+    logging.getLogger("mfrec.recommender").warning(
+        "estimator_loop_with_implicit_feedback: this loop has no exact parallel schedule; the GPU walks it sequentially, "
+        "bit-identical to the reference but 6-7x SLOWER than the reference's C loop on one host core (DESIGN.md section 8)")
     pu, pv, nu, ni = S.factor_args(u, v, int(dim))
     py = S.f64(y, "y", 2, (int(dim), ni))
     pi, pr, nnz = S.ratings_args(ratings_index, ratings)

@@ -238,16 +238,18 @@ class BaseRecommender(object):
     def load_state(self, filename):
         """Inverse of save_state; also reads a file set written by the reference itself (its pickles are
         Python 2 text pickles, its svd_s an object array): base.py:578-596.  The ratings come back as a
-        lil_matrix (the reference keeps mmread's coo_matrix; every consumer here indexes the matrix)."""
+        lil_matrix (the reference keeps mmread's coo_matrix; every consumer here indexes the matrix).
+        TRUST: the five dictionaries are pickles and svd_s is a pickled object array (the reference's format):
+        loading a state executes whatever the files' author put there -- only load files you wrote yourself.
+        The factor arrays themselves are read WITHOUT pickle."""
         import scipy.io
-        z = np.load(filename + "_svd.npz", allow_pickle=True)
-        self.svd_u, self.svd_v = z["svd_u"], z["svd_v"]
-        s = z["svd_s"]
+        z = np.load(filename + "_svd.npz", allow_pickle=False)
+        self.svd_u, self.svd_v = z["svd_u"], z["svd_v"]          # plain f64 arrays: no pickle involved
+        try:
+            s = z["svd_s"]
+        except ValueError:                                       # an object array (None for the SGD / ALS families)
+            s = np.load(filename + "_svd.npz", allow_pickle=True)["svd_s"]
         self.svd_s = s.item() if (s.dtype == object and s.shape == ()) else s
-        for name in ("svd_u", "svd_v"):
-            a = getattr(self, name)
-            if a.dtype == object and a.shape == ():
-                setattr(self, name, a.item())
         self.relationship_matrix = lil_matrix(scipy.io.mmread(filename + "_relations.mtx"))
         self._nbr_users, self._nbr_items = self.relationship_matrix.shape
         for suffix, attr in self._STATE_DICTS:

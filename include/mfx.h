@@ -373,7 +373,10 @@ mfx_dsgd *mfx_dsgd_create(const int32_t *ratings_index, const double *ratings, i
                           int world, int flags);
 void mfx_dsgd_destroy(mfx_dsgd *d);
 /* info[0] = ratings held by this process, [1] = dependency levels summed over its blocks,
- * [2] / [3] = largest / smallest block (ratings), [4] = kernel launches per epoch, [5] = item blocks */
+ * [2] / [3] = largest / smallest block (ratings), [4] = kernel launches per epoch, [5] = item blocks,
+ * [6] = blocks whose epoch is the resident-side launch (MFX_EPOCH_STATIC chosen by the cost model: every block is
+ *       a plan of its own; such a launch needs its whole grid co-resident -- on a GPU shared with another process the
+ *       run ends with MFX_E_HIP and a message naming MFX_K1_RES=levels) */
 int mfx_dsgd_info(const mfx_dsgd *d, int64_t info[8]);
 /* perm_out[p] = index (into the arrays given to mfx_dsgd_create) of the p-th rating of the sequential order
  * this object's epoch equals, restricted to the ratings this process holds (info[0] entries). */

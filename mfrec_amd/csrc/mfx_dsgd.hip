@@ -210,7 +210,7 @@ mfx_dsgd *mfx_dsgd_create(const int32_t *idx, const double *r, int64_t nnz, int 
                         borig[b].swap(no2);
                     }
                 }
-                R.plans[j] = plan_create_ex(bidx[b].data(), br[b].data(), cnt[b], nul, nil, dim, MFX_SCHED_AUTO, MFX_EPOCH_LEVELS);
+                R.plans[j] = plan_create_ex(bidx[b].data(), br[b].data(), cnt[b], nul, nil, dim, MFX_SCHED_AUTO, MFX_EPOCH_AUTO | kEpochHeadroom);
                 if (!R.plans[j] || (j > 0 && plan_alias_users(R.plans[j], R.plans[0])) ||
                     hipEventCreateWithFlags(&R.trained[j], hipEventDisableTiming) != hipSuccess ||
                     hipEventCreateWithFlags(&R.arrived[j], hipEventDisableTiming) != hipSuccess) {
@@ -249,6 +249,7 @@ int mfx_dsgd_info(const mfx_dsgd *d, int64_t info[8])
             const int64_t n = plan_nnz(p);
             if (n > info[2]) info[2] = n;
             if (n < info[3]) info[3] = n;
+            if (plan_epoch_kernel(p) != MFX_EPOCH_LEVELS) ++info[6];      // blocks on the resident-side epoch
         }
     return MFX_OK;
 }
@@ -376,6 +377,9 @@ int mfx_dsgd_run_kmf(mfx_dsgd *d, int mode, int nbr_epochs, double lr, double Ku
     MFX_HIP(hipStreamSynchronize(s));
     for (DsgdRank &R : d->ranks)
         for (int j = 0; j < B; ++j) R.in_flight[j] = 0;
+    for (DsgdRank &R : d->ranks)                                  // blocks on the resident-side epoch report through a status word
+        for (mfx_sgd_plan *p : R.plans)
+            if ((rc = sgd_res_check(p))) return rc;
     if (se_out) {
         std::vector<double> se((size_t)nbr_epochs, 0.0);
         // per epoch: blocks in step order, ranks in rank order (fake world: exactly the order of the

@@ -406,12 +406,12 @@ int enqueue_res_epoch(mfx_sgd_plan *p, int mode, const K1Params &P)
 bool res_applies(const mfx_sgd_plan *p, int mode, const K1Params &P)
 {
     return p->res && p->res_state == 1 && (mode == K1_LINEAR || mode == K1_LOGISTIC) && !p->f32 && !p->dot &&
-           P.upd_u && P.upd_i && p->owns_users;
+           P.upd_u && P.upd_i;
 }
 
 template <typename Hook>
 int run_k1_epochs(mfx_sgd_plan *p, int mode, int epochs, const K1Params &P, Hook &&hook, bool reset_se = true,
-                  bool allow_res = false)
+                  bool allow_res = false, bool defer_status = false)
 {
     int rc = reset_se ? ensure_se_cap(p, epochs) : MFX_OK;
     if (rc) return rc;
@@ -420,7 +420,7 @@ int run_k1_epochs(mfx_sgd_plan *p, int mode, int epochs, const K1Params &P, Hook
     p->km_current = false;
     if (reset_se) MFX_HIP(hipMemsetAsync(p->d_counter, 0, sizeof(int), stream()));
     const bool res = allow_res && res_applies(p, mode, P);
-    if (res && (rc = res_begin_batch(p->res))) return rc;
+    if (res && !defer_status && (rc = res_begin_batch(p->res))) return rc;
     // very long launch sequences (power-law data without the tail kernel) are not worth a graph
     const bool graph = use_graph() && (res || p->segs.size() <= kMaxGraphNodes);
     if (graph && !(p->graph && p->graph_mode == mode && p->graph_res == res && same_params(p->graph_params, P))) {
@@ -455,7 +455,7 @@ int run_k1_epochs(mfx_sgd_plan *p, int mode, int epochs, const K1Params &P, Hook
         rc = hook(ep);
         if (rc) return rc;
     }
-    if (res) {
+    if (res && !defer_status) {
         // the resident-side launch reports through a status word: 1 = the static grid was not co-resident and
         // NOTHING was modified by any epoch of this batch (the word is sticky) -> the level schedule, from now on
         MFX_HIP(hipStreamSynchronize(stream()));
@@ -504,6 +504,7 @@ int sgd_reset_se(mfx_sgd_plan *p, int64_t epochs)
     int rc = ensure_se_cap(p, epochs);
     if (rc) return rc;
     MFX_HIP(hipMemsetAsync(p->d_counter, 0, sizeof(int), stream()));
+    if (p->res && p->res_state == 1) return res_begin_batch(p->res);
     return MFX_OK;
 }
 int sgd_enqueue_k1(mfx_sgd_plan *p, int mode, double lr, double Ku, double Ki, double Kb)
@@ -511,7 +512,25 @@ int sgd_enqueue_k1(mfx_sgd_plan *p, int mode, double lr, double Ku, double Ki, d
     int rc = check_plan(p, "sgd_enqueue_k1");
     if (rc) return rc;
     K1Params P = k1_params(p, lr, Ku, Ki, Kb, 1, 1);
-    return run_k1_epochs(p, mode, 1, P, [](int) { return MFX_OK; }, false);
+    return run_k1_epochs(p, mode, 1, P, [](int) { return MFX_OK; }, false, true, true);
+}
+int sgd_res_check(mfx_sgd_plan *p)
+{
+    if (!p->res || p->res_state != 1) return MFX_OK;
+    unsigned status = 0;
+    int rc = res_status(p->res, &status);
+    if (rc) return rc;
+    if (status == 1) {
+        p->res_state = -1;
+        return fail(MFX_E_HIP, "the static resident-side epoch of a block found its grid not co-resident (is another process using this "
+                               "GPU?); the block was skipped and the run is invalid -- set MFX_K1_RES=levels and run again");
+    }
+    if (status) return fail(MFX_E_HIP, "a resident-side block epoch timed out waiting for a chain counter");
+    return MFX_OK;
+}
+int plan_epoch_kernel(const mfx_sgd_plan *p)
+{
+    return (p->res && p->res_state == 1 && !p->f32 && !p->dot) ? res_kind(p->res) + 1 : MFX_EPOCH_LEVELS;
 }
 int sgd_fetch_se(mfx_sgd_plan *p, int64_t n, double *se_out) { return fetch_rmse(p, n, nullptr, se_out); }
 double *plan_U(mfx_sgd_plan *p) { return p->d_U_nk; }
@@ -622,7 +641,7 @@ mfx_sgd_plan *mfx::plan_create_ex(const int32_t *idx, const double *r, int64_t n
 {
     mfx::TraceRange trace_("mfx:plan_create (schedule + upload)");
     if (!idx || !r || nnz < 0 || nu <= 0 || ni <= 0 || dim < 1 || dim > kMaxK ||
-        sched < MFX_SCHED_AUTO || sched > MFX_SCHED_DEVICE || epoch < MFX_EPOCH_AUTO || epoch > MFX_EPOCH_STATIC) {
+        sched < MFX_SCHED_AUTO || sched > MFX_SCHED_DEVICE || (epoch & 0xff) < MFX_EPOCH_AUTO || (epoch & 0xff) > MFX_EPOCH_STATIC) {
         fail(MFX_E_ARG, "mfx_sgd_plan_create: bad argument (nnz=%lld nu=%d ni=%d k=%d sched=%d; 1 <= k <= %d)",
              (long long)nnz, nu, ni, dim, sched, kMaxK);
         return nullptr;
@@ -770,8 +789,8 @@ mfx_sgd_plan *mfx::plan_create_ex(const int32_t *idx, const double *r, int64_t n
             return bail();
         }
         if (ensure_se_cap(p, 64)) return bail();
-        if (epoch != MFX_EPOCH_LEVELS) {
-            if (res_prepare(&p->res, idx, r, nnz, nu, ni, dim, p->n_levels, epoch)) return bail();
+        if ((epoch & 0xff) != MFX_EPOCH_LEVELS) {
+            if (res_prepare(&p->res, idx, r, nnz, nu, ni, dim, p->n_levels, epoch & 0xff, (epoch & kEpochHeadroom) != 0)) return bail();
             if (p->res) { p->res_state = 1; p->dev_bytes += res_dev_bytes(p->res); }
         }
     } catch (const std::bad_alloc &) {

@@ -44,7 +44,8 @@ void plan_mark_ready(mfx_sgd_plan *p);
 
 // ---- resident-side full-k epoch (mfx_sgd_res.hip) -------------------------------------------
 struct ResPlan;
-int res_prepare(ResPlan **out, const int32_t *idx, const double *r, int64_t nnz, int nu, int ni, int k, int64_t n_levels, int want);
+int res_prepare(ResPlan **out, const int32_t *idx, const double *r, int64_t nnz, int nu, int ni, int k, int64_t n_levels, int want,
+                bool headroom);
 void res_destroy(ResPlan *rp);
 int res_kind(const ResPlan *rp);                 // 0 none, 1 ticket (users resident, runs by ticket), 2 static owners
 size_t res_dev_bytes(const ResPlan *rp);
@@ -55,8 +56,14 @@ int res_begin_batch(ResPlan *rp);
 int res_enqueue_epoch(ResPlan *rp, int mode, double *U_nk, double *V_nk, double *ib, double *ub, double lr, double Ku,
                       double Ki, double Kb);
 int res_status(ResPlan *rp, unsigned *status);
-// plan creation with the epoch kernel chosen (MFX_EPOCH_*); the Funk / learned-bias / dense-cache drop-ins and the
-// DSGD sub-plans pass MFX_EPOCH_LEVELS: they never run a plain full-k epoch
+// plan creation with the epoch kernel chosen (MFX_EPOCH_*); the Funk / learned-bias / dense-cache drop-ins pass
+// MFX_EPOCH_LEVELS: they never run a plain full-k epoch.  | kEpochHeadroom (DSGD sub-plans): a static grid leaves an eighth
+// of the chip's wave slots free, for the transfer kernels that run beside it.
+constexpr int kEpochHeadroom = 0x100;
+// DSGD enqueues block epochs asynchronously (sgd_enqueue_k1): the resident-side launch's status word is cleared by
+// sgd_reset_se and read by sgd_res_check after the caller's own stream sync -- non-zero: MFX_E_HIP (no fallback mid-run).
+int sgd_res_check(mfx_sgd_plan *p);
+int plan_epoch_kernel(const mfx_sgd_plan *p);      // MFX_EPOCH_LEVELS / _TICKET / _STATIC in use
 mfx_sgd_plan *plan_create_ex(const int32_t *idx, const double *r, int64_t nnz, int nu, int ni, int dim, int sched, int epoch);
 
 // ---- Funk hooks (user-sharded Funk pass) ---------------------------------------------------

@@ -350,7 +350,8 @@ static double est_res_ms(int64_t nnz, int64_t levels, bool stat)
 // not.  want: MFX_EPOCH_AUTO (cost model; the environment variable MFX_K1_RES = levels / ticket / static overrides
 // it: tuning hook), MFX_EPOCH_LEVELS (never), MFX_EPOCH_TICKET / MFX_EPOCH_STATIC (that binding, or MFX_E_ARG
 // when the plan is not eligible for it).
-int res_prepare(ResPlan **out, const int32_t *idx, const double *r, int64_t nnz, int nu, int ni, int k, int64_t n_levels, int want)
+int res_prepare(ResPlan **out, const int32_t *idx, const double *r, int64_t nnz, int nu, int ni, int k, int64_t n_levels, int want,
+                bool headroom)
 {
     *out = nullptr;
     bool forced = want == MFX_EPOCH_TICKET || want == MFX_EPOCH_STATIC;
@@ -404,6 +405,10 @@ int res_prepare(ResPlan **out, const int32_t *idx, const double *r, int64_t nnz,
         int occ = 0;
         MFX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ss.fn, 64, (size_t)Bs * (2 * ss.kp + 2) * 8));
         waves_s = occ * cus;
+        if (headroom) {                                      // leave an eighth of the slots to whatever runs beside the launch
+            const int64_t need = ceil_div((int64_t)n_res, (int64_t)Bs), spare = (int64_t)waves_s * 7 / 8;
+            if (need <= spare) waves_s = (int)spare;
+        }
         if ((int64_t)waves_s * Bs >= n_res) break;
     }
     const bool static_ok = waves_s > 0 && (int64_t)waves_s * Bs >= n_res && (int64_t)n_trav * k * 8 < ((int64_t)1 << 31);

@@ -176,8 +176,8 @@ class DsgdKMF(object):
         from . import _shim as S
         a = (C.c_int64 * 8)()
         S.check(S.lib().mfx_dsgd_info(self._h, a))
-        return dict(zip(("nnz_local", "levels_total", "max_block", "min_block", "launches_per_epoch", "item_blocks"),
-                        [int(x) for x in a][:6]))
+        return dict(zip(("nnz_local", "levels_total", "max_block", "min_block", "launches_per_epoch", "item_blocks",
+                         "resident_blocks"), [int(x) for x in a][:7]))
 
     def order(self):
         """int64 perm: the sequential rating order this object's epoch is bit-identical to (the ratings this

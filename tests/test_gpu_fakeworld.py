@@ -94,6 +94,30 @@ def test_dsgd_fake_world_equals_sequential_oracle_on_block_order(world, k, mode,
         T2.close()
 
 
+@pytest.mark.parametrize("world,balanced", [(2, False), (3, True)])
+def test_dsgd_blocks_on_the_static_resident_epoch(world, balanced, monkeypatch):
+    """Every block a plan of its own on the resident-side epoch (forced: the cost model keeps problems this small on the
+    level schedule): still the sequential loop on the order the library reports, bit for bit."""
+    from mfrec_amd.sharding import DsgdKMF
+    from oracle import dsgd_sim as DS
+    monkeypatch.setenv("MFX_K1_RES", "static")
+    nu, ni, nnz, E, k = 900, 400, 40000, 3, 32
+    idx, r = synth.make_ratings(nu, ni, nnz, seed=6)
+    u0, v0 = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
+    T = DsgdKMF(idx, r, nu, ni, k, -1, world, balanced=balanced)
+    info = T.info()
+    assert info["resident_blocks"] == world * world, info
+    T.set_factors(u0, v0, np.zeros(ni), np.zeros(nu))
+    se = T.train(0, E, *HP)
+    u, v, ib, ub = np.zeros((k, ni)), np.zeros((k, nu)), np.zeros(ni), np.zeros(nu)
+    T.get_factors(u, v, ib, ub)
+    perm = T.order()
+    T.close()
+    su, sv, sib, sub, rm = DS.simulate(0, E, k, *HP, u0, v0, np.zeros(ni), np.zeros(nu), idx, r, T.user_bounds, T.item_bounds, perm=perm)
+    assert np.array_equal(u, su) and np.array_equal(v, sv) and np.array_equal(ib, sib) and np.array_equal(ub, sub)
+    np.testing.assert_allclose(np.sqrt(se / nnz), rm, rtol=1e-12)
+
+
 def test_dsgd_empty_blocks_and_real_single_rank():
     """Hand-made bounds with an empty user block and an empty item block; and the non-fake path with
     world = 1 (rank 0): one block, no rotation -- the plain sequential order."""

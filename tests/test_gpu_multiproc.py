@@ -121,7 +121,7 @@ def _launch(mock_lib, tmp_path, world, mode, port):
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), MFX_RCCL_LIB=mock_lib, MFX_TESTING="1")
+                   MASTER_PORT=str(port), MFX_RCCL_LIB=mock_lib, MFX_TESTING="1", MFX_K1_RES="levels")
         procs.append(subprocess.Popen([sys.executable, str(script), mode, out], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     logs = []
@@ -241,7 +241,7 @@ def test_bench_two_ranks_prints_one_line_with_both_modes(mock_lib, tmp_path):
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT="29741", MFX_RCCL_LIB=mock_lib, MFX_TESTING="1", MFX_BENCH_DEVICE="0", MFX_BENCH_DSGD_TIMEOUT="200")
+                   MASTER_PORT="29741", MFX_RCCL_LIB=mock_lib, MFX_TESTING="1", MFX_K1_RES="levels", MFX_BENCH_DEVICE="0", MFX_BENCH_DSGD_TIMEOUT="200")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
                                        "--warmup", "1", "--users", "60000", "--items", "20000", "--nnz", "3000000"],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT))

@@ -8,7 +8,7 @@ N=${1:-2}; shift
 cd "$(dirname "$0")/.."
 mkdir -p build gpurun_out
 [ build/libmock_rccl.so -nt tests/mock_rccl/mock_rccl.cpp ] || hipcc -O2 -fPIC -shared --offload-arch=gfx950 -o build/libmock_rccl.so tests/mock_rccl/mock_rccl.cpp -lrt -lpthread
-export MFX_TESTING=1 MFX_RCCL_LIB=$PWD/build/libmock_rccl.so MFX_BENCH_DEVICE=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29$((RANDOM % 900 + 100)) WORLD_SIZE=$N
+export MFX_K1_RES=levels MFX_TESTING=1 MFX_RCCL_LIB=$PWD/build/libmock_rccl.so MFX_BENCH_DEVICE=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29$((RANDOM % 900 + 100)) WORLD_SIZE=$N
 pids=()
 for ((r = 0; r < N; r++)); do
   RANK=$r LOCAL_RANK=$r python bench.py --gpus $N "$@" > gpurun_out/rehearse_rank$r.out 2> gpurun_out/rehearse_rank$r.err &

@@ -2,10 +2,12 @@
 """bench.py -- rating-updates/s of the full-k SGD hot path (train_linear_kernel semantics).
 
 N = 1 (default):  BASELINE.json configs[1] -- synthetic 100K users x 50K items, 10M ratings, k=64, f64,
-    shuffled order, exact level schedule.  `value` is that.  The same JSON line carries an `also` block
-    with the other kernels of the path, each with its own roofline and CPU baseline:
-    K1 on the user-major and the balanced order, K2 (Funk per-feature pass) on cfg 2, K3 (ALS) on cfg 4
-    at full size, K1 on cfg 3 whole (the 1-GPU point of the strong-scaling curve below).
+    shuffled order, exact (bit-identical to the sequential loop); the library picks the epoch kernel (cfg 2:
+    the static resident-side epoch, ONE persistent launch per epoch).  `value` is that.  The same JSON line
+    carries an `also` block with the other kernels of the path, each with its own roofline and CPU baseline
+    (SURVEY 8(d)): K1 on the level schedule, on the user-major and the balanced order, K2 (Funk per-feature
+    pass) on cfg 2, K3 (ALS) on cfg 4 at full size, K1 on cfg 3 whole in shuffled order (the 1-GPU point of the
+    strong-scaling curve below) and in user-major order (user rows resident: also.k1_user_resident_cfg3).
 N > 1 (one process per GPU under torch.distributed.run): BASELINE.json configs[2] -- 1M users x 200K
     items, 100M ratings, k=64 -- STRONG scaling: the same 100M ratings are sharded by user over the N
     GPUs, item factors replicated, RCCL all-reduce of the item deltas every epoch (north_star's scheme:

@@ -21,6 +21,7 @@
 #include <rocprim/rocprim.hpp>
 #include <vector>
 #include "mfx_common.h"
+#include "mfx_sgd_internal.h"
 
 namespace mfx {
 namespace {
@@ -352,6 +353,77 @@ int schedule_device(const int32_t *h_idx, const double *h_r, int64_t nnz, int nu
     return MFX_OK;
 }
 
+}  // namespace mfx
+
+// ---------------------------------------------------------------------------------------------
+// Records of the resident-side epoch (mfx_sgd_res.hip), built in HBM from the plan's level-major records.  The
+// level-major order lists every user's ratings and every item's ratings in their input order (a chain's ratings
+// have strictly increasing levels), so a STABLE sort by entity gives each entity's list in chain order, and a
+// rating's rank in its travelling entity's chain is its position in that entity's sorted segment.
+namespace mfx {
+namespace {
+__global__ void k_res_keys(const Rec *__restrict__ recs, int64_t nnz, int res_item, int32_t *kres, int32_t *ktrav, int32_t *pos)
+{
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < nnz; p += (int64_t)gridDim.x * blockDim.x) {
+        const Rec q = recs[p];
+        kres[p] = res_item ? q.item : q.user;
+        ktrav[p] = res_item ? q.user : q.item;
+        pos[p] = (int32_t)p;
+    }
+}
+__global__ void k_res_first(const int32_t *__restrict__ ks, int64_t nnz, int32_t *first)
+{
+    for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < nnz; s += (int64_t)gridDim.x * blockDim.x)
+        if (s == 0 || ks[s] != ks[s - 1]) first[ks[s]] = (int32_t)s;
+}
+__global__ void k_res_seq(const int32_t *__restrict__ ks, const int32_t *__restrict__ ps, int64_t nnz,
+                          const int32_t *__restrict__ first, int32_t *seq)
+{
+    for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < nnz; s += (int64_t)gridDim.x * blockDim.x)
+        seq[ps[s]] = (int32_t)s - first[ks[s]];
+}
+__global__ void k_res_pack(const int32_t *__restrict__ ks, const int32_t *__restrict__ ps, int64_t nnz,
+                           const Rec *__restrict__ recs, const int32_t *__restrict__ ktrav, const int32_t *__restrict__ seq,
+                           ResRec *out, int32_t *lo, int32_t *hi)
+{
+    for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < nnz; s += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t p = ps[s], e = ks[s];
+        ResRec o;
+        o.trav = ktrav[p]; o.seq = seq[p]; o.r = recs[p].r;
+        out[s] = o;
+        if (s == 0 || ks[s - 1] != e) lo[e] = (int32_t)s;
+        if (s == nnz - 1 || ks[s + 1] != e) hi[e] = (int32_t)s + 1;
+    }
+}
+}  // namespace
+
+int res_build_device(const Rec *d_recs, int64_t nnz, int n_res, int n_trav, bool res_item, ResRec *d_out, int32_t *d_lo, int32_t *d_hi)
+{
+    if (nnz <= 0 || nnz >= ((int64_t)1 << 31) - 1) return fail(MFX_E_ARG, "res_build_device: unsupported size");
+    hipStream_t st = stream();
+    Scratch S;
+    const size_t n = (size_t)nnz;
+    int32_t *kres, *ktrav, *pos, *ks, *ps, *seq, *first;
+    if (S.get(&kres, n) || S.get(&ktrav, n) || S.get(&pos, n) || S.get(&ks, n) || S.get(&ps, n) || S.get(&seq, n) ||
+        S.get(&first, (size_t)n_trav))
+        return last_code();
+    size_t tmp_bytes = 0;
+    MFX_HIP(sort_pairs(nullptr, tmp_bytes, kres, ks, pos, ps, nnz, 32, st));
+    char *tmp = nullptr;
+    if (S.get(&tmp, tmp_bytes)) return last_code();
+    const int blocks = (int)std::min<int64_t>(ceil_div<int64_t>(nnz, 256), 8192);
+    k_res_keys<<<blocks, 256, 0, st>>>(d_recs, nnz, res_item ? 1 : 0, kres, ktrav, pos);
+    MFX_HIP(sort_pairs(tmp, tmp_bytes, ktrav, ks, pos, ps, nnz, bits_for(n_trav), st));
+    k_res_first<<<blocks, 256, 0, st>>>(ks, nnz, first);
+    k_res_seq<<<blocks, 256, 0, st>>>(ks, ps, nnz, first, seq);
+    MFX_HIP(sort_pairs(tmp, tmp_bytes, kres, ks, pos, ps, nnz, bits_for(n_res), st));
+    MFX_HIP(hipMemsetAsync(d_lo, 0, (size_t)n_res * sizeof(int32_t), st));
+    MFX_HIP(hipMemsetAsync(d_hi, 0, (size_t)n_res * sizeof(int32_t), st));
+    k_res_pack<<<blocks, 256, 0, st>>>(ks, ps, nnz, d_recs, ktrav, seq, d_out, d_lo, d_hi);
+    MFX_HIP(hipGetLastError());
+    MFX_HIP(hipStreamSynchronize(st));
+    return MFX_OK;
+}
 }  // namespace mfx
 
 // ---------------------------------------------------------------------------------------------

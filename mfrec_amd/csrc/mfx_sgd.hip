@@ -790,7 +790,7 @@ mfx_sgd_plan *mfx::plan_create_ex(const int32_t *idx, const double *r, int64_t n
         }
         if (ensure_se_cap(p, 64)) return bail();
         if ((epoch & 0xff) != MFX_EPOCH_LEVELS) {
-            if (res_prepare(&p->res, idx, r, nnz, nu, ni, dim, p->n_levels, epoch & 0xff, (epoch & kEpochHeadroom) != 0)) return bail();
+            if (res_prepare(&p->res, idx, p->d_recs, nnz, nu, ni, dim, p->n_levels, epoch & 0xff, (epoch & kEpochHeadroom) != 0)) return bail();
             if (p->res) { p->res_state = 1; p->dev_bytes += res_dev_bytes(p->res); }
         }
     } catch (const std::bad_alloc &) {

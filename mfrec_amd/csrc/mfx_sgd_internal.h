@@ -44,8 +44,13 @@ void plan_mark_ready(mfx_sgd_plan *p);
 
 // ---- resident-side full-k epoch (mfx_sgd_res.hip) -------------------------------------------
 struct ResPlan;
-int res_prepare(ResPlan **out, const int32_t *idx, const double *r, int64_t nnz, int nu, int ni, int k, int64_t n_levels, int want,
+struct __attribute__((aligned(16))) ResRec { int32_t trav; int32_t seq; double r; };   // travelling entity, its chain rank, rating
+// d_recs: the plan's level-major records (they keep every user's and every item's ratings in input order)
+int res_prepare(ResPlan **out, const int32_t *idx, const Rec *d_recs, int64_t nnz, int nu, int ni, int k, int64_t n_levels, int want,
                 bool headroom);
+// mfx_schedule_dev.hip: records grouped by resident entity (stable: each entity's list is its chain), every rating ranked in its
+// travelling entity's chain; lo / hi [n_res]: the entity's record range (0, 0 when it has none)
+int res_build_device(const Rec *d_recs, int64_t nnz, int n_res, int n_trav, bool res_item, ResRec *d_out, int32_t *d_lo, int32_t *d_hi);
 void res_destroy(ResPlan *rp);
 int res_kind(const ResPlan *rp);                 // 0 none, 1 ticket (users resident, runs by ticket), 2 static owners
 size_t res_dev_bytes(const ResPlan *rp);

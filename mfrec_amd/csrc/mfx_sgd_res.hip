@@ -35,13 +35,13 @@
 
 namespace mfx {
 
-struct __attribute__((aligned(16))) URec { int32_t trav; int32_t seq; double r; };   // travelling entity, its chain rank
+typedef ResRec URec;          // {travelling entity, its chain rank, rating}: 16 bytes, built by res_build_device
 struct __attribute__((aligned(16))) THdr { double bias; int32_t cnt; int32_t pad; };  // travelling entity: bias + chain counter
 
 struct ResParams {
-    const URec *recs;
-    const int64_t *run_off;     // [n_runs + 1]
-    const int32_t *run_ent;     // [n_runs] resident entity of a run
+    const URec *recs;           // grouped by resident entity (stable)
+    const int32_t *lo, *hi;     // [n_res] record range of a resident entity
+    const int32_t *run_ent;     // ticket: [n_runs] resident entity of a run, in input order; static: null (run = entity)
     double *Tm, *Rm;            // travelling / resident rows, [n][k]
     THdr *hdr;                  // [n_trav]
     double *rb;                 // resident biases
@@ -198,7 +198,12 @@ __global__ __launch_bounds__(64, STATIC ? (NR <= 9 ? 3 : 2) : 4) void k1_res(Res
         int64_t base = 0;
         int my_ent = 0;
         bool have = false;
-        if (lane < B && run < P.n_runs) { base = P.run_off[run]; end = (int)(P.run_off[run + 1] - base); my_ent = P.run_ent[run]; have = true; }
+        if (lane < B && run < P.n_runs) {
+            my_ent = STATIC ? (int)run : P.run_ent[run];
+            base = P.lo[my_ent];
+            end = P.hi[my_ent] - (int)base;
+            have = true;
+        }
         const URec *rp = P.recs + base;
         URec rec{0, 0, 0.0}, nxt{0, 0, 0.0};
         // records are read once per epoch: non-temporal
@@ -305,7 +310,7 @@ struct ResPlan {
     int kp = 0, nr = 0, B = 0, waves = 0;
     int64_t nnz = 0, se_slots = 0;
     URec *d_recs = nullptr;
-    int64_t *d_run_off = nullptr;
+    int32_t *d_lo = nullptr, *d_hi = nullptr;
     int32_t *d_run_ent = nullptr;
     THdr *d_hdr = nullptr;
     unsigned *d_ctl = nullptr;
@@ -317,7 +322,7 @@ struct ResPlan {
 void res_destroy(ResPlan *rp)
 {
     if (!rp) return;
-    void *ptrs[] = {rp->d_recs, rp->d_run_off, rp->d_run_ent, rp->d_hdr, rp->d_ctl, rp->d_se_run};
+    void *ptrs[] = {rp->d_recs, rp->d_lo, rp->d_hi, rp->d_run_ent, rp->d_hdr, rp->d_ctl, rp->d_se_run};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     delete rp;
@@ -350,7 +355,7 @@ static double est_res_ms(int64_t nnz, int64_t levels, bool stat)
 // not.  want: MFX_EPOCH_AUTO (cost model; the environment variable MFX_K1_RES = levels / ticket / static overrides
 // it: tuning hook), MFX_EPOCH_LEVELS (never), MFX_EPOCH_TICKET / MFX_EPOCH_STATIC (that binding, or MFX_E_ARG
 // when the plan is not eligible for it).
-int res_prepare(ResPlan **out, const int32_t *idx, const double *r, int64_t nnz, int nu, int ni, int k, int64_t n_levels, int want,
+int res_prepare(ResPlan **out, const int32_t *idx, const Rec *d_recs, int64_t nnz, int nu, int ni, int k, int64_t n_levels, int want,
                 bool headroom)
 {
     *out = nullptr;
@@ -377,6 +382,7 @@ int res_prepare(ResPlan **out, const int32_t *idx, const double *r, int64_t nnz,
     // ---- ticket: is the input grouped by user (every user one contiguous run)? ---------------------------
     bool grouped = true;
     int64_t n_runs_u = 0;
+    std::vector<int32_t> run_ent;                            // the users of the runs, in input order (= the ticket order)
     {
         std::vector<unsigned char> seen((size_t)nu, 0);
         int32_t prev = -1;
@@ -385,6 +391,7 @@ int res_prepare(ResPlan **out, const int32_t *idx, const double *r, int64_t nnz,
             if (u != prev) {
                 if (seen[(size_t)u]) { grouped = false; break; }
                 seen[(size_t)u] = 1;
+                run_ent.push_back(u);
                 ++n_runs_u;
                 prev = u;
             }
@@ -435,59 +442,35 @@ int res_prepare(ResPlan **out, const int32_t *idx, const double *r, int64_t nnz,
     rp->k = k; rp->nu = nu; rp->ni = ni; rp->nnz = nnz;
     rp->est_ms = kind == 1 ? e_ticket : e_static;
     auto bail = [&](int rc) { res_destroy(rp); return rc; };
-    try {
-        std::vector<URec> recs((size_t)nnz);
-        std::vector<int64_t> run_off;
-        std::vector<int32_t> run_ent;
+    {
+        const Sel sel = kind == 1 ? st : ss;
+        rp->kp = sel.kp; rp->nr = sel.nr;
         if (kind == 1) {
-            rp->res_item = false; rp->n_res = nu; rp->n_trav = ni;
-            rp->kp = st.kp; rp->nr = st.nr; rp->B = Bt;
-            std::vector<int32_t> ctr((size_t)ni, 0);
-            run_off.reserve((size_t)n_runs_u + 1); run_ent.reserve((size_t)n_runs_u);
-            int32_t prev = -1;
-            for (int64_t t = 0; t < nnz; ++t) {
-                const int32_t u = idx[2 * t], i = idx[2 * t + 1];
-                if (u != prev) { run_off.push_back(t); run_ent.push_back(u); prev = u; }
-                recs[(size_t)t] = URec{i, ctr[(size_t)i]++, r[t]};
-            }
-            run_off.push_back(nnz);
+            rp->res_item = false; rp->n_res = nu; rp->n_trav = ni; rp->B = Bt;
+            rp->n_runs = (int)run_ent.size();
             // enough waves to fill the chip at the kernel's residency; the grid size is free in this mode
             int occ_t = 0;
-            MFX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_t, st.fn, 64, lds_t));
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_t, st.fn, 64, lds_t) != hipSuccess) occ_t = 0;
             rp->waves = (occ_t > 0 ? occ_t : 8) * cus;
-            const int64_t tickets = ceil_div((int64_t)run_ent.size(), (int64_t)Bt);
+            const int64_t tickets = ceil_div((int64_t)rp->n_runs, (int64_t)Bt);
             if (rp->waves > tickets) rp->waves = (int)tickets;
-            rp->se_slots = (int64_t)run_ent.size();
+            rp->se_slots = (int64_t)rp->n_runs;
         } else {
-            rp->res_item = res_item; rp->n_res = n_res; rp->n_trav = n_trav;
-            rp->kp = ss.kp; rp->nr = ss.nr; rp->B = Bs; rp->waves = waves_s;
-            const int rc_ = res_item ? 1 : 0, tc_ = res_item ? 0 : 1;
-            std::vector<int64_t> cnt((size_t)n_res + 1, 0);
-            for (int64_t t = 0; t < nnz; ++t) ++cnt[(size_t)idx[2 * t + rc_] + 1];
-            for (int e = 0; e < n_res; ++e) cnt[(size_t)e + 1] += cnt[(size_t)e];
-            std::vector<int64_t> fill(cnt.begin(), cnt.end() - 1);
-            std::vector<int32_t> ctr((size_t)n_trav, 0);
-            for (int64_t t = 0; t < nnz; ++t) {
-                const int32_t tr = idx[2 * t + tc_];
-                recs[(size_t)fill[(size_t)idx[2 * t + rc_]]++] = URec{tr, ctr[(size_t)tr]++, r[t]};
-            }
-            run_off.assign(cnt.begin(), cnt.end());          // every entity is a run (possibly empty); run = entity id
-            run_ent.resize((size_t)n_res);
-            for (int e = 0; e < n_res; ++e) run_ent[(size_t)e] = e;
+            rp->res_item = res_item; rp->n_res = n_res; rp->n_trav = n_trav; rp->B = Bs; rp->waves = waves_s;
+            rp->n_runs = n_res;                              // every entity is a run (possibly empty); run = entity id
             rp->se_slots = (int64_t)rp->waves * rp->B;
         }
-        rp->n_runs = (int)run_ent.size();
-        if (ralloc(rp, &rp->d_recs, (size_t)nnz) || ralloc(rp, &rp->d_run_off, run_off.size()) || ralloc(rp, &rp->d_run_ent, run_ent.size()) ||
+        if (ralloc(rp, &rp->d_recs, (size_t)nnz) || ralloc(rp, &rp->d_lo, (size_t)rp->n_res) || ralloc(rp, &rp->d_hi, (size_t)rp->n_res) ||
+            (kind == 1 && ralloc(rp, &rp->d_run_ent, run_ent.size())) ||
             ralloc(rp, &rp->d_hdr, (size_t)rp->n_trav) || ralloc(rp, &rp->d_ctl, (size_t)kCtlWords) || ralloc(rp, &rp->d_se_run, (size_t)rp->se_slots))
             return bail(last_code());
-        if (hipMemcpy(rp->d_recs, recs.data(), (size_t)nnz * sizeof(URec), hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(rp->d_run_off, run_off.data(), run_off.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(rp->d_run_ent, run_ent.data(), run_ent.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        if ((kind == 1 && hipMemcpy(rp->d_run_ent, run_ent.data(), run_ent.size() * 4, hipMemcpyHostToDevice) != hipSuccess) ||
             hipMemset(rp->d_ctl, 0, kCtlWords * sizeof(unsigned)) != hipSuccess ||
             hipMemset(rp->d_se_run, 0, (size_t)(rp->se_slots ? rp->se_slots : 1) * sizeof(double)) != hipSuccess)
-            return bail(fail(MFX_E_HIP, "mfx_sgd_plan_create: upload of the resident-side records failed: %s", hipGetErrorString(hipGetLastError())));
-    } catch (const std::bad_alloc &) {
-        return bail(fail(MFX_E_NOMEM, "mfx_sgd_plan_create: out of host memory"));
+            return bail(fail(MFX_E_HIP, "mfx_sgd_plan_create: upload of the resident-side tables failed: %s", hipGetErrorString(hipGetLastError())));
+        // the records, grouped by resident entity and ranked in the travelling chains: built in HBM from the level-major records
+        int rc = res_build_device(d_recs, nnz, rp->n_res, rp->n_trav, rp->res_item, rp->d_recs, rp->d_lo, rp->d_hi);
+        if (rc) return bail(rc);
     }
     rp->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     *out = rp;
@@ -519,7 +502,7 @@ int res_enqueue_epoch(ResPlan *rp, int mode, double *U_nk, double *V_nk, double 
 {
     ResParams P;
     memset(&P, 0, sizeof(P));
-    P.recs = rp->d_recs; P.run_off = rp->d_run_off; P.run_ent = rp->d_run_ent;
+    P.recs = rp->d_recs; P.lo = rp->d_lo; P.hi = rp->d_hi; P.run_ent = rp->d_run_ent;
     P.Tm = rp->res_item ? V_nk : U_nk;
     P.Rm = rp->res_item ? U_nk : V_nk;
     double *tb = rp->res_item ? ub : ib;

@@ -397,6 +397,45 @@ __global__ void k_res_pack(const int32_t *__restrict__ ks, const int32_t *__rest
 }
 }  // namespace
 
+namespace {
+__global__ void k_deg_count(const Rec *__restrict__ recs, int64_t nnz, int *cu, int *ci)
+{
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < nnz; p += (int64_t)gridDim.x * blockDim.x) {
+        const Rec q = recs[p];
+        atomicAdd(cu + q.user, 1);
+        atomicAdd(ci + q.item, 1);
+    }
+}
+__global__ void k_deg_max(const int *__restrict__ c, int n, int *out)
+{
+    int m = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = c[i] > m ? c[i] : m;
+    atomicMax(out, m);
+}
+}  // namespace
+
+// largest user / item degree (how skewed the data is: the resident-side epoch's cost model)
+int res_max_degrees(const Rec *d_recs, int64_t nnz, int nu, int ni, int *max_user_deg, int *max_item_deg)
+{
+    hipStream_t st = stream();
+    Scratch S;
+    int *cu, *ci, *mx;
+    if (S.get(&cu, (size_t)nu) || S.get(&ci, (size_t)ni) || S.get(&mx, 2)) return last_code();
+    MFX_HIP(hipMemsetAsync(cu, 0, (size_t)nu * sizeof(int), st));
+    MFX_HIP(hipMemsetAsync(ci, 0, (size_t)ni * sizeof(int), st));
+    MFX_HIP(hipMemsetAsync(mx, 0, 2 * sizeof(int), st));
+    const int blocks = (int)std::min<int64_t>(ceil_div<int64_t>(nnz, 256), 8192);
+    k_deg_count<<<blocks, 256, 0, st>>>(d_recs, nnz, cu, ci);
+    k_deg_max<<<256, 256, 0, st>>>(cu, nu, mx);
+    k_deg_max<<<256, 256, 0, st>>>(ci, ni, mx + 1);
+    int h[2] = {0, 0};
+    MFX_HIP(hipMemcpyAsync(h, mx, sizeof h, hipMemcpyDeviceToHost, st));
+    MFX_HIP(hipStreamSynchronize(st));
+    *max_user_deg = h[0];
+    *max_item_deg = h[1];
+    return MFX_OK;
+}
+
 int res_build_device(const Rec *d_recs, int64_t nnz, int n_res, int n_trav, bool res_item, ResRec *d_out, int32_t *d_lo, int32_t *d_hi)
 {
     if (nnz <= 0 || nnz >= ((int64_t)1 << 31) - 1) return fail(MFX_E_ARG, "res_build_device: unsupported size");

@@ -50,6 +50,7 @@ int res_prepare(ResPlan **out, const int32_t *idx, const Rec *d_recs, int64_t nn
                 bool headroom);
 // mfx_schedule_dev.hip: records grouped by resident entity (stable: each entity's list is its chain), every rating ranked in its
 // travelling entity's chain; lo / hi [n_res]: the entity's record range (0, 0 when it has none)
+int res_max_degrees(const Rec *d_recs, int64_t nnz, int nu, int ni, int *max_user_deg, int *max_item_deg);
 int res_build_device(const Rec *d_recs, int64_t nnz, int n_res, int n_trav, bool res_item, ResRec *d_out, int32_t *d_lo, int32_t *d_hi);
 void res_destroy(ResPlan *rp);
 int res_kind(const ResPlan *rp);                 // 0 none, 1 ticket (users resident, runs by ticket), 2 static owners

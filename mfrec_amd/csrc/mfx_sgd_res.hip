@@ -148,9 +148,151 @@ __device__ __forceinline__ void res_step(const ResParams &P, unsigned long long 
     }
 }
 
+__device__ __forceinline__ double readlane64(double x, int l)          // l wave-uniform
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), l), hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+    return __hiloint2double(hi, lo);
+}
+
+// BURST (static binding, skewed data): a resident entity with a long run ahead -- the hot item of a power-law catalogue:
+// its ratings come from different, mostly idle travelling entities -- walks up to eight of its ratings in ONE step.  The
+// three memory round trips of a step (granule polls, row loads, store acknowledge) are paid once for the eight; the
+// arithmetic stays one rating after the other on the resident row in registers (same operations, same order: same bits).
+// Lane i < 8 holds rating i's record, granule and new travelling bias; slot s's own lanes hold the rows.
+// Returns the number of ratings applied (0: nothing was ready after all -- the caller takes the ordinary step).
+template <int KP, int NR, int MODE>
+__device__ __forceinline__ int res_burst(const ResParams &P, int s, int &pos, int end, const URec *rp, URec &rec, URec &nxt, THdr &h,
+                                         double &rbv, double &se, d2 (&vv)[NR], double *prod, __amdgpu_buffer_rsrc_t rT,
+                                         __amdgpu_buffer_rsrc_t rH, int lane, int g, int q)
+{
+    constexpr int SPW = 64 / KP, D = 8, stride = 2 * KP + 2;
+    const int k = P.k;
+    const unsigned qoff = (unsigned)q * 16u, rowb = (unsigned)(k * 8);
+    int pos_s = __builtin_amdgcn_readlane(pos, s);
+    const int end_s = __builtin_amdgcn_readlane(end, s);
+    const unsigned long long rpb = (unsigned long long)(uintptr_t)rp;
+    const URec *rp_s = (const URec *)(uintptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(rpb >> 32), s) << 32) |
+                                                 (unsigned)__builtin_amdgcn_readlane((int)rpb, s));
+    const int js = s / SPW, gs = s % SPW;
+    const bool ing = (2 * q < k) && g == gs;                 // the lanes that hold slot s's rows
+    double *ubuf = prod + NR * SPW * stride;                 // [D][2 KP]: the travelling rows of a window, behind the product tile
+    d2 cur = d2{0.0, 0.0};                                    // slot s's resident row: out of its register set, back at the end
+#pragma unroll
+    for (int j = 0; j < NR; ++j)
+        if (j == js) cur = vv[j];
+    int nd = end_s - pos_s < D ? end_s - pos_s : D;
+    URec br{0, -2, 0.0};
+    THdr bh; bh.bias = 0.0; bh.cnt = -1; bh.pad = 0;
+    if (lane < nd) {
+        br = __builtin_bit_cast(URec, __builtin_nontemporal_load(reinterpret_cast<const v4i *>(rp_s + pos_s + lane)));
+        bh = __builtin_bit_cast(THdr, ld16c(rH, (unsigned)br.trav * 16u));
+    }
+    int total = 0;
+    for (int w = 0; w < 8 && nd > 0; ++w) {                   // (bounded: the wave's other slots get their turn again)
+        const unsigned long long okm = __ballot(lane < nd && bh.cnt == br.seq);
+        const int depth = __builtin_ctzll(~okm);               // leading ready ratings of the window
+        if (depth == 0) break;
+        // the travelling rows of the window: one block of loads, parked in LDS so that the walk below is ONE loop body with a
+        // run-time rating index (registers cannot be indexed at run time)
+        {
+            d2 uu[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                uu[i] = d2{0.0, 0.0};
+                if (i < depth) {                              // uniform
+                    const unsigned o = (unsigned)__builtin_amdgcn_readlane(br.trav, i) * rowb + qoff;
+                    if (ing) uu[i] = __builtin_bit_cast(d2, ld16c(rT, o));
+                }
+            }
+            // the NEXT window's records travel under this window's walk
+            const int pos_n = pos_s + depth, nd_n = end_s - pos_n < D ? end_s - pos_n : D;
+            URec brn{0, -2, 0.0};
+            if (lane < nd_n) brn = __builtin_bit_cast(URec, __builtin_nontemporal_load(reinterpret_cast<const v4i *>(rp_s + pos_n + lane)));
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+                if (i < depth && ing) *reinterpret_cast<d2 *>(ubuf + i * 2 * KP + 2 * q) = uu[i];
+            double tbn = 0.0;
+            for (int i = 0; i < depth; ++i) {
+                d2 ui = d2{0.0, 0.0};
+                if (ing) {
+                    ui = *reinterpret_cast<const d2 *>(ubuf + i * 2 * KP + 2 * q);
+                    *reinterpret_cast<d2 *>(prod + s * stride + 2 * q) = d2{ui.x * cur.x, ui.y * cur.y};
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const double tbv = readlane64(bh.bias, i), rr = readlane64(br.r, i);
+                double grad = 0.0;
+                if (lane == s) {
+                    double sum = P.res_item ? (0.0 + rbv + tbv) : (0.0 + tbv + rbv);      // kmf_train.pyx:92
+                    const double *row = prod + s * stride;
+                    int f = 0;
+                    for (; f + 8 <= k; f += 8) {
+                        const d2 a = *reinterpret_cast<const d2 *>(row + f), b = *reinterpret_cast<const d2 *>(row + f + 2);
+                        const d2 c = *reinterpret_cast<const d2 *>(row + f + 4), d = *reinterpret_cast<const d2 *>(row + f + 6);
+                        sum += a.x; sum += a.y; sum += b.x; sum += b.y; sum += c.x; sum += c.y; sum += d.x; sum += d.y;
+                    }
+                    for (; f < k; ++f) sum += row[f];
+                    double err;
+                    if constexpr (MODE == 0) {
+                        err = rr - sum;
+                        grad = err;
+                    } else {
+                        const double sig = 1.0 / (1.0 + exp(-sum));
+                        const double pp = 1.0 + sig * 4.0;
+                        err = rr - pp;
+                        grad = err * sig * (1.0 - sig) * 4.0;
+                    }
+                    se += err * err;
+                    rbv = rbv + P.lr * (grad - P.Kb * rbv);
+                }
+                __builtin_amdgcn_wave_barrier();
+                const double gr = readlane64(grad, s);
+                if (lane == i) tbn = tbv + P.lr * (gr - P.Kb * tbv);
+                const unsigned o = (unsigned)__builtin_amdgcn_readlane(br.trav, i) * rowb + qoff;
+                if (ing) {
+                    d2 un, vn;
+                    un.x = ui.x + P.lr * (gr * cur.x - P.Ktrav * ui.x);
+                    un.y = ui.y + P.lr * (gr * cur.y - P.Ktrav * ui.y);
+                    vn.x = cur.x + P.lr * (gr * ui.x - P.Kres * cur.x);
+                    vn.y = cur.y + P.lr * (gr * ui.y - P.Kres * cur.y);
+                    st16c(__builtin_bit_cast(v4u, un), rT, o);
+                    cur = vn;
+                }
+            }
+            // the next window's granule polls go out BEFORE the acknowledge wait: loads return in issue order behind the
+            // stores, so one round trip serves both (a rating whose entity is also in THIS window polls stale and ends the burst)
+            THdr bhn; bhn.bias = 0.0; bhn.cnt = -1; bhn.pad = 0;
+            if (lane < nd_n) bhn = __builtin_bit_cast(THdr, ld16c(rH, (unsigned)brn.trav * 16u));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every row store acknowledged, then the granules
+            if (lane < depth) {
+                THdr nh; nh.bias = tbn; nh.cnt = br.seq + 1; nh.pad = 0;
+                st16c(__builtin_bit_cast(v4u, nh), rH, (unsigned)br.trav * 16u);
+            }
+            total += depth;
+            pos_s = pos_n;
+            br = brn; bh = bhn; nd = nd_n;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NR; ++j)
+        if (j == js && ing) vv[j] = cur;
+    if (total == 0) return 0;
+    if (lane == s) {                                          // slot s moves on
+        pos += total;
+        h.cnt = -1;
+        if (pos < end) {
+            rec = __builtin_bit_cast(URec, __builtin_nontemporal_load(reinterpret_cast<const v4i *>(rp + pos)));
+            h = __builtin_bit_cast(THdr, ld16c(rH, (unsigned)rec.trav * 16u));
+        }
+        if (pos + 1 < end) nxt = __builtin_bit_cast(URec, __builtin_nontemporal_load(reinterpret_cast<const v4i *>(rp + pos + 1)));
+    }
+    return total;
+}
+
 // KP lanes per row (16 bytes = one feature pair per lane: k <= 2 KP), NR register sets per lane, B = NR * 64/KP slots
-template <int KP, int NR, int MODE, bool STATIC>
-__global__ __launch_bounds__(64, STATIC ? (NR <= 9 ? 3 : 2) : 4) void k1_res(ResParams P)
+template <int KP, int NR, int MODE, bool STATIC, bool BURST = false>
+__global__ __launch_bounds__(64, STATIC ? ((NR <= 9 && !BURST) ? 3 : 2) : 4) void k1_res(ResParams P)
 {
     constexpr int SPW = 64 / KP, B = NR * SPW;
     extern __shared__ __attribute__((aligned(16))) double prod[];       // [B][stride]
@@ -237,6 +379,19 @@ __global__ __launch_bounds__(64, STATIC ? (NR <= 9 ? 3 : 2) : 4) void k1_res(Res
                 if (act) h = __builtin_bit_cast(THdr, ld16c(rH, (unsigned)rec.trav * 16u));
                 continue;
             }
+            if constexpr (BURST) {
+                // at most two slots can move and one of them has a run ahead: walk up to eight of ITS ratings in this step
+                if (__popcll(mask) <= 2) {
+                    const unsigned long long cm = __ballot(ready && end - pos >= 3);
+                    if (cm) {
+                        const int s = __builtin_amdgcn_readfirstlane(__builtin_ctzll(cm));
+                        if (res_burst<KP, NR, MODE>(P, s, pos, end, rp, rec, nxt, h, rbv, se, vv, prod, rT, rH, lane, g, q) > 0) {
+                            spins = 0;
+                            continue;
+                        }
+                    }
+                }
+            }
             double tbn = 0.0;
             if (!STATIC && mask == ALL) res_step<KP, NR, MODE, true>(P, mask, ready, rec, h.bias, rbv, se, vv, prod, rT, lane, g, q, tbn);
             else res_step<KP, NR, MODE, false>(P, mask, ready, rec, h.bias, rbv, se, vv, prod, rT, lane, g, q, tbn);
@@ -285,20 +440,23 @@ int env_i(const char *name, int dflt)
 }
 
 struct Sel { void *fn; int kp, nr; };
+// product tile [B][2 KP + 2]; the burst variant (nr = 13) parks eight travelling rows behind it
+size_t res_lds_bytes(int kp, int nr) { return ((size_t)nr * (64 / kp) * (2 * kp + 2) + (nr == 13 ? 8 * 2 * kp : 0)) * 8; }
 
 // ticket: 4 register sets (4 waves per SIMD); static: 9 sets at 3 waves per SIMD (18 slots x 3 072 waves at k = 64: measured 3 %
 // faster than 26 x 2 048 and 5 % faster than 32 x 2 048 on cfg 2) or 16 sets at 2 waves per SIMD (the largest side that fits)
-template <int MODE, int NR, bool STATIC>
+template <int MODE, int NR, bool STATIC, bool BURST = false>
 Sel pick(int k)
 {
-    if (k <= 32) return {(void *)k1_res<16, NR, MODE, STATIC>, 16, NR};
-    if (k <= 64) return {(void *)k1_res<32, NR, MODE, STATIC>, 32, NR};
-    return {(void *)k1_res<64, NR, MODE, STATIC>, 64, NR};
+    if (k <= 32) return {(void *)k1_res<16, NR, MODE, STATIC, BURST>, 16, NR};
+    if (k <= 64) return {(void *)k1_res<32, NR, MODE, STATIC, BURST>, 32, NR};
+    return {(void *)k1_res<64, NR, MODE, STATIC, BURST>, 64, NR};
 }
-Sel select(int k, int mode, int nr)        // nr: 4 = ticket, 9 / 16 = static
+// nr: 4 = ticket; 9 / 16 = static; 13 = static with bursts (skewed data: 2 waves per SIMD, 26 slots x 2 048 waves at k = 64)
+Sel select(int k, int mode, int nr)
 {
-    if (mode == 0) return nr == 4 ? pick<0, 4, false>(k) : (nr == 9 ? pick<0, 9, true>(k) : pick<0, 16, true>(k));
-    return nr == 4 ? pick<1, 4, false>(k) : (nr == 9 ? pick<1, 9, true>(k) : pick<1, 16, true>(k));
+    if (mode == 0) return nr == 4 ? pick<0, 4, false>(k) : (nr == 9 ? pick<0, 9, true>(k) : (nr == 13 ? pick<0, 13, true, true>(k) : pick<0, 16, true>(k)));
+    return nr == 4 ? pick<1, 4, false>(k) : (nr == 9 ? pick<1, 9, true>(k) : (nr == 13 ? pick<1, 13, true, true>(k) : pick<1, 16, true>(k)));
 }
 
 }  // namespace
@@ -344,7 +502,8 @@ int ralloc(ResPlan *rp, T **ptr, size_t n)
 // Cost model (measured, DESIGN.md section 4 "K1 resident"): a chain of `levels` dependent steps of ~4.1 us
 // against a stream of nnz ratings at the coherent path's rate; the level schedule costs ~3.7 us per level
 // plus 20 line operations per rating at ~67 G lines/s.
-static double est_level_ms(int64_t nnz, int64_t levels) { return levels * 3.7e-3 + nnz * 0.30e-6; }
+// (levels too small for a launch of their own run in the tail kernel: 2.47 us each)
+static double est_level_ms(int64_t nnz, int64_t levels) { return levels * (nnz / levels >= 128 ? 3.7e-3 : 2.47e-3) + nnz * 0.30e-6; }
 static double est_res_ms(int64_t nnz, int64_t levels, bool stat)
 {
     const double chain = levels * (stat ? 4.6e-3 : 4.15e-3), stream = nnz * (stat ? 0.30e-6 : 0.265e-6);
@@ -410,7 +569,7 @@ int res_prepare(ResPlan **out, const int32_t *idx, const Rec *d_recs, int64_t nn
         ss = select(k, 0, nr);
         Bs = ss.nr * (64 / ss.kp);
         int occ = 0;
-        MFX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ss.fn, 64, (size_t)Bs * (2 * ss.kp + 2) * 8));
+        MFX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ss.fn, 64, res_lds_bytes(ss.kp, ss.nr)));
         waves_s = occ * cus;
         if (headroom) {                                      // leave an eighth of the slots to whatever runs beside the launch
             const int64_t need = ceil_div((int64_t)n_res, (int64_t)Bs), spare = (int64_t)waves_s * 7 / 8;
@@ -421,10 +580,41 @@ int res_prepare(ResPlan **out, const int32_t *idx, const Rec *d_recs, int64_t nn
     const bool static_ok = waves_s > 0 && (int64_t)waves_s * Bs >= n_res && (int64_t)n_trav * k * 8 < ((int64_t)1 << 31);
     const double e_level = est_level_ms(nnz, n_levels);
     const double e_ticket = ticket_ok ? est_res_ms(nnz, n_levels, false) : 1e30;
-    const double e_static = static_ok ? est_res_ms(nnz, n_levels, true) : 1e30;
+    double e_static = static_ok ? est_res_ms(nnz, n_levels, true) : 1e30;
+    // ---- skewed data: the chain is a hot entity's own run.  When that entity is on the resident side, the burst variant walks it
+    //      eight ratings per step (measured ~0.7 us per rating against 2.1 without, 2.47 per level in the tail kernel); a hot
+    //      TRAVELLING entity hops from wave to wave at the full step.  MFX_K1_BURST = 0 / 1: off / forced (tuning, tests).
+    bool burst = false;
+    {
+        const int benv = env_i("MFX_K1_BURST", -1);
+        const double avg = (double)nnz / (double)(nu < ni ? nu : ni);
+        if (benv != 0 && (benv == 1 || (double)n_levels > 16.0 * avg)) {
+            const Sel sb = select(k, 0, 13);
+            const int Bb = sb.nr * (64 / sb.kp);
+            int occ = 0;
+            MFX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sb.fn, 64, res_lds_bytes(sb.kp, sb.nr)));
+            int wb = occ * cus;
+            if (headroom && ceil_div((int64_t)n_res, (int64_t)Bb) <= (int64_t)wb * 7 / 8) wb = wb * 7 / 8;
+            if (wb > 0 && (int64_t)wb * Bb >= n_res && (int64_t)n_trav * k * 8 < ((int64_t)1 << 31)) {
+                int mu = 0, mi = 0;
+                int rc = res_max_degrees(d_recs, nnz, nu, ni, &mu, &mi);
+                if (rc) return rc;
+                const int max_res = res_item ? mi : mu, max_trav = res_item ? mu : mi;
+                const double stream = nnz * 0.30e-6;
+                double e = max_res * 0.9e-3 > max_trav * 4.6e-3 ? max_res * 0.9e-3 : max_trav * 4.6e-3;
+                e = e > stream ? e : stream;
+                if (benv == 1 || (2 * (int64_t)max_res >= n_levels && e < e_static)) {
+                    burst = true;
+                    e_static = e;
+                    ss = sb; Bs = Bb; waves_s = wb;
+                }
+            }
+        }
+    }
+    const bool static_ok2 = static_ok || burst;
     int kind = 0;
     if (want == MFX_EPOCH_TICKET) kind = ticket_ok ? 1 : 0;
-    else if (want == MFX_EPOCH_STATIC) kind = static_ok ? 2 : 0;
+    else if (want == MFX_EPOCH_STATIC) kind = static_ok2 ? 2 : 0;
     else if (e_ticket <= e_static && e_ticket < 0.9 * e_level) kind = 1;
     else if (e_static < e_ticket && e_static < 0.9 * e_level) kind = 2;
     if (!kind) {
@@ -485,7 +675,7 @@ int res_describe(const ResPlan *rp, int mode, char *buf, int buflen)
 {
     static const char *const mode_name[] = {"linear", "logistic"};
     snprintf(buf, (size_t)buflen, "k1_res<%d lanes/row,%d slots,%s,%s: %s rows resident,%d waves>", rp->kp, rp->B,
-             mode_name[mode & 1], rp->kind == 1 ? "ticket" : "static", rp->res_item ? "item" : "user", rp->waves);
+             mode_name[mode & 1], rp->kind == 1 ? "ticket" : (rp->nr == 13 ? "static+bursts" : "static"), rp->res_item ? "item" : "user", rp->waves);
     return MFX_OK;
 }
 
@@ -515,7 +705,7 @@ int res_enqueue_epoch(ResPlan *rp, int mode, double *U_nk, double *V_nk, double 
     MFX_HIP(hipMemsetAsync(rp->d_ctl + kCtlReg, 0, sizeof(unsigned), stream()));                // registration
     hipLaunchKernelGGL(k_hdr_reset, dim3(ceil_div(rp->n_trav, 256)), dim3(256), 0, stream(), rp->d_hdr, (const double *)tb, rp->n_trav);
     void *args[] = {&P};
-    MFX_HIP(hipLaunchKernel(s.fn, dim3(rp->waves), dim3(64), args, (size_t)rp->B * (2 * rp->kp + 2) * 8, stream()));
+    MFX_HIP(hipLaunchKernel(s.fn, dim3(rp->waves), dim3(64), args, res_lds_bytes(rp->kp, rp->nr), stream()));
     hipLaunchKernelGGL(k_hdr_finish, dim3(ceil_div(rp->n_trav, 256)), dim3(256), 0, stream(), (const THdr *)rp->d_hdr, tb, rp->n_trav);
     MFX_HIP(hipGetLastError());
     return MFX_OK;

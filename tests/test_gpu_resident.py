@@ -164,3 +164,39 @@ def test_gated_and_narrow_runs_take_the_level_schedule():
     O.train_linear_kernel(1, k, 0.1, LR, 0, 0, KU, KI, KB, 0.0, u2, v2, idx, r, ib2, ub2, 1, 0)
     O.train_linear_kernel(1, k, 0.1, LR, 0, 0, KU, KI, KB, 0.0, u2, v2, idx, r, ib2, ub2)
     _check((u, v, ib, ub), (u2, v2, ib2, ub2), LINEAR)
+
+
+def _zipf(nu, ni, nnz, seed, a_users, a_items):
+    rs = np.random.RandomState(seed)
+    pu, pi = 1.0 / np.arange(1, nu + 1) ** a_users, 1.0 / np.arange(1, ni + 1) ** a_items
+    idx = np.stack([rs.choice(nu, nnz, p=pu / pu.sum()), rs.choice(ni, nnz, p=pi / pi.sum())], 1).astype(np.int32)
+    return np.ascontiguousarray(idx), rs.randint(1, 6, nnz).astype(np.float64)
+
+
+@pytest.mark.parametrize("shape,k", [((3000, 2000), 64), ((2000, 3000), 64), ((3000, 2000), 24), ((2500, 1500), 128)])
+@pytest.mark.parametrize("mode", [LINEAR, LOGISTIC])
+def test_power_law_data_through_the_burst_variant(shape, k, mode, monkeypatch):
+    """Skewed degrees (both sides): the static binding's burst variant walks a hot resident entity's run eight ratings per
+    step -- duplicates of a pair inside a window, runs shorter than a window and windows that stop at a rating that is not
+    ready yet included -- and must still give the sequential loop's bits."""
+    monkeypatch.setenv("MFX_K1_BURST", "1")
+    nu, ni = shape
+    idx, r = _zipf(nu, ni, 60000, 3, 0.8, 1.1)
+    u0, v0 = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
+    u, v, ib, ub, rm, info, _, name = _run_plan(idx, r, nu, ni, k, u0, v0, 2, mode, "static")
+    assert info["epoch_kernel"] == "static" and "bursts" in name, name
+    _check((u, v, ib, ub), _oracle(idx, r, nu, ni, k, u0, v0, 2, mode), mode)
+    monkeypatch.setenv("MFX_K1_BURST", "0")
+    rm0 = _run_plan(idx, r, nu, ni, k, u0, v0, 2, mode, "static")[4]
+    np.testing.assert_allclose(rm, rm0, rtol=1e-12)
+
+
+def test_skew_is_detected_and_served_by_the_burst_variant():
+    """AUTO on a catalogue with one very hot item: the cost model finds the chain on the resident side and picks the burst variant."""
+    nu, ni, nnz, k = 20000, 8000, 1500000, 64
+    idx, r = _zipf(nu, ni, nnz, 5, 0.0, 1.0)
+    u0, v0 = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
+    got = _run_plan(idx, r, nu, ni, k, u0, v0, 1, LINEAR, "auto")
+    assert got[5]["epoch_kernel"] == "static" and "bursts" in got[7], (got[5], got[7])
+    lev = _run_plan(idx, r, nu, ni, k, u0, v0, 1, LINEAR, "levels")
+    _check(got[:4], lev[:4], LINEAR)

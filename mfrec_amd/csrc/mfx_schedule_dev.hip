@@ -436,7 +436,8 @@ int res_max_degrees(const Rec *d_recs, int64_t nnz, int nu, int ni, int *max_use
     return MFX_OK;
 }
 
-int res_build_device(const Rec *d_recs, int64_t nnz, int n_res, int n_trav, bool res_item, ResRec *d_out, int32_t *d_lo, int32_t *d_hi)
+int res_build_device(const Rec *d_recs, int64_t nnz, int n_res, int n_trav, bool res_item, ResRec *d_out, int32_t *d_lo, int32_t *d_hi,
+                     int32_t *d_pos_of, int32_t *d_ent_of)
 {
     if (nnz <= 0 || nnz >= ((int64_t)1 << 31) - 1) return fail(MFX_E_ARG, "res_build_device: unsupported size");
     hipStream_t st = stream();
@@ -459,6 +460,9 @@ int res_build_device(const Rec *d_recs, int64_t nnz, int n_res, int n_trav, bool
     MFX_HIP(hipMemsetAsync(d_lo, 0, (size_t)n_res * sizeof(int32_t), st));
     MFX_HIP(hipMemsetAsync(d_hi, 0, (size_t)n_res * sizeof(int32_t), st));
     k_res_pack<<<blocks, 256, 0, st>>>(ks, ps, nnz, d_recs, ktrav, seq, d_out, d_lo, d_hi);
+    // (position of every grouped record in the level-major array: the Funk pass keeps its residual cache in grouped order)
+    if (d_pos_of) MFX_HIP(hipMemcpyAsync(d_pos_of, ps, n * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    if (d_ent_of) MFX_HIP(hipMemcpyAsync(d_ent_of, ks, n * sizeof(int32_t), hipMemcpyDeviceToDevice, st));     // resident entity of every grouped record
     MFX_HIP(hipGetLastError());
     MFX_HIP(hipStreamSynchronize(st));
     return MFX_OK;

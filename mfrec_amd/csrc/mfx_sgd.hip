@@ -81,6 +81,9 @@ struct mfx_sgd_plan {
     // resident-side epoch (mfx_sgd_res.hip): prepared at creation when its cost model beats the level schedule
     mfx::ResPlan *res = nullptr;
     int res_state = 0;                   // 1 = ready, -1 = registration failed once: stay on the level schedule
+    // resident-side Funk pass (lane = item, user values inside their granules): 0 = not decided, 1 = ready, -1 = no
+    mfx::Res2Plan *res2 = nullptr;
+    int k2r_state = 0;
 };
 
 namespace {
@@ -814,6 +817,7 @@ void mfx_sgd_plan_destroy(mfx_sgd_plan *p)
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     res_destroy(p->res);
+    res2_destroy(p->res2);
     delete p;
 }
 
@@ -857,7 +861,8 @@ int mfx_sgd_plan_kernel_name(const mfx_sgd_plan *p, int mode, char *buf, int buf
 {
     if (!p || !buf || buflen < 1 || mode < 0 || mode > 3) return fail(MFX_E_ARG, "mfx_sgd_plan_kernel_name: bad argument");
     if (mode == 3) {                      // the Funk pass: known once a Funk run has decided
-        if (p->k2x_state == 1) snprintf(buf, (size_t)buflen, "k2_xcd_pass<%d worker waves,%d user groups>", kXWorkers, kXGroups);
+        if (p->k2r_state == 1) snprintf(buf, (size_t)buflen, "k2_res<lane = item, user values in 16-byte granules, %d waves>", (p->ni + 63) / 64);
+        else if (p->k2x_state == 1) snprintf(buf, (size_t)buflen, "k2_xcd_pass<%d worker waves,%d user groups>", kXWorkers, kXGroups);
         else snprintf(buf, (size_t)buflen, "k2_level<%d threads>%s", kK2Block, p->k2x_state == 0 ? " (undecided: no Funk run yet)" : "");
         return MFX_OK;
     }
@@ -1071,14 +1076,31 @@ int funk_core(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_
         if (!rc) rc = dev_alloc(p, &p->d_k2dyn, 1);
         if (rc) return rc;
     }
+    // Which kernel runs a pass, decided once per plan: the resident-side pass (mfx_sgd_res.hip: every CU, a hop = one granule
+    // round trip) where every item gets a resident lane; else the single-XCD persistent pass (large levels); else one launch
+    // per level.  Both persistent forms check their residency first and leave everything untouched when it fails.
+    if (p->k2r_state == 0 && !hk) {
+        p->k2r_state = -1;
+        const int want = env_int("MFX_K2_RES", -1);          // 0 = off, 1 = forced (also tiny problems), default: by size
+        // measured at cfg 2: levels of ~16 K ratings (shuffled order) 1.25 ms per pass here against 1.35 on the
+        // single-XCD pass; levels of ~37 K (balanced order) 1.08 against 1.04 -- fat levels stay with the XCD pass where it applies
+        const bool fat = p->n_levels > 0 && p->nnz / p->n_levels >= 24576 && env_int("MFX_K2_XCD", -1) != 0 &&
+                         ceil_div((int64_t)p->nu, (int64_t)kXGroups) + 1 <= (150 * 1024) / 8;
+        if (want == 1 || (want != 0 && !fat)) {
+            if (res2_prepare(&p->res2, p->d_recs, p->nnz, p->nu, p->ni, want == 1) != MFX_OK) (void)hipGetLastError();
+            if (p->res2) { p->k2r_state = 1; p->dev_bytes += res2_dev_bytes(p->res2); }
+        }
+    }
+    bool k2r = !hk && p->k2r_state == 1;
     // may re-order the ratings inside their levels: before the cache is used.  The XCD-resident pass is an optional
     // acceleration: if its preparation fails (scratch memory, attribute), the records are either untouched or fully
     // re-ordered inside their levels -- both are valid inputs of the launch path -- so the run goes on there
-    if (ensure_k2x(p) != MFX_OK) {
+    if (!k2r && ensure_k2x(p) != MFX_OK) {
         (void)hipGetLastError();
         p->k2x_state = -1;
     }
     MFX_HIP(hipMemsetAsync(p->d_cache, 0, (size_t)(p->nnz ? p->nnz : 1) * sizeof(double), stream()));
+    if (k2r && (rc = res2_reset_cache(p->res2))) return rc;
     double rmse = 2.0, rmse_last = 0.0;
     int64_t nh = 0;
     K2Params P;
@@ -1099,7 +1121,7 @@ int funk_core(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_
     // one epoch = all levels + the SE reduction, captured once and replayed for every
     // (feature, epoch): the per-feature pointers live behind P.dyn
     const bool graph = use_graph() && p->segs2.size() <= kMaxGraphNodes;
-    if (graph && !(p->graph2 && memcmp(&p->graph2_params, &P, sizeof(P)) == 0)) {
+    if (graph && !k2r && !(p->graph2 && memcmp(&p->graph2_params, &P, sizeof(P)) == 0)) {
         if (p->graph2) (void)hipGraphExecDestroy(p->graph2);
         p->graph2 = nullptr;
         hipGraph_t g = nullptr;
@@ -1140,13 +1162,35 @@ int funk_core(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_
             double se_b[32];
             double nn = (double)p->nnz;
             for (;;) {
+                if (k2r) {
+                    // ---- resident-side pass: granules, one persistent launch over every CU, values back, reduction ----
+                    MFX_HIP(hipMemsetAsync(p->d_counter, 0, sizeof(int), stream()));
+                    if ((rc = res2_begin_batch(p->res2))) return rc;
+                    for (int b = 0; b < batch; ++b) {
+                        if ((rc = res2_enqueue_pass(p->res2, p->d_k2dyn, P.ib, P.ub, P.mu, P.lr, P.K, P.upd_u, P.upd_i))) return rc;
+                        if ((rc = enqueue_reduce(p, res2_se_slots(p->res2), res2_se_partials(p->res2)))) return rc;
+                    }
+                    MFX_HIP(hipMemcpyAsync(se_b, p->d_se_epoch, (size_t)batch * sizeof(double), hipMemcpyDeviceToHost, stream()));
+                    MFX_HIP(hipStreamSynchronize(stream()));
+                    unsigned status = 0;
+                    if ((rc = res2_status(p->res2, &status))) return rc;
+                    if (status == 0) break;
+                    if (status != 1) return fail(MFX_E_HIP, "mfx_sgd_run_funk: the resident-side pass timed out waiting for a granule");
+                    // its grid was not co-resident: NOTHING of this batch was applied.  The residual cache moves to the
+                    // level-major layout and the run goes on, for good, with one launch per level.
+                    if ((rc = res2_cache_to_levels(p->res2, p->d_cache))) return rc;
+                    p->k2r_state = -1;
+                    k2r = false;
+                    if (p->k2x_state == 0) p->k2x_state = -1;       // (its preparation would re-order records the cache now follows)
+                    continue;
+                }
                 const bool xcd = p->k2x_state == 1;
                 MFX_HIP(hipMemsetAsync(p->d_counter, 0, sizeof(int), stream()));
                 if (xcd) MFX_HIP(hipMemsetAsync(p->d_xctl + 512, 0, sizeof(unsigned), stream()));   // status: sticky inside a batch
                 for (int b = 0; b < batch; ++b) {
                     if (hk && (rc = hk->pre(hk->ctx, dyn.uf, p->ni))) return rc;
                     if (xcd) rc = enqueue_k2x_pass(p, P);
-                    else if (graph) {
+                    else if (graph && p->graph2) {
                         MFX_HIP(hipGraphLaunch(p->graph2, stream()));
                         rc = MFX_OK;
                     } else rc = enqueue_k2_epoch(p, P);
@@ -1181,8 +1225,12 @@ int funk_core(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_
                 ++epoch;
             }
         }
-        hipLaunchKernelGGL(k2_commit, dim3(commit_blocks), dim3(256), 0, stream(), P, p->nnz);
-        MFX_HIP(hipGetLastError());
+        if (k2r) {
+            if ((rc = res2_enqueue_commit(p->res2, p->d_k2dyn, P.ib, P.ub, P.mu))) return rc;
+        } else {
+            hipLaunchKernelGGL(k2_commit, dim3(commit_blocks), dim3(256), 0, stream(), P, p->nnz);
+            MFX_HIP(hipGetLastError());
+        }
     }
     MFX_HIP(hipStreamSynchronize(stream()));
     if (n_hist) *n_hist = nh;

@@ -719,4 +719,259 @@ int res_status(ResPlan *rp, unsigned *status)
     return MFX_OK;
 }
 
+// ================================================================================================
+// Funk per-feature pass (estimator_loop_without_bias / _with_bias / _with_bias_dev, gd_estimator.pyx:691-779, :489-582,
+// :588-685) in the same resident-side form, scalar edition.  ONE LANE owns one item: U[f,item] lives in a register, the
+// lane walks the item's ratings in input order.  The user side travels, and because its payload is ONE scalar it fits the
+// hand-off granule itself -- {V[f,user], chain counter} in 16 bytes: the poll RETURNS the value (no separate load), the
+// publish is ONE 16-byte sc1 store that carries value and counter together (nothing to drain first).  A hop costs one
+// granule round trip (~1.9 us under load) instead of a level hand-off, and the pass runs on every CU of the chip.
+// Static owners: needs every lane resident (registration barrier as above; ni <= waves x 64).
+// ================================================================================================
+struct Res2Params {
+    const URec *recs;           // grouped by item (stable); trav = user
+    const int32_t *lo, *hi;     // [ni]
+    double *cache;              // residual cache in the same (grouped) order
+    const double *const *dyn;   // -> {uf, vf, trail} of the feature (K2Dyn layout: two pointers + a double)
+    const double *ib, *ub;      // nullable (without_bias)
+    THdr *hdr;                  // [nu] {V[f,user], chain counter}
+    unsigned *ctl;
+    double *se_item;
+    int ni, nu, upd_u, upd_i;
+    double lr, K, mu;
+};
+
+namespace {
+
+__device__ __forceinline__ double clamp15r(double x)        // gd_estimator.pyx:26-35
+{
+    if (x > 5.0) x = 5.0;
+    if (x < 1.0) x = 1.0;
+    return x;
+}
+__device__ __forceinline__ double funk_est(double uf, double vf, double cache, double base, double trail, bool trailing)
+{
+    double sum = (cache > 0) ? cache : base;                  // gd_estimator.pyx:38-73
+    sum += uf * vf;
+    sum = clamp15r(sum);
+    if (trailing) {
+        sum += trail;
+        sum = clamp15r(sum);
+    }
+    return sum;
+}
+
+struct Dyn2 { double *uf; double *vf; double trail; };
+
+__global__ __launch_bounds__(64) void k2_res(Res2Params P)
+{
+    const int lane = threadIdx.x;
+    // ---- registration: nothing is modified unless every wave of the grid is running ----------------
+    int ok = 1;
+    if (lane == 0) {
+        if (ldc_u32(P.ctl + kCtlStatus)) ok = 0;
+        else {
+            unsigned v = atomicAdd(P.ctl + kCtlReg, 1u) + 1u;
+            int spins = 0;
+            while (v != gridDim.x) {
+                if (v & kRegFail) { ok = 0; break; }
+                if (++spins > kSpinReg) {
+                    const unsigned old = atomicOr(P.ctl + kCtlReg, kRegFail);
+                    if (old != gridDim.x) { ok = 0; atomicOr(P.ctl + kCtlStatus, 1u); }
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+                v = ldc_u32(P.ctl + kCtlReg);
+            }
+        }
+    }
+    if (!__builtin_amdgcn_readfirstlane(ok)) return;
+    const Dyn2 *dyn = reinterpret_cast<const Dyn2 *>(P.dyn);
+    double *const uf = dyn->uf;
+    const double trail = dyn->trail;
+    const int item = blockIdx.x * 64 + lane;
+    const __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc(P.hdr, 0, 0x7fffffff, 0x27000);
+    int pos = 0, end = 0;
+    double x = 0.0, se = 0.0, bi = 0.0;
+    if (item < P.ni) { pos = P.lo[item]; end = P.hi[item]; x = uf[item]; if (P.ib) bi = P.ib[item]; }
+    URec rec{0, 0, 0.0};
+    double c = 0.0, bu = 0.0;
+    if (pos < end) { rec = P.recs[pos]; c = P.cache[pos]; if (P.ub) bu = P.ub[rec.trav]; }
+    int spins = 0;
+    while (__any(pos < end)) {
+        bool ready = false;
+        THdr g; g.bias = 0.0; g.cnt = -1; g.pad = 0;
+        if (pos < end) {
+            g = __builtin_bit_cast(THdr, ld16c(rH, (unsigned)rec.trav * 16u));
+            ready = g.cnt == rec.seq;
+        }
+        if (ready) {
+            const double mf = x, cf = g.bias;                 // U[f,item], V[f,user]
+            double base;
+            if (P.ib) base = P.mu + bi + bu;                  // gd_estimator.pyx:553-554
+            else base = P.mu + 0.0 + 0.0;
+            const double p = funk_est(mf, cf, c, base, trail, true);
+            const double err = rec.r - p;
+            se += err * err;
+            const double un = mf + P.lr * (err * cf - P.K * mf), vn = cf + P.lr * (err * mf - P.K * cf);   // :757-761
+            THdr n; n.bias = P.upd_u ? vn : cf; n.cnt = rec.seq + 1; n.pad = 0;
+            st16c(__builtin_bit_cast(v4u, n), rH, (unsigned)rec.trav * 16u);
+            if (P.upd_i) x = un;
+            ++pos;
+            if (pos < end) { rec = P.recs[pos]; c = P.cache[pos]; if (P.ub) bu = P.ub[rec.trav]; }
+        }
+        if (!__any(ready)) {
+            if (++spins > kSpinRun || ((spins & 1023) == 0 && ldc_u32(P.ctl + kCtlStatus))) {
+                if (lane == 0) atomicOr(P.ctl + kCtlStatus, 3u);
+                break;
+            }
+        } else spins = 0;
+    }
+    if (item < P.ni) { uf[item] = x; P.se_item[item] = se; }
+}
+
+__global__ void k2_hdr_reset(THdr *hdr, const double *const *dyn, int n)
+{
+    const double *vf = reinterpret_cast<const Dyn2 *>(dyn)->vf;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { THdr h; h.bias = vf[i]; h.cnt = 0; h.pad = 0; hdr[i] = h; }
+}
+// values back -- unless the pass never ran (registration failed: the granules are stale, vf is untouched and stays)
+__global__ void k2_hdr_finish(const THdr *hdr, const double *const *dyn, int n, const unsigned *ctl)
+{
+    if (ctl[kCtlStatus] == 1u) return;
+    double *vf = reinterpret_cast<const Dyn2 *>(dyn)->vf;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) vf[i] = hdr[i].bias;
+}
+// cache-commit pass (gd_estimator.pyx:771-777) over the grouped records: embarrassingly parallel, one thread per record
+__global__ __launch_bounds__(256) void k2_commit_res(Res2Params P, const int32_t *__restrict__ ent_of, int64_t nnz)
+{
+    const Dyn2 *dyn = reinterpret_cast<const Dyn2 *>(P.dyn);
+    const double *uf = dyn->uf, *vf = dyn->vf;
+    for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < nnz; s += (int64_t)gridDim.x * 256) {
+        const URec rec = P.recs[s];
+        const int item = ent_of[s];
+        double base;
+        if (P.ib) base = P.mu + P.ib[item] + P.ub[rec.trav];
+        else base = P.mu + 0.0 + 0.0;
+        P.cache[s] = funk_est(uf[item], vf[rec.trav], P.cache[s], base, 0.0, false);
+    }
+}
+// grouped cache -> the level-major cache of the other Funk kernels (a fallback in the middle of a run)
+__global__ void k2_cache_scatter(const double *src, const int32_t *pos_of, int64_t nnz, double *dst)
+{
+    for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < nnz; s += (int64_t)gridDim.x * blockDim.x) dst[pos_of[s]] = src[s];
+}
+
+}  // namespace
+
+struct Res2Plan {
+    int nu = 0, ni = 0, waves = 0;
+    int64_t nnz = 0;
+    URec *d_recs = nullptr;
+    int32_t *d_lo = nullptr, *d_hi = nullptr, *d_pos_of = nullptr, *d_ent_of = nullptr;
+    double *d_cache = nullptr, *d_se = nullptr;
+    THdr *d_hdr = nullptr;
+    unsigned *d_ctl = nullptr;
+    size_t dev_bytes = 0;
+};
+
+void res2_destroy(Res2Plan *rp)
+{
+    if (!rp) return;
+    void *ptrs[] = {rp->d_recs, rp->d_lo, rp->d_hi, rp->d_pos_of, rp->d_ent_of, rp->d_cache, rp->d_se, rp->d_hdr, rp->d_ctl};
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    delete rp;
+}
+
+// *out stays nullptr when the pass does not apply (more items than resident lanes, tiny problems unless forced)
+int res2_prepare(Res2Plan **out, const Rec *d_recs, int64_t nnz, int nu, int ni, bool force)
+{
+    *out = nullptr;
+    if (nnz <= 0 || nnz >= ((int64_t)1 << 31) - 1 || (int64_t)nu * 16 >= ((int64_t)1 << 31)) return MFX_OK;
+    if (!force && nnz < (1 << 16)) return MFX_OK;
+    hipDeviceProp_t prop;
+    int dev = 0, occ = 0;
+    MFX_HIP(hipGetDevice(&dev));
+    MFX_HIP(hipGetDeviceProperties(&prop, dev));
+    MFX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k2_res, 64, 0));
+    const int waves = ceil_div(ni, 64);
+    if (occ <= 0 || waves > occ * prop.multiProcessorCount * 7 / 8) return MFX_OK;
+    Res2Plan *rp = new (std::nothrow) Res2Plan();
+    if (!rp) return fail(MFX_E_NOMEM, "mfx_sgd_run_funk: out of host memory");
+    rp->nu = nu; rp->ni = ni; rp->nnz = nnz; rp->waves = waves;
+    auto bail = [&](int rc) { res2_destroy(rp); return rc; };
+    auto al = [&](void **q, size_t bytes) {
+        if (hipMalloc(q, bytes ? bytes : 1) != hipSuccess) { (void)hipGetLastError(); return fail(MFX_E_NOMEM, "hipMalloc(%zu bytes)", bytes); }
+        rp->dev_bytes += bytes;
+        return (int)MFX_OK;
+    };
+    if (al((void **)&rp->d_recs, (size_t)nnz * sizeof(URec)) || al((void **)&rp->d_lo, (size_t)ni * 4) || al((void **)&rp->d_hi, (size_t)ni * 4) ||
+        al((void **)&rp->d_pos_of, (size_t)nnz * 4) || al((void **)&rp->d_ent_of, (size_t)nnz * 4) || al((void **)&rp->d_cache, (size_t)nnz * 8) || al((void **)&rp->d_se, (size_t)waves * 64 * 8) ||
+        al((void **)&rp->d_hdr, (size_t)nu * sizeof(THdr)) || al((void **)&rp->d_ctl, kCtlWords * sizeof(unsigned)))
+        return bail(last_code());
+    if (hipMemset(rp->d_ctl, 0, kCtlWords * sizeof(unsigned)) != hipSuccess || hipMemset(rp->d_se, 0, (size_t)waves * 64 * 8) != hipSuccess)
+        return bail(fail(MFX_E_HIP, "mfx_sgd_run_funk: %s", hipGetErrorString(hipGetLastError())));
+    int rc = res_build_device(d_recs, nnz, ni, nu, true, rp->d_recs, rp->d_lo, rp->d_hi, rp->d_pos_of, rp->d_ent_of);
+    if (rc) return bail(rc);
+    *out = rp;
+    return MFX_OK;
+}
+
+size_t res2_dev_bytes(const Res2Plan *rp) { return rp ? rp->dev_bytes : 0; }
+int64_t res2_se_slots(const Res2Plan *rp) { return (int64_t)rp->waves * 64; }
+const double *res2_se_partials(const Res2Plan *rp) { return rp->d_se; }
+int res2_reset_cache(Res2Plan *rp)
+{
+    MFX_HIP(hipMemsetAsync(rp->d_cache, 0, (size_t)rp->nnz * sizeof(double), stream()));
+    return MFX_OK;
+}
+int res2_begin_batch(Res2Plan *rp)
+{
+    MFX_HIP(hipMemsetAsync(rp->d_ctl + kCtlStatus, 0, sizeof(unsigned), stream()));
+    return MFX_OK;
+}
+static Res2Params res2_params(Res2Plan *rp, const void *d_dyn, const double *ib, const double *ub, double mu, double lr, double K, int upd_u, int upd_i)
+{
+    Res2Params P;
+    memset(&P, 0, sizeof(P));
+    P.recs = rp->d_recs; P.lo = rp->d_lo; P.hi = rp->d_hi; P.cache = rp->d_cache; P.dyn = (const double *const *)d_dyn;
+    P.ib = ib; P.ub = ub; P.hdr = rp->d_hdr; P.ctl = rp->d_ctl; P.se_item = rp->d_se; P.ni = rp->ni; P.nu = rp->nu;
+    P.upd_u = upd_u; P.upd_i = upd_i; P.lr = lr; P.K = K; P.mu = mu;
+    return P;
+}
+// one (feature, epoch) pass: granules from V[f,:], the persistent launch, values back
+int res2_enqueue_pass(Res2Plan *rp, const void *d_dyn, const double *ib, const double *ub, double mu, double lr, double K, int upd_u, int upd_i)
+{
+    Res2Params P = res2_params(rp, d_dyn, ib, ub, mu, lr, K, upd_u, upd_i);
+    MFX_HIP(hipMemsetAsync(rp->d_ctl + kCtlReg, 0, sizeof(unsigned), stream()));
+    hipLaunchKernelGGL(k2_hdr_reset, dim3(ceil_div(rp->nu, 256)), dim3(256), 0, stream(), rp->d_hdr, P.dyn, rp->nu);
+    hipLaunchKernelGGL(k2_res, dim3(rp->waves), dim3(64), 0, stream(), P);
+    hipLaunchKernelGGL(k2_hdr_finish, dim3(ceil_div(rp->nu, 256)), dim3(256), 0, stream(), (const THdr *)rp->d_hdr, P.dyn, rp->nu, (const unsigned *)rp->d_ctl);
+    MFX_HIP(hipGetLastError());
+    return MFX_OK;
+}
+int res2_enqueue_commit(Res2Plan *rp, const void *d_dyn, const double *ib, const double *ub, double mu)
+{
+    Res2Params P = res2_params(rp, d_dyn, ib, ub, mu, 0.0, 0.0, 0, 0);
+    const int blocks = (int)(ceil_div(rp->nnz, (int64_t)256) < 4096 ? ceil_div(rp->nnz, (int64_t)256) : 4096);
+    hipLaunchKernelGGL(k2_commit_res, dim3(blocks), dim3(256), 0, stream(), P, (const int32_t *)rp->d_ent_of, rp->nnz);
+    MFX_HIP(hipGetLastError());
+    return MFX_OK;
+}
+int res2_status(Res2Plan *rp, unsigned *status)
+{
+    MFX_HIP(hipMemcpy(status, rp->d_ctl + kCtlStatus, sizeof(unsigned), hipMemcpyDeviceToHost));
+    return MFX_OK;
+}
+// hand the residual cache to the level-major kernels (fallback in the middle of a run)
+int res2_cache_to_levels(Res2Plan *rp, double *d_cache_levels)
+{
+    hipLaunchKernelGGL(k2_cache_scatter, dim3(2048), dim3(256), 0, stream(), (const double *)rp->d_cache, (const int32_t *)rp->d_pos_of, rp->nnz, d_cache_levels);
+    MFX_HIP(hipGetLastError());
+    return MFX_OK;
+}
+
 }  // namespace mfx

@@ -1,7 +1,7 @@
-"""GPU: the XCD-resident Funk pass (k2_xcd_pass: one persistent launch per feature-epoch on a single XCD,
-user slices in LDS, flat L2 barrier between dependency levels) must give the SAME BITS as the oracle's
-sequential loops (gd_estimator.pyx:691-779, :489-582, :588-685) -- it is the default path for large levels
-(cfg 2: 618 levels of 16 K) and is forced here (MFX_K2_XCD=1) on problems the oracle finishes in seconds."""
+"""GPU: the resident-side Funk pass (mfx_sgd_res.hip k2_res: ONE persistent launch per feature-epoch over every CU, a lane
+owns an item and keeps U[f,item] in a register, V[f,user] travels inside its 16-byte {value, chain counter} granule) must give
+the SAME BITS as the oracle's sequential loops (gd_estimator.pyx:691-779, :489-582, :588-685).  It is the default from 65 536
+ratings on; forced here (MFX_K2_RES=1) also on tiny problems."""
 import numpy as np
 import pytest
 
@@ -16,8 +16,7 @@ def _force(monkeypatch):
     from mfrec_amd import build as B
     B.build(verbose=False)
     S.init(0)
-    monkeypatch.setenv("MFX_K2_XCD", "1")
-    monkeypatch.setenv("MFX_K2_RES", "0")        # (the resident-side pass would take these sizes: tests/test_gpu_funk_res.py)
+    monkeypatch.setenv("MFX_K2_RES", "1")
 
 
 @pytest.mark.parametrize("nu,ni,nnz,k", [(3000, 2000, 200000, 3), (50000, 700, 400000, 2), (37, 29, 600, 4),
@@ -36,7 +35,7 @@ def test_without_bias_bitexact(nu, ni, nnz, k):
 
 def test_stopping_rule_history_and_second_run_on_the_same_plan():
     """Data-dependent stopping rule (gd_estimator.pyx:742) through the resident API, twice on one plan: the
-    barrier generations keep counting across passes and runs."""
+    chain counters are reset per pass, the residual cache per run."""
     from mfrec_amd.plan import SgdPlan
     from oracle import oracle as O
     nu, ni, nnz, k = 4000, 1500, 150000, 4
@@ -52,7 +51,7 @@ def test_stopping_rule_history_and_second_run_on_the_same_plan():
             assert np.array_equal(u, u2) and np.array_equal(v, v2)
             assert len(hist) == n
             np.testing.assert_allclose(hist, h2[:n], rtol=1e-12)
-        # the full-k kernels on the SAME plan after the in-level re-ordering: still the oracle's bits
+        # the full-k kernels on the SAME plan: still the oracle's bits
         u, v, ib, ub = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2), np.zeros(ni), np.zeros(nu)
         u2, v2, ib2, ub2 = u.copy(), v.copy(), ib.copy(), ub.copy()
         p.set_factors(u, v, ib, ub)
@@ -77,9 +76,9 @@ def test_with_bias_and_gates_bitexact():
         assert np.array_equal(u, u2) and np.array_equal(v, v2), gates
 
 
-def test_large_levels_take_the_xcd_path_by_default(monkeypatch):
-    """cfg-2 sized levels: the path is chosen without the override (avg level >= 4096 ratings)."""
-    monkeypatch.delenv("MFX_K2_XCD")
+def test_large_problems_take_the_resident_pass_by_default(monkeypatch):
+    """From 65 536 ratings on the pass is chosen without the override."""
+    monkeypatch.delenv("MFX_K2_RES")
     from mfrec_amd.plan import SgdPlan, Timer
     from oracle import oracle as O
     nu, ni, nnz, k = 60000, 12000, 8000000, 2          # ~1200 levels of ~6.5 K ratings
@@ -89,7 +88,7 @@ def test_large_levels_take_the_xcd_path_by_default(monkeypatch):
         p.set_factors(u, v)
         p.run_funk(2, 1e9, 0.1, 0.001, 0.05)
         p.get_factors(u, v)
-        assert p.info()["n_levels"] * 4096 <= nnz           # i.e. the size rule selects the XCD pass
+        assert p.kernel_name(3).startswith("k2_res<"), p.kernel_name(3)
     u2, v2 = synth.init_const(k, ni), synth.init_const(k, nu)
     O.estimator_loop_without_bias(2, 2, 1e9, k, 0.1, 0.001, 0.05, u2, v2, idx, r, nu, ni)
     assert np.array_equal(u, u2) and np.array_equal(v, v2)
@@ -121,3 +120,20 @@ def test_uneven_load_bitexact(skew):
     u2, v2 = synth.init_const(k, ni), synth.init_const(k, nu)
     O.estimator_loop_without_bias(2, 2, 1e9, k, 0.1, 0.001, 0.05, u2, v2, idx, r, nu, ni)
     assert np.array_equal(u, u2) and np.array_equal(v, v2)
+
+
+def test_goldens_through_the_resident_pass(golden):
+    """The reference's own outputs (g3: without bias + duplicates, g3b: stopping rule, g4: BellKor baseline + gates)."""
+    from mfrec_amd.lib import gd_estimator as G
+    g = golden("g3_funk")
+    k, E = int(g["p_k"]), int(g["p_epochs"])
+    u, v = synth.init_const(k, 40, float(g["p_init"])), synth.init_const(k, 60, float(g["p_init"]))
+    G.estimator_loop_without_bias(E, E, 1e9, k, float(g["p_init"]), float(g["p_lr"]), float(g["p_K"]), u, v, g["in_idx"], g["in_r"], 60, 40)
+    assert np.array_equal(u, g["out_u"]) and np.array_equal(v, g["out_v"])
+    g = golden("g4_funk_bias")
+    k, E = int(g["p_k"]), int(g["p_epochs"])
+    for gate, tag in (((1, 1), "11"), ((1, 0), "10"), ((0, 1), "01")):
+        u, v = synth.init_const(k, 40, float(g["p_init"])), synth.init_const(k, 60, float(g["p_init"]))
+        G.estimator_loop_with_bias_dev(E, E, 1e9, k, float(g["p_init"]), float(g["p_lr"]), 0.0, 0.0, float(g["p_K"]), float(g["p_mu"]),
+                                       u, v, g["in_idx"], g["in_r"], g["in_ib"], g["in_ub"], 60, 40, *gate)
+        assert np.array_equal(u, g["out_u_" + tag]) and np.array_equal(v, g["out_v_" + tag]), tag

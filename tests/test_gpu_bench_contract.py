@@ -40,7 +40,8 @@ def test_main_line_and_roofline_are_consistent():
     assert r["traffic"] is None or r["traffic"] > r["algorithmic_bytes_per_launch"]
     assert 2.5e9 < d["value"] < 5.0e9                       # ~3.1 G updates/s (the level schedule: ~1.95 G)
     k2 = d["also"]["k2_funk"]
-    assert k2["unit"] == "scalar-updates/s" and k2["roofline"]["kernel"].startswith("k2_xcd_pass")
+    # shuffled order at cfg 2: levels of ~16 K ratings -> the resident-side Funk pass (lane = item, values inside the granules)
+    assert k2["unit"] == "scalar-updates/s" and k2["roofline"]["kernel"].startswith("k2_res<")
     assert k2["value"] > 4.0e9                              # round 1's launch path: 4.8 G
 
 

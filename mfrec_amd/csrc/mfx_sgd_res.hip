@@ -737,7 +737,7 @@ struct Res2Params {
     THdr *hdr;                  // [nu] {V[f,user], chain counter}
     unsigned *ctl;
     double *se_item;
-    int ni, nu, upd_u, upd_i;
+    int ni, nu, upd_u, upd_i, window, hot_deg;
     double lr, K, mu;
 };
 
@@ -795,30 +795,66 @@ __global__ __launch_bounds__(64) void k2_res(Res2Params P)
     double x = 0.0, se = 0.0, bi = 0.0;
     if (item < P.ni) { pos = P.lo[item]; end = P.hi[item]; x = uf[item]; if (P.ib) bi = P.ib[item]; }
     URec rec{0, 0, 0.0};
-    double c = 0.0, bu = 0.0;
-    if (pos < end) { rec = P.recs[pos]; c = P.cache[pos]; if (P.ub) bu = P.ub[rec.trav]; }
+    double c = 0.0;
+    if (pos < end) { rec = P.recs[pos]; c = P.cache[pos]; }
     int spins = 0;
+    // one rating: the estimate with the residual cache, the error, both values from the OLD ones (gd_estimator.pyx:750-761)
+    auto apply = [&](const URec &q, double cq, const THdr &g) {
+        const double mf = x, cf = g.bias;                     // U[f,item], V[f,user]
+        double base;
+        if (P.ib) base = P.mu + bi + P.ub[q.trav];            // gd_estimator.pyx:553-554
+        else base = P.mu + 0.0 + 0.0;
+        const double p = funk_est(mf, cf, cq, base, trail, true);
+        const double err = q.r - p;
+        se += err * err;
+        const double un = mf + P.lr * (err * cf - P.K * mf), vn = cf + P.lr * (err * mf - P.K * cf);
+        THdr n; n.bias = P.upd_u ? vn : cf; n.cnt = q.seq + 1; n.pad = 0;
+        st16c(__builtin_bit_cast(v4u, n), rH, (unsigned)q.trav * 16u);
+        if (P.upd_i) x = un;
+    };
+    // A HOT item (eight times the average degree or more: the chains that bound a pass on skewed data; its raters are mostly
+    // idle) on a streak -- its last two heads were ready at the first poll -- looks three ratings further: their records and
+    // granules travel together with the head's poll, and every one whose counter already matches is applied in the same
+    // iteration (a counter that matches can only be advanced by this lane, so an early answer stays valid).  Ordinary items
+    // never do: the pass is bound by the request rate of the polls, and on uniform data the look-ahead costs more requests than
+    // it saves round trips (measured: 1.26 -> 1.77 ms per pass at cfg 2 with the window on every lane).
+    const bool window = P.window != 0 && end - pos >= P.hot_deg;
+    int streak = 0;
     while (__any(pos < end)) {
-        bool ready = false;
-        THdr g; g.bias = 0.0; g.cnt = -1; g.pad = 0;
-        if (pos < end) {
-            g = __builtin_bit_cast(THdr, ld16c(rH, (unsigned)rec.trav * 16u));
-            ready = g.cnt == rec.seq;
+        const bool act = pos < end;
+        const bool wide = window && act && streak >= 2 && pos + 1 < end;
+        THdr g0; g0.bias = 0.0; g0.cnt = -1; g0.pad = 0;
+        if (act) g0 = __builtin_bit_cast(THdr, ld16c(rH, (unsigned)rec.trav * 16u));
+        URec q1{0, -2, 0.0}, q2{0, -2, 0.0}, q3{0, -2, 0.0};
+        double c1 = 0.0, c2 = 0.0, c3 = 0.0;
+        THdr g1 = g0, g2 = g0, g3 = g0;
+        g1.cnt = g2.cnt = g3.cnt = -1;
+        if (wide) {
+            q1 = P.recs[pos + 1]; c1 = P.cache[pos + 1];
+            if (pos + 2 < end) { q2 = P.recs[pos + 2]; c2 = P.cache[pos + 2]; }
+            if (pos + 3 < end) { q3 = P.recs[pos + 3]; c3 = P.cache[pos + 3]; }
+            g1 = __builtin_bit_cast(THdr, ld16c(rH, (unsigned)q1.trav * 16u));
+            if (pos + 2 < end) g2 = __builtin_bit_cast(THdr, ld16c(rH, (unsigned)q2.trav * 16u));
+            if (pos + 3 < end) g3 = __builtin_bit_cast(THdr, ld16c(rH, (unsigned)q3.trav * 16u));
         }
+        const bool ready = act && g0.cnt == rec.seq;
         if (ready) {
-            const double mf = x, cf = g.bias;                 // U[f,item], V[f,user]
-            double base;
-            if (P.ib) base = P.mu + bi + bu;                  // gd_estimator.pyx:553-554
-            else base = P.mu + 0.0 + 0.0;
-            const double p = funk_est(mf, cf, c, base, trail, true);
-            const double err = rec.r - p;
-            se += err * err;
-            const double un = mf + P.lr * (err * cf - P.K * mf), vn = cf + P.lr * (err * mf - P.K * cf);   // :757-761
-            THdr n; n.bias = P.upd_u ? vn : cf; n.cnt = rec.seq + 1; n.pad = 0;
-            st16c(__builtin_bit_cast(v4u, n), rH, (unsigned)rec.trav * 16u);
-            if (P.upd_i) x = un;
+            apply(rec, c, g0);
             ++pos;
-            if (pos < end) { rec = P.recs[pos]; c = P.cache[pos]; if (P.ub) bu = P.ub[rec.trav]; }
+            int n = 1;
+            if (wide) {
+                if (g1.cnt == q1.seq) {
+                    apply(q1, c1, g1); ++pos; ++n;
+                    if (g2.cnt == q2.seq) {
+                        apply(q2, c2, g2); ++pos; ++n;
+                        if (g3.cnt == q3.seq) { apply(q3, c3, g3); ++pos; ++n; }
+                    }
+                }
+            }
+            streak = (!wide || n >= 2) ? streak + 1 : 0;
+            if (pos < end) { rec = P.recs[pos]; c = P.cache[pos]; }
+        } else {
+            streak = 0;
         }
         if (!__any(ready)) {
             if (++spins > kSpinRun || ((spins & 1023) == 0 && ldc_u32(P.ctl + kCtlStatus))) {
@@ -940,6 +976,8 @@ static Res2Params res2_params(Res2Plan *rp, const void *d_dyn, const double *ib,
     P.recs = rp->d_recs; P.lo = rp->d_lo; P.hi = rp->d_hi; P.cache = rp->d_cache; P.dyn = (const double *const *)d_dyn;
     P.ib = ib; P.ub = ub; P.hdr = rp->d_hdr; P.ctl = rp->d_ctl; P.se_item = rp->d_se; P.ni = rp->ni; P.nu = rp->nu;
     P.upd_u = upd_u; P.upd_i = upd_i; P.lr = lr; P.K = K; P.mu = mu;
+    P.window = env_i("MFX_K2_WIN", 1);                     // 0: no look-ahead (A/B hook)
+    { const int64_t h = 8 * (rp->nnz / (rp->ni > 0 ? rp->ni : 1)); P.hot_deg = (int)(h < 64 ? 64 : (h > 0x7fffffff ? 0x7fffffff : h)); }
     return P;
 }
 // one (feature, epoch) pass: granules from V[f,:], the persistent launch, values back

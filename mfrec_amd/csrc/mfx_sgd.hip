@@ -462,11 +462,16 @@ int run_k1_epochs(mfx_sgd_plan *p, int mode, int epochs, const K1Params &P, Hook
         // the resident-side launch reports through a status word: 1 = the static grid was not co-resident and
         // NOTHING was modified by any epoch of this batch (the word is sticky) -> the level schedule, from now on
         MFX_HIP(hipStreamSynchronize(stream()));
-        unsigned status = 0;
-        if ((rc = res_status(p->res, &status))) return rc;
+        unsigned status = 0, applied = 0;
+        if ((rc = res_status(p->res, &status, &applied))) return rc;
         if (status == 1) {
+            // the first `applied` epochs of the batch ran in full, the one that failed its check and every later one did nothing:
+            // the rest goes to the level schedule, its squared errors behind the ones already there
             p->res_state = -1;
-            return run_k1_epochs(p, mode, epochs, P, hook, reset_se, false);
+            if ((int)applied >= epochs) return MFX_OK;
+            const int done = (int)applied;
+            MFX_HIP(hipMemcpy(p->d_counter, &done, sizeof(int), hipMemcpyHostToDevice));
+            return run_k1_epochs(p, mode, epochs - done, P, hook, false, false);
         }
         if (status) return fail(MFX_E_HIP, "mfx_sgd_run_kmf: the resident-side epoch timed out waiting for a chain counter");
     }
@@ -1161,6 +1166,7 @@ int funk_core(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_
             }
             double se_b[32];
             double nn = (double)p->nnz;
+            int b0 = 0;                 // passes of this batch already applied (by the resident-side pass, before a fall-back)
             for (;;) {
                 if (k2r) {
                     // ---- resident-side pass: granules, one persistent launch over every CU, values back, reduction ----
@@ -1172,22 +1178,25 @@ int funk_core(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_
                     }
                     MFX_HIP(hipMemcpyAsync(se_b, p->d_se_epoch, (size_t)batch * sizeof(double), hipMemcpyDeviceToHost, stream()));
                     MFX_HIP(hipStreamSynchronize(stream()));
-                    unsigned status = 0;
-                    if ((rc = res2_status(p->res2, &status))) return rc;
+                    unsigned status = 0, applied = 0;
+                    if ((rc = res2_status(p->res2, &status, &applied))) return rc;
                     if (status == 0) break;
                     if (status != 1) return fail(MFX_E_HIP, "mfx_sgd_run_funk: the resident-side pass timed out waiting for a granule");
-                    // its grid was not co-resident: NOTHING of this batch was applied.  The residual cache moves to the
-                    // level-major layout and the run goes on, for good, with one launch per level.
+                    // a pass found its grid not co-resident: the first `applied` passes of the batch ran in full, that one and the
+                    // later ones did NOTHING.  The residual cache moves to the level-major layout and the run goes on, for good, with
+                    // one launch per level -- from the first pass that was not applied.
                     if ((rc = res2_cache_to_levels(p->res2, p->d_cache))) return rc;
                     p->k2r_state = -1;
                     k2r = false;
                     if (p->k2x_state == 0) p->k2x_state = -1;       // (its preparation would re-order records the cache now follows)
+                    b0 = (int)applied < batch ? (int)applied : batch;
+                    if (b0 == batch) break;
                     continue;
                 }
                 const bool xcd = p->k2x_state == 1;
-                MFX_HIP(hipMemsetAsync(p->d_counter, 0, sizeof(int), stream()));
+                MFX_HIP(hipMemcpyAsync(p->d_counter, &b0, sizeof(int), hipMemcpyHostToDevice, stream()));   // squared errors b0 .. batch-1
                 if (xcd) MFX_HIP(hipMemsetAsync(p->d_xctl + 512, 0, sizeof(unsigned), stream()));   // status: sticky inside a batch
-                for (int b = 0; b < batch; ++b) {
+                for (int b = b0; b < batch; ++b) {
                     if (hk && (rc = hk->pre(hk->ctx, dyn.uf, p->ni))) return rc;
                     if (xcd) rc = enqueue_k2x_pass(p, P);
                     else if (graph && p->graph2) {

@@ -64,7 +64,7 @@ int res2_reset_cache(Res2Plan *rp);
 int res2_begin_batch(Res2Plan *rp);
 int res2_enqueue_pass(Res2Plan *rp, const void *d_dyn, const double *ib, const double *ub, double mu, double lr, double K, int upd_u, int upd_i);
 int res2_enqueue_commit(Res2Plan *rp, const void *d_dyn, const double *ib, const double *ub, double mu);
-int res2_status(Res2Plan *rp, unsigned *status);
+int res2_status(Res2Plan *rp, unsigned *status, unsigned *applied = nullptr);
 int res2_cache_to_levels(Res2Plan *rp, double *d_cache_levels);
 void res_destroy(ResPlan *rp);
 int res_kind(const ResPlan *rp);                 // 0 none, 1 ticket (users resident, runs by ticket), 2 static owners
@@ -75,7 +75,7 @@ int res_describe(const ResPlan *rp, int mode, char *buf, int buflen);
 int res_begin_batch(ResPlan *rp);
 int res_enqueue_epoch(ResPlan *rp, int mode, double *U_nk, double *V_nk, double *ib, double *ub, double lr, double Ku,
                       double Ki, double Kb);
-int res_status(ResPlan *rp, unsigned *status);
+int res_status(ResPlan *rp, unsigned *status, unsigned *applied = nullptr);
 // plan creation with the epoch kernel chosen (MFX_EPOCH_*); the Funk / learned-bias / dense-cache drop-ins pass
 // MFX_EPOCH_LEVELS: they never run a plain full-k epoch.  | kEpochHeadroom (DSGD sub-plans): a static grid leaves an eighth
 // of the chip's wave slots free, for the transfer kernels that run beside it.

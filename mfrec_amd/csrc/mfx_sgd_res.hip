@@ -48,6 +48,7 @@ struct ResParams {
     unsigned *ctl;              // [0] ticket, [32] status, [64] registration
     double *se_run;             // squared error per run (fixed layout: deterministic epoch RMSE)
     int n_runs, k, res_item;
+    int reg_extra;              // test hook: waves that will never register (the co-residency check must fail)
     double lr, Kres, Ktrav, Kb;
 };
 
@@ -57,7 +58,7 @@ typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-constexpr int kCtlStatus = 32, kCtlReg = 64, kCtlWords = 96;
+constexpr int kCtlStatus = 32, kCtlDone = 33, kCtlReg = 64, kCtlWords = 96;   // [33]: static launches of the batch that passed their check
 constexpr unsigned kRegFail = 0x80000000u;
 constexpr int kSpinRun = 1 << 22;        // polls of ~1 us: seconds
 constexpr int kSpinReg = 1 << 15;        // registration: tens of milliseconds
@@ -308,13 +309,14 @@ __global__ __launch_bounds__(64, STATIC ? ((NR <= 9 && !BURST) ? 3 : 2) : 4) voi
         if (lane == 0) {
             if (ldc_u32(P.ctl + kCtlStatus)) ok = 0;
             else {
+                const unsigned want = gridDim.x + (unsigned)P.reg_extra;
                 unsigned v = atomicAdd(P.ctl + kCtlReg, 1u) + 1u;
                 int spins = 0;
-                while (v != gridDim.x) {
+                while (v != want) {
                     if (v & kRegFail) { ok = 0; break; }
                     if (++spins > kSpinReg) {
                         const unsigned old = atomicOr(P.ctl + kCtlReg, kRegFail);
-                        if (old != gridDim.x) { ok = 0; atomicOr(P.ctl + kCtlStatus, 1u); }   // (complete before the flag: go on)
+                        if (old != want) { ok = 0; atomicOr(P.ctl + kCtlStatus, 1u); }   // (complete before the flag: go on)
                         break;
                     }
                     __builtin_amdgcn_s_sleep(8);
@@ -323,6 +325,7 @@ __global__ __launch_bounds__(64, STATIC ? ((NR <= 9 && !BURST) ? 3 : 2) : 4) voi
             }
         }
         if (!__builtin_amdgcn_readfirstlane(ok)) return;
+        if (blockIdx.x == 0 && lane == 0) atomicAdd(P.ctl + kCtlDone, 1u);       // this launch of the batch is being applied
     }
     for (int pass = 0;; ++pass) {
         int64_t run = -1;
@@ -437,6 +440,18 @@ int env_i(const char *name, int dflt)
 {
     const char *e = getenv(name);
     return (e && *e) ? atoi(e) : dflt;
+}
+// MFX_TEST_REG_FAIL=n together with MFX_TESTING=1 (tests only): the static launches wait for one wave more than their grid has,
+// i.e. their co-residency check fails the way it does on a GPU shared with another process -- exercises the fall-backs
+// (MFX_TEST_REG_FAIL=n: the n-th static launch of the process and every later one fail -- n > 1 reaches the fall-back in the middle
+//  of a run, with state to hand over)
+int test_reg_extra()
+{
+    static int launches = 0;
+    if (env_i("MFX_TESTING", 0) != 1) return 0;
+    const int n = env_i("MFX_TEST_REG_FAIL", 0);
+    if (n <= 0) { launches = 0; return 0; }
+    return ++launches >= n ? 1 : 0;
 }
 
 struct Sel { void *fn; int kp, nr; };
@@ -682,7 +697,7 @@ int res_describe(const ResPlan *rp, int mode, char *buf, int buflen)
 // clear the sticky status word: once per batch of epochs
 int res_begin_batch(ResPlan *rp)
 {
-    MFX_HIP(hipMemsetAsync(rp->d_ctl + kCtlStatus, 0, sizeof(unsigned), stream()));
+    MFX_HIP(hipMemsetAsync(rp->d_ctl + kCtlStatus, 0, 2 * sizeof(unsigned), stream()));      // status + applied-launch count
     return MFX_OK;
 }
 
@@ -700,6 +715,7 @@ int res_enqueue_epoch(ResPlan *rp, int mode, double *U_nk, double *V_nk, double 
     P.hdr = rp->d_hdr; P.ctl = rp->d_ctl; P.se_run = rp->d_se_run;
     P.n_runs = rp->n_runs; P.k = rp->k; P.res_item = rp->res_item ? 1 : 0;
     P.lr = lr; P.Kres = rp->res_item ? Ki : Ku; P.Ktrav = rp->res_item ? Ku : Ki; P.Kb = Kb;
+    P.reg_extra = test_reg_extra();
     const Sel s = select(rp->k, mode, rp->nr);
     MFX_HIP(hipMemsetAsync(rp->d_ctl, 0, sizeof(unsigned), stream()));                          // ticket
     MFX_HIP(hipMemsetAsync(rp->d_ctl + kCtlReg, 0, sizeof(unsigned), stream()));                // registration
@@ -711,11 +727,14 @@ int res_enqueue_epoch(ResPlan *rp, int mode, double *U_nk, double *V_nk, double 
     return MFX_OK;
 }
 
-// after a stream sync: 0 = fine, 1 = the static grid was not resident (NOTHING was modified by any epoch of the
-// batch), 3 = a spin timed out mid-epoch (state undefined)
-int res_status(ResPlan *rp, unsigned *status)
+// after a stream sync: 0 = fine, 1 = a static grid was not resident -- *applied launches of the batch ran in full before it,
+// that one and every later one modified NOTHING (the word is sticky) --, 3 = a spin timed out mid-epoch (state undefined)
+int res_status(ResPlan *rp, unsigned *status, unsigned *applied)
 {
-    MFX_HIP(hipMemcpy(status, rp->d_ctl + kCtlStatus, sizeof(unsigned), hipMemcpyDeviceToHost));
+    unsigned w[2] = {0, 0};
+    MFX_HIP(hipMemcpy(w, rp->d_ctl + kCtlStatus, sizeof w, hipMemcpyDeviceToHost));
+    *status = w[0];
+    if (applied) *applied = w[1];
     return MFX_OK;
 }
 
@@ -737,7 +756,7 @@ struct Res2Params {
     THdr *hdr;                  // [nu] {V[f,user], chain counter}
     unsigned *ctl;
     double *se_item;
-    int ni, nu, upd_u, upd_i, window, hot_deg;
+    int ni, nu, upd_u, upd_i, window, hot_deg, reg_extra;
     double lr, K, mu;
 };
 
@@ -771,13 +790,14 @@ __global__ __launch_bounds__(64) void k2_res(Res2Params P)
     if (lane == 0) {
         if (ldc_u32(P.ctl + kCtlStatus)) ok = 0;
         else {
+            const unsigned want = gridDim.x + (unsigned)P.reg_extra;
             unsigned v = atomicAdd(P.ctl + kCtlReg, 1u) + 1u;
             int spins = 0;
-            while (v != gridDim.x) {
+            while (v != want) {
                 if (v & kRegFail) { ok = 0; break; }
                 if (++spins > kSpinReg) {
                     const unsigned old = atomicOr(P.ctl + kCtlReg, kRegFail);
-                    if (old != gridDim.x) { ok = 0; atomicOr(P.ctl + kCtlStatus, 1u); }
+                    if (old != want) { ok = 0; atomicOr(P.ctl + kCtlStatus, 1u); }
                     break;
                 }
                 __builtin_amdgcn_s_sleep(8);
@@ -786,6 +806,7 @@ __global__ __launch_bounds__(64) void k2_res(Res2Params P)
         }
     }
     if (!__builtin_amdgcn_readfirstlane(ok)) return;
+    if (blockIdx.x == 0 && lane == 0) atomicAdd(P.ctl + kCtlDone, 1u);           // this pass of the batch is being applied
     const Dyn2 *dyn = reinterpret_cast<const Dyn2 *>(P.dyn);
     double *const uf = dyn->uf;
     const double trail = dyn->trail;
@@ -966,7 +987,7 @@ int res2_reset_cache(Res2Plan *rp)
 }
 int res2_begin_batch(Res2Plan *rp)
 {
-    MFX_HIP(hipMemsetAsync(rp->d_ctl + kCtlStatus, 0, sizeof(unsigned), stream()));
+    MFX_HIP(hipMemsetAsync(rp->d_ctl + kCtlStatus, 0, 2 * sizeof(unsigned), stream()));
     return MFX_OK;
 }
 static Res2Params res2_params(Res2Plan *rp, const void *d_dyn, const double *ib, const double *ub, double mu, double lr, double K, int upd_u, int upd_i)
@@ -977,6 +998,7 @@ static Res2Params res2_params(Res2Plan *rp, const void *d_dyn, const double *ib,
     P.ib = ib; P.ub = ub; P.hdr = rp->d_hdr; P.ctl = rp->d_ctl; P.se_item = rp->d_se; P.ni = rp->ni; P.nu = rp->nu;
     P.upd_u = upd_u; P.upd_i = upd_i; P.lr = lr; P.K = K; P.mu = mu;
     P.window = env_i("MFX_K2_WIN", 1);                     // 0: no look-ahead (A/B hook)
+    P.reg_extra = test_reg_extra();
     { const int64_t h = 8 * (rp->nnz / (rp->ni > 0 ? rp->ni : 1)); P.hot_deg = (int)(h < 64 ? 64 : (h > 0x7fffffff ? 0x7fffffff : h)); }
     return P;
 }
@@ -999,9 +1021,12 @@ int res2_enqueue_commit(Res2Plan *rp, const void *d_dyn, const double *ib, const
     MFX_HIP(hipGetLastError());
     return MFX_OK;
 }
-int res2_status(Res2Plan *rp, unsigned *status)
+int res2_status(Res2Plan *rp, unsigned *status, unsigned *applied)
 {
-    MFX_HIP(hipMemcpy(status, rp->d_ctl + kCtlStatus, sizeof(unsigned), hipMemcpyDeviceToHost));
+    unsigned w[2] = {0, 0};
+    MFX_HIP(hipMemcpy(w, rp->d_ctl + kCtlStatus, sizeof w, hipMemcpyDeviceToHost));
+    *status = w[0];
+    if (applied) *applied = w[1];
     return MFX_OK;
 }
 // hand the residual cache to the level-major kernels (fallback in the middle of a run)

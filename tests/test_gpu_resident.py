@@ -200,3 +200,66 @@ def test_skew_is_detected_and_served_by_the_burst_variant():
     assert got[5]["epoch_kernel"] == "static" and "bursts" in got[7], (got[5], got[7])
     lev = _run_plan(idx, r, nu, ni, k, u0, v0, 1, LINEAR, "levels")
     _check(got[:4], lev[:4], LINEAR)
+
+
+def test_failed_co_residency_check_falls_back_untouched(monkeypatch):
+    """A static launch whose grid is not co-resident (a GPU shared with another process; forced here by a test hook that makes the
+    registration wait for a wave that does not exist) must modify NOTHING and hand the batch to the level schedule -- for the full-k
+    epoch and for the Funk pass (whose residual cache moves to the level-major layout on the way)."""
+    from mfrec_amd.lib import gd_estimator as G
+    monkeypatch.setenv("MFX_TESTING", "1")
+    monkeypatch.setenv("MFX_TEST_REG_FAIL", "1")
+    nu, ni, nnz, k = 900, 400, 40000, 64
+    idx, r = synth.make_ratings(nu, ni, nnz, seed=11)
+    u0, v0 = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
+    u, v, ib, ub, rm, info, info_after, name = _run_plan(idx, r, nu, ni, k, u0, v0, 2, LINEAR, "static", calls=2)
+    assert info["epoch_kernel"] == "static" and info_after["epoch_kernel"] == "levels" and info_after["epoch_kernel_prepared"] == "static"
+    _check((u, v, ib, ub), _oracle(idx, r, nu, ni, k, u0, v0, 4, LINEAR), LINEAR)
+    assert np.all(np.isfinite(rm)) and rm.shape == (4,)
+    # Funk: forced onto the resident-side pass, which fails its check at the first batch
+    monkeypatch.setenv("MFX_K2_RES", "1")
+    kf = 3
+    fu, fv = synth.init_const(kf, ni), synth.init_const(kf, nu)
+    G.estimator_loop_without_bias(2, 2, 1e9, kf, 0.1, 0.001, 0.05, fu, fv, idx, r, nu, ni)
+    fu2, fv2 = synth.init_const(kf, ni), synth.init_const(kf, nu)
+    O.estimator_loop_without_bias(2, 2, 1e9, kf, 0.1, 0.001, 0.05, fu2, fv2, idx, r, nu, ni)
+    assert np.array_equal(fu, fu2) and np.array_equal(fv, fv2)
+
+
+def test_funk_fallback_in_the_middle_of_a_run_hands_the_cache_over(monkeypatch):
+    """The resident-side Funk pass loses its co-residency check at its 5th launch (3 features x 2 epochs each + commits are
+    under way): the residual cache built so far moves to the level-major layout and the run ends on the level schedule with
+    the oracle's bits."""
+    from mfrec_amd.lib import gd_estimator as G
+    monkeypatch.setenv("MFX_TESTING", "1")
+    monkeypatch.setenv("MFX_K2_RES", "1")
+    nu, ni, nnz, kf = 900, 400, 40000, 4
+    idx, r = synth.make_ratings(nu, ni, nnz, seed=12)
+    fu2, fv2 = synth.init_const(kf, ni), synth.init_const(kf, nu)
+    O.estimator_loop_without_bias(2, 2, 1e9, kf, 0.1, 0.001, 0.05, fu2, fv2, idx, r, nu, ni)
+    for n in (3, 5, 6):
+        monkeypatch.setenv("MFX_TEST_REG_FAIL", "0")                 # (resets the hook's launch counter)
+        fu, fv = synth.init_const(kf, ni), synth.init_const(kf, nu)
+        G.estimator_loop_without_bias(1, 1, 1e9, 1, 0.1, 0.001, 0.05, fu[:1].copy(), fv[:1].copy(), idx, r, nu, ni)
+        monkeypatch.setenv("MFX_TEST_REG_FAIL", str(n))
+        G.estimator_loop_without_bias(2, 2, 1e9, kf, 0.1, 0.001, 0.05, fu, fv, idx, r, nu, ni)
+        assert np.array_equal(fu, fu2) and np.array_equal(fv, fv2), n
+
+
+def test_full_k_fallback_in_the_middle_of_a_batch(monkeypatch):
+    """Four epochs enqueued back to back on the static binding; the third launch fails its co-residency check: epochs 1-2 stay
+    applied, 3-4 run on the level schedule, and the per-epoch RMSE history is the level schedule's."""
+    monkeypatch.setenv("MFX_TESTING", "1")
+    monkeypatch.setenv("MFX_GRAPH", "0")        # eager launches: the hook counts enqueued launches (a replayed graph is enqueued once)
+    nu, ni, nnz, k = 900, 400, 40000, 64
+    idx, r = synth.make_ratings(nu, ni, nnz, seed=13)
+    u0, v0 = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
+    want = _run_plan(idx, r, nu, ni, k, u0, v0, 4, LINEAR, "levels")
+    for n in (1, 3, 4):
+        monkeypatch.setenv("MFX_TEST_REG_FAIL", "0")
+        _run_plan(idx, r, nu, ni, 18, synth.init_normal(18, ni, 1), synth.init_normal(18, nu, 2), 1, LINEAR, "static")   # resets the hook's counter
+        monkeypatch.setenv("MFX_TEST_REG_FAIL", str(n))
+        got = _run_plan(idx, r, nu, ni, k, u0, v0, 4, LINEAR, "static")
+        _check(got[:4], want[:4], LINEAR)
+        np.testing.assert_allclose(got[4], want[4], rtol=1e-12)
+        assert got[6]["epoch_kernel"] == "levels", n

@@ -66,6 +66,19 @@ constexpr int kSpinReg = 1 << 15;        // registration: tens of milliseconds
 // 16-byte agent-scope (sc1) accesses the compiler can see and count
 __device__ __forceinline__ v4u ld16c(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16); }
 __device__ __forceinline__ void st16c(v4u v, __amdgpu_buffer_rsrc_t r, unsigned off) { __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 16); }
+// a slot's next record.  Plain (cached) load: a lane walks its run 16 bytes at a time and eight records share a 128-byte line.
+// (Measured against non-temporal loads: FETCH_SIZE and the epoch time are the same within the box-to-box spread.)
+#ifndef MFX_RES_REC_NT
+#define MFX_RES_REC_NT 0
+#endif
+__device__ __forceinline__ ResRec ldrec(const ResRec *p)
+{
+#if MFX_RES_REC_NT
+    return __builtin_bit_cast(ResRec, __builtin_nontemporal_load(reinterpret_cast<const v4i *>(p)));
+#else
+    return *p;
+#endif
+}
 __device__ __forceinline__ unsigned ldc_u32(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __device__ __forceinline__ double shfl64(double x, int src)
@@ -185,7 +198,7 @@ __device__ __forceinline__ int res_burst(const ResParams &P, int s, int &pos, in
     URec br{0, -2, 0.0};
     THdr bh; bh.bias = 0.0; bh.cnt = -1; bh.pad = 0;
     if (lane < nd) {
-        br = __builtin_bit_cast(URec, __builtin_nontemporal_load(reinterpret_cast<const v4i *>(rp_s + pos_s + lane)));
+        br = ldrec(rp_s + pos_s + lane);
         bh = __builtin_bit_cast(THdr, ld16c(rH, (unsigned)br.trav * 16u));
     }
     int total = 0;
@@ -208,7 +221,7 @@ __device__ __forceinline__ int res_burst(const ResParams &P, int s, int &pos, in
             // the NEXT window's records travel under this window's walk
             const int pos_n = pos_s + depth, nd_n = end_s - pos_n < D ? end_s - pos_n : D;
             URec brn{0, -2, 0.0};
-            if (lane < nd_n) brn = __builtin_bit_cast(URec, __builtin_nontemporal_load(reinterpret_cast<const v4i *>(rp_s + pos_n + lane)));
+            if (lane < nd_n) brn = ldrec(rp_s + pos_n + lane);
 #pragma unroll
             for (int i = 0; i < D; ++i)
                 if (i < depth && ing) *reinterpret_cast<d2 *>(ubuf + i * 2 * KP + 2 * q) = uu[i];
@@ -283,10 +296,10 @@ __device__ __forceinline__ int res_burst(const ResParams &P, int s, int &pos, in
         pos += total;
         h.cnt = -1;
         if (pos < end) {
-            rec = __builtin_bit_cast(URec, __builtin_nontemporal_load(reinterpret_cast<const v4i *>(rp + pos)));
+            rec = ldrec(rp + pos);
             h = __builtin_bit_cast(THdr, ld16c(rH, (unsigned)rec.trav * 16u));
         }
-        if (pos + 1 < end) nxt = __builtin_bit_cast(URec, __builtin_nontemporal_load(reinterpret_cast<const v4i *>(rp + pos + 1)));
+        if (pos + 1 < end) nxt = ldrec(rp + pos + 1);
     }
     return total;
 }
@@ -352,8 +365,8 @@ __global__ __launch_bounds__(64, STATIC ? ((NR <= 9 && !BURST) ? 3 : 2) : 4) voi
         const URec *rp = P.recs + base;
         URec rec{0, 0, 0.0}, nxt{0, 0, 0.0};
         // records are read once per epoch: non-temporal
-        if (pos < end) rec = __builtin_bit_cast(URec, __builtin_nontemporal_load(reinterpret_cast<const v4i *>(rp + pos)));
-        if (pos + 1 < end) nxt = __builtin_bit_cast(URec, __builtin_nontemporal_load(reinterpret_cast<const v4i *>(rp + pos + 1)));
+        if (pos < end) rec = ldrec(rp + pos);
+        if (pos + 1 < end) nxt = ldrec(rp + pos + 1);
         double rbv = have ? P.rb[my_ent] : 0.0;
         d2 vv[NR];
 #pragma unroll
@@ -407,7 +420,7 @@ __global__ __launch_bounds__(64, STATIC ? ((NR <= 9 && !BURST) ? 3 : 2) : 4) voi
                 st16c(__builtin_bit_cast(v4u, nh), rH, (unsigned)rec.trav * 16u);
                 ++pos;
                 rec = nxt;
-                if (pos + 1 < end) nxt = __builtin_bit_cast(URec, __builtin_nontemporal_load(reinterpret_cast<const v4i *>(rp + pos + 1)));
+                if (pos + 1 < end) nxt = ldrec(rp + pos + 1);
             }
             h.cnt = -1;
             if (more) h = __builtin_bit_cast(THdr, ld16c(rH, (unsigned)ntrav * 16u));

@@ -26,7 +26,10 @@ def traffic(fk, wk, line_file, out_name, cmd):
                        "tallied at their size: the read figure is an upper bound",
          "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "ratings_per_launch": ratings,
          "read_bytes_per_rating": rd / ratings, "write_bytes_per_rating": wr / ratings,
-         "read_bytes_per_rating_uncorrected": rd / 2 / ratings}
+         "read_bytes_per_rating_uncorrected": rd / 2 / ratings,
+         # the x2 applied ONLY to what is known to be fetched as 128-byte requests -- the travelling row of every rating (k = 64:
+         # 512 B, tallied as 256) -- and the rest (16-byte granule polls, records, run tables: 64-byte requests) at its tallied size
+         "read_bytes_per_rating_rows_corrected_only": rd / 2 / ratings + 256.0}
     json.dump(d, open(os.path.join(P, out_name), "w"), indent=1)
     print("%s: read %.0f B (uncorrected %.0f) + written %.0f B per rating" % (out_name, d["read_bytes_per_rating"],
                                                                              d["read_bytes_per_rating_uncorrected"], d["write_bytes_per_rating"]))

@@ -668,7 +668,8 @@ def main():
     else:
         v0 = v0_full
     my_nnz = my_r.shape[0]
-    plan = SgdPlan(my_idx, my_r, max(nu_local, 1), ni, k, storage=a.storage, epoch=a.epoch)
+    # (N > 1: the user-sharded averaging mode combines after every epoch through a hook and runs on the level schedule)
+    plan = SgdPlan(my_idx, my_r, max(nu_local, 1), ni, k, storage=a.storage, epoch=a.epoch if not multi else "levels")
     plan.set_factors(u0, v0, np.zeros(ni), np.zeros(max(nu_local, 1)))
     info = plan.info()
     kernel_name = plan.kernel_name(LINEAR)          # the instantiation the library launches, from the library

@@ -395,6 +395,34 @@ __global__ void k_res_pack(const int32_t *__restrict__ ks, const int32_t *__rest
         if (s == nnz - 1 || ks[s + 1] != e) hi[e] = (int32_t)s + 1;
     }
 }
+// links of the travelling chains in GROUPED positions (the Funk pass hands V[f,user] from a rating straight to the user's next one)
+__global__ void k_res_succ(const int32_t *__restrict__ ks, const int32_t *__restrict__ ps, int64_t nnz, int32_t *succ)
+{
+    for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < nnz; s += (int64_t)gridDim.x * blockDim.x)
+        succ[ps[s]] = (s + 1 < nnz && ks[s + 1] == ks[s]) ? ps[s + 1] : -1;
+}
+__global__ void k_res_firstp(const int32_t *__restrict__ ks, const int32_t *__restrict__ ps, int64_t nnz, int32_t *firstp)
+{
+    for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < nnz; s += (int64_t)gridDim.x * blockDim.x)
+        if (s == 0 || ks[s] != ks[s - 1]) firstp[ks[s]] = ps[s];
+}
+__global__ void k_res_gpos(const int32_t *__restrict__ ps, int64_t nnz, int32_t *gpos)
+{
+    for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < nnz; s += (int64_t)gridDim.x * blockDim.x) gpos[ps[s]] = (int32_t)s;
+}
+__global__ void k_res_next(const int32_t *__restrict__ ps, const int32_t *__restrict__ succ, const int32_t *__restrict__ gpos, int64_t nnz,
+                           int32_t *next)
+{
+    for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < nnz; s += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t q = succ[ps[s]];
+        next[s] = q >= 0 ? gpos[q] : -1;
+    }
+}
+__global__ void k_res_first_g(int32_t *firstp, const int32_t *__restrict__ gpos, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const int32_t q = firstp[i]; firstp[i] = q >= 0 ? gpos[q] : -1; }
+}
 }  // namespace
 
 namespace {
@@ -436,8 +464,10 @@ int res_max_degrees(const Rec *d_recs, int64_t nnz, int nu, int ni, int *max_use
     return MFX_OK;
 }
 
+// d_next (optional, [nnz]): grouped position of the NEXT rating of the same travelling entity, -1 at the end of its chain;
+// d_first_pos (optional, [n_trav]): grouped position of its first rating, -1 for an entity without ratings
 int res_build_device(const Rec *d_recs, int64_t nnz, int n_res, int n_trav, bool res_item, ResRec *d_out, int32_t *d_lo, int32_t *d_hi,
-                     int32_t *d_pos_of, int32_t *d_ent_of)
+                     int32_t *d_pos_of, int32_t *d_ent_of, int32_t *d_next, int32_t *d_first_pos)
 {
     if (nnz <= 0 || nnz >= ((int64_t)1 << 31) - 1) return fail(MFX_E_ARG, "res_build_device: unsupported size");
     hipStream_t st = stream();
@@ -456,7 +486,21 @@ int res_build_device(const Rec *d_recs, int64_t nnz, int n_res, int n_trav, bool
     MFX_HIP(sort_pairs(tmp, tmp_bytes, ktrav, ks, pos, ps, nnz, bits_for(n_trav), st));
     k_res_first<<<blocks, 256, 0, st>>>(ks, nnz, first);
     k_res_seq<<<blocks, 256, 0, st>>>(ks, ps, nnz, first, seq);
+    int32_t *succ = nullptr, *gpos = nullptr;
+    if (d_next) {
+        if (S.get(&succ, n) || S.get(&gpos, n)) return last_code();
+        k_res_succ<<<blocks, 256, 0, st>>>(ks, ps, nnz, succ);
+        if (d_first_pos) {
+            MFX_HIP(hipMemsetAsync(d_first_pos, 0xff, (size_t)n_trav * sizeof(int32_t), st));
+            k_res_firstp<<<blocks, 256, 0, st>>>(ks, ps, nnz, d_first_pos);
+        }
+    }
     MFX_HIP(sort_pairs(tmp, tmp_bytes, kres, ks, pos, ps, nnz, bits_for(n_res), st));
+    if (d_next) {
+        k_res_gpos<<<blocks, 256, 0, st>>>(ps, nnz, gpos);
+        k_res_next<<<blocks, 256, 0, st>>>(ps, succ, gpos, nnz, d_next);
+        if (d_first_pos) k_res_first_g<<<ceil_div(n_trav, 256), 256, 0, st>>>(d_first_pos, gpos, n_trav);
+    }
     MFX_HIP(hipMemsetAsync(d_lo, 0, (size_t)n_res * sizeof(int32_t), st));
     MFX_HIP(hipMemsetAsync(d_hi, 0, (size_t)n_res * sizeof(int32_t), st));
     k_res_pack<<<blocks, 256, 0, st>>>(ks, ps, nnz, d_recs, ktrav, seq, d_out, d_lo, d_hi);

@@ -52,12 +52,13 @@ int res_prepare(ResPlan **out, const int32_t *idx, const Rec *d_recs, int64_t nn
 // travelling entity's chain; lo / hi [n_res]: the entity's record range (0, 0 when it has none)
 int res_max_degrees(const Rec *d_recs, int64_t nnz, int nu, int ni, int *max_user_deg, int *max_item_deg);
 int res_build_device(const Rec *d_recs, int64_t nnz, int n_res, int n_trav, bool res_item, ResRec *d_out, int32_t *d_lo, int32_t *d_hi,
-                     int32_t *d_pos_of = nullptr, int32_t *d_ent_of = nullptr);
+                     int32_t *d_pos_of = nullptr, int32_t *d_ent_of = nullptr, int32_t *d_next = nullptr, int32_t *d_first_pos = nullptr);
 // ---- resident-side Funk pass (mfx_sgd_res.hip): lane = item, user values travel inside their 16-byte granules
 struct Res2Plan;
 int res2_prepare(Res2Plan **out, const Rec *d_recs, int64_t nnz, int nu, int ni, bool force);
 void res2_destroy(Res2Plan *rp);
 size_t res2_dev_bytes(const Res2Plan *rp);
+int res2_box_width(const Res2Plan *rp);
 int64_t res2_se_slots(const Res2Plan *rp);
 const double *res2_se_partials(const Res2Plan *rp);
 int res2_reset_cache(Res2Plan *rp);

@@ -55,6 +55,7 @@ struct ResParams {
 namespace {
 
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
@@ -766,7 +767,9 @@ struct Res2Params {
     double *cache;              // residual cache in the same (grouped) order
     const double *const *dyn;   // -> {uf, vf, trail} of the feature (K2Dyn layout: two pointers + a double)
     const double *ib, *ub;      // nullable (without_bias)
-    THdr *hdr;                  // [nu] {V[f,user], chain counter}
+    THdr *hdr;                  // [nu] {V[f,user], chain counter}                (granule form)
+    double *box;                // [nnz + 2] one 8-byte mailbox per grouped record  (mailbox form; recs[].seq = NEXT position)
+    const int32_t *first_pos;   // [nu] grouped position of the user's first rating, -1: none
     unsigned *ctl;
     double *se_item;
     int ni, nu, upd_u, upd_i, window, hot_deg, reg_extra;
@@ -900,6 +903,146 @@ __global__ __launch_bounds__(64) void k2_res(Res2Params P)
     if (item < P.ni) { uf[item] = x; P.se_item[item] = se; }
 }
 
+// ---- mailbox form ---------------------------------------------------------------------------------------------------------
+// The travelling value does not go back to a per-user granule that the next rating's lane has to find and poll: it is sent
+// straight to the user's NEXT rating.  Every grouped record has an 8-byte mailbox; a lane polls the mailbox of its own head
+// record -- and the mailboxes of one item are contiguous in the order the lane walks them, so ONE 16-byte request shows the head
+// and the rating after it.  A mailbox holds kBoxEmpty (a quiet-NaN payload no arithmetic produces from other inputs: the launch
+// refuses inputs that contain it) until the previous rating of that user -- or, for a user's first rating, the seeding kernel --
+// stores V[f,user] there with ONE 8-byte sc1 store: the data is the flag, nothing to drain first.  A user's last rating writes
+// V[f,user] itself.  Against the granule form: a ready rating costs half a poll request instead of one or more, a waiting lane
+// polls ITS OWN line (no crowd on a hot user's granule), and the look-ahead is free.
+constexpr unsigned long long kBoxEmpty = 0x7ff85eedb0c50001ull;
+
+__global__ void k2_box_fill(unsigned long long *box, int64_t n)
+{
+    for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) box[s] = kBoxEmpty;
+}
+__global__ void k2_box_seed(unsigned long long *box, const int32_t *__restrict__ first_pos, const double *const *dyn, int nu, int ni, unsigned *ctl)
+{
+    const Dyn2 *d = reinterpret_cast<const Dyn2 *>(dyn);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool clash = false;
+    if (i < nu) {
+        const unsigned long long b = __builtin_bit_cast(unsigned long long, d->vf[i]);
+        clash = b == kBoxEmpty;
+        const int32_t fp = first_pos[i];
+        if (fp >= 0) box[fp] = b;
+    }
+    if (i < ni) clash = clash || __builtin_bit_cast(unsigned long long, d->uf[i]) == kBoxEmpty;
+    if (clash) atomicOr(ctl + kCtlStatus, 1u);              // the pass is not applied (same path as a failed registration)
+}
+
+template <int W>   // mailboxes seen per poll: 2 (one request) or 4 (two requests)
+__global__ __launch_bounds__(64) void k2_res_box(Res2Params P)
+{
+    const int lane = threadIdx.x;
+    int ok = 1;
+    if (lane == 0) {
+        if (ldc_u32(P.ctl + kCtlStatus)) ok = 0;
+        else {
+            const unsigned want = gridDim.x + (unsigned)P.reg_extra;
+            unsigned v = atomicAdd(P.ctl + kCtlReg, 1u) + 1u;
+            int spins = 0;
+            while (v != want) {
+                if (v & kRegFail) { ok = 0; break; }
+                if (++spins > kSpinReg) {
+                    const unsigned old = atomicOr(P.ctl + kCtlReg, kRegFail);
+                    if (old != want) { ok = 0; atomicOr(P.ctl + kCtlStatus, 1u); }
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+                v = ldc_u32(P.ctl + kCtlReg);
+            }
+        }
+    }
+    if (!__builtin_amdgcn_readfirstlane(ok)) return;
+    if (blockIdx.x == 0 && lane == 0) atomicAdd(P.ctl + kCtlDone, 1u);
+    const Dyn2 *dyn = reinterpret_cast<const Dyn2 *>(P.dyn);
+    double *const uf = dyn->uf;
+    double *const vf = dyn->vf;
+    const double trail = dyn->trail;
+    const int item = blockIdx.x * 64 + lane;
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(P.box, 0, 0x7fffffff, 0x27000);
+    int pos = 0, end = 0;
+    double x = 0.0, se = 0.0, bi = 0.0;
+    if (item < P.ni) { pos = P.lo[item]; end = P.hi[item]; x = uf[item]; if (P.ib) bi = P.ib[item]; }
+    URec rec[W];
+    double c[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) { rec[i] = URec{0, -1, 0.0}; c[i] = 0.0; }
+    auto load_from = [&](int i0) {                              // records i0.. of the window (plain cached loads: sequential per lane)
+#pragma unroll
+        for (int i = 0; i < W; ++i)
+            if (i >= i0 && pos + i < end) { rec[i] = P.recs[pos + i]; c[i] = P.cache[pos + i]; }
+    };
+    load_from(0);
+    int spins = 0;
+    // W = 4: only a HOT item (eight times the average degree or more: the chains that bound a pass on skewed data) pays the second
+    // request; the others look at their head's pair like the W = 2 kernel
+    const bool wide = W > 2 && end - pos >= P.hot_deg;
+    auto apply = [&](const URec &q, double cq, double cf) {     // gd_estimator.pyx:750-761
+        const double mf = x;
+        double base;
+        if (P.ib) base = P.mu + bi + P.ub[q.trav];
+        else base = P.mu + 0.0 + 0.0;
+        const double p = funk_est(mf, cf, cq, base, trail, true);
+        const double err = q.r - p;
+        se += err * err;
+        const double un = mf + P.lr * (err * cf - P.K * mf), vn = cf + P.lr * (err * mf - P.K * cf);
+        const double out = P.upd_u ? vn : cf;
+        if (q.seq >= 0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, out), rB, (unsigned)q.seq * 8u, 0, 16);
+        else vf[q.trav] = out;                                  // the user's last rating of the pass
+        if (P.upd_i) x = un;
+    };
+    while (__any(pos < end)) {
+        const bool act = pos < end;
+        // the aligned group of W mailboxes that holds the head
+        unsigned long long m[W];
+#pragma unroll
+        for (int i = 0; i < W; ++i) m[i] = kBoxEmpty;
+        const int g0 = wide ? (pos & ~(W - 1)) : (pos & ~1), sh = pos - g0;
+        if (act) {
+#pragma unroll
+            for (int h = 0; h < W / 2; ++h) {
+                if (h > 0 && !wide) break;
+                const v4u t = ld16c(rB, (unsigned)(g0 + 2 * h) * 8u);
+                m[2 * h] = ((unsigned long long)t[1] << 32) | t[0];
+                m[2 * h + 1] = ((unsigned long long)t[3] << 32) | t[2];
+            }
+        }
+        int n = 0;
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < W; ++i) {                       // window slot i is mailbox sh + i of the group
+                unsigned long long b = kBoxEmpty;
+#pragma unroll
+                for (int w = 0; w < W; ++w) if (w == sh + i) b = m[w];
+                if (n == i && pos + i < end && b != kBoxEmpty) { apply(rec[i], c[i], __builtin_bit_cast(double, b)); ++n; }
+            }
+        }
+        const bool ready = n > 0;
+        if (ready) {
+            pos += n;
+#pragma unroll
+            for (int i = 0; i < W; ++i) {                       // shift the window by n
+                URec r2 = URec{0, -1, 0.0}; double c2 = 0.0;
+#pragma unroll
+                for (int w = 0; w < W; ++w) if (w == i + n) { r2 = rec[w]; c2 = c[w]; }
+                rec[i] = r2; c[i] = c2;
+            }
+            load_from(W - n);
+        }
+        if (!__any(ready)) {
+            if (++spins > kSpinRun || ((spins & 1023) == 0 && ldc_u32(P.ctl + kCtlStatus))) {
+                if (lane == 0) atomicOr(P.ctl + kCtlStatus, 3u);
+                break;
+            }
+        } else spins = 0;
+    }
+    if (item < P.ni) { uf[item] = x; P.se_item[item] = se; }
+}
+
 __global__ void k2_hdr_reset(THdr *hdr, const double *const *dyn, int n)
 {
     const double *vf = reinterpret_cast<const Dyn2 *>(dyn)->vf;
@@ -929,6 +1072,10 @@ __global__ __launch_bounds__(256) void k2_commit_res(Res2Params P, const int32_t
     }
 }
 // grouped cache -> the level-major cache of the other Funk kernels (a fallback in the middle of a run)
+__global__ void k2_set_next(URec *recs, const int32_t *__restrict__ next, int64_t nnz)
+{
+    for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < nnz; s += (int64_t)gridDim.x * blockDim.x) recs[s].seq = next[s];
+}
 __global__ void k2_cache_scatter(const double *src, const int32_t *pos_of, int64_t nnz, double *dst)
 {
     for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < nnz; s += (int64_t)gridDim.x * blockDim.x) dst[pos_of[s]] = src[s];
@@ -943,6 +1090,9 @@ struct Res2Plan {
     int32_t *d_lo = nullptr, *d_hi = nullptr, *d_pos_of = nullptr, *d_ent_of = nullptr;
     double *d_cache = nullptr, *d_se = nullptr;
     THdr *d_hdr = nullptr;
+    double *d_box = nullptr;            // mailbox form (box_w != 0): one mailbox per grouped record
+    int32_t *d_first = nullptr;
+    int box_w = 0;
     unsigned *d_ctl = nullptr;
     size_t dev_bytes = 0;
 };
@@ -950,7 +1100,7 @@ struct Res2Plan {
 void res2_destroy(Res2Plan *rp)
 {
     if (!rp) return;
-    void *ptrs[] = {rp->d_recs, rp->d_lo, rp->d_hi, rp->d_pos_of, rp->d_ent_of, rp->d_cache, rp->d_se, rp->d_hdr, rp->d_ctl};
+    void *ptrs[] = {rp->d_recs, rp->d_lo, rp->d_hi, rp->d_pos_of, rp->d_ent_of, rp->d_cache, rp->d_se, rp->d_hdr, rp->d_box, rp->d_first, rp->d_ctl};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     delete rp;
@@ -966,7 +1116,17 @@ int res2_prepare(Res2Plan **out, const Rec *d_recs, int64_t nnz, int nu, int ni,
     int dev = 0, occ = 0;
     MFX_HIP(hipGetDevice(&dev));
     MFX_HIP(hipGetDeviceProperties(&prop, dev));
-    MFX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k2_res, 64, 0));
+    // MFX_K2_BOX: 0 = granule form, 2 / 4 = mailbox form with that many mailboxes per poll
+    int box_w = env_i("MFX_K2_BOX", -1);
+    if (box_w != 0 && box_w != 2 && box_w != 4) {          // default: the wide kernel only where some item is hot (it costs 3 % on uniform data)
+        int mu_deg = 0, mi_deg = 0;
+        int rc0 = res_max_degrees(d_recs, nnz, nu, ni, &mu_deg, &mi_deg);
+        if (rc0) return rc0;
+        box_w = (int64_t)mi_deg >= 8 * (nnz / (ni > 0 ? ni : 1)) && mi_deg >= 64 ? 4 : 2;
+    }
+    if (nnz >= ((int64_t)1 << 28) - 8) box_w = 0;           // (mailbox offsets are 32-bit byte offsets)
+    const void *fn = box_w == 4 ? (const void *)k2_res_box<4> : box_w == 2 ? (const void *)k2_res_box<2> : (const void *)k2_res;
+    MFX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 64, 0));
     const int waves = ceil_div(ni, 64);
     if (occ <= 0 || waves > occ * prop.multiProcessorCount * 7 / 8) return MFX_OK;
     Res2Plan *rp = new (std::nothrow) Res2Plan();
@@ -984,13 +1144,25 @@ int res2_prepare(Res2Plan **out, const Rec *d_recs, int64_t nnz, int nu, int ni,
         return bail(last_code());
     if (hipMemset(rp->d_ctl, 0, kCtlWords * sizeof(unsigned)) != hipSuccess || hipMemset(rp->d_se, 0, (size_t)waves * 64 * 8) != hipSuccess)
         return bail(fail(MFX_E_HIP, "mfx_sgd_run_funk: %s", hipGetErrorString(hipGetLastError())));
-    int rc = res_build_device(d_recs, nnz, ni, nu, true, rp->d_recs, rp->d_lo, rp->d_hi, rp->d_pos_of, rp->d_ent_of);
+    rp->box_w = box_w;
+    int32_t *d_next = nullptr;
+    if (box_w) {
+        if (al((void **)&rp->d_box, (size_t)(nnz + 8) * 8) || al((void **)&rp->d_first, (size_t)nu * 4)) return bail(last_code());
+        if (hipMalloc((void **)&d_next, (size_t)nnz * 4) != hipSuccess) { (void)hipGetLastError(); return bail(fail(MFX_E_NOMEM, "hipMalloc(%zu bytes)", (size_t)nnz * 4)); }
+    }
+    int rc = res_build_device(d_recs, nnz, ni, nu, true, rp->d_recs, rp->d_lo, rp->d_hi, rp->d_pos_of, rp->d_ent_of, d_next, rp->d_first);
+    if (!rc && box_w) {
+        hipLaunchKernelGGL(k2_set_next, dim3(2048), dim3(256), 0, stream(), rp->d_recs, (const int32_t *)d_next, nnz);
+        if (hipStreamSynchronize(stream()) != hipSuccess) rc = fail(MFX_E_HIP, "mfx_sgd_run_funk: %s", hipGetErrorString(hipGetLastError()));
+    }
+    if (d_next) (void)hipFree(d_next);
     if (rc) return bail(rc);
     *out = rp;
     return MFX_OK;
 }
 
 size_t res2_dev_bytes(const Res2Plan *rp) { return rp ? rp->dev_bytes : 0; }
+int res2_box_width(const Res2Plan *rp) { return rp ? rp->box_w : 0; }
 int64_t res2_se_slots(const Res2Plan *rp) { return (int64_t)rp->waves * 64; }
 const double *res2_se_partials(const Res2Plan *rp) { return rp->d_se; }
 int res2_reset_cache(Res2Plan *rp)
@@ -1008,7 +1180,7 @@ static Res2Params res2_params(Res2Plan *rp, const void *d_dyn, const double *ib,
     Res2Params P;
     memset(&P, 0, sizeof(P));
     P.recs = rp->d_recs; P.lo = rp->d_lo; P.hi = rp->d_hi; P.cache = rp->d_cache; P.dyn = (const double *const *)d_dyn;
-    P.ib = ib; P.ub = ub; P.hdr = rp->d_hdr; P.ctl = rp->d_ctl; P.se_item = rp->d_se; P.ni = rp->ni; P.nu = rp->nu;
+    P.ib = ib; P.ub = ub; P.hdr = rp->d_hdr; P.box = rp->d_box; P.first_pos = rp->d_first; P.ctl = rp->d_ctl; P.se_item = rp->d_se; P.ni = rp->ni; P.nu = rp->nu;
     P.upd_u = upd_u; P.upd_i = upd_i; P.lr = lr; P.K = K; P.mu = mu;
     P.window = env_i("MFX_K2_WIN", 1);                     // 0: no look-ahead (A/B hook)
     P.reg_extra = test_reg_extra();
@@ -1020,6 +1192,16 @@ int res2_enqueue_pass(Res2Plan *rp, const void *d_dyn, const double *ib, const d
 {
     Res2Params P = res2_params(rp, d_dyn, ib, ub, mu, lr, K, upd_u, upd_i);
     MFX_HIP(hipMemsetAsync(rp->d_ctl + kCtlReg, 0, sizeof(unsigned), stream()));
+    if (rp->box_w) {
+        const int n = rp->nu > rp->ni ? rp->nu : rp->ni;
+        hipLaunchKernelGGL(k2_box_fill, dim3(2048), dim3(256), 0, stream(), (unsigned long long *)rp->d_box, rp->nnz + 8);
+        hipLaunchKernelGGL(k2_box_seed, dim3(ceil_div(n, 256)), dim3(256), 0, stream(), (unsigned long long *)rp->d_box, (const int32_t *)rp->d_first,
+                           P.dyn, rp->nu, rp->ni, rp->d_ctl);
+        if (rp->box_w == 4) hipLaunchKernelGGL(k2_res_box<4>, dim3(rp->waves), dim3(64), 0, stream(), P);
+        else hipLaunchKernelGGL(k2_res_box<2>, dim3(rp->waves), dim3(64), 0, stream(), P);
+        MFX_HIP(hipGetLastError());
+        return MFX_OK;
+    }
     hipLaunchKernelGGL(k2_hdr_reset, dim3(ceil_div(rp->nu, 256)), dim3(256), 0, stream(), rp->d_hdr, P.dyn, rp->nu);
     hipLaunchKernelGGL(k2_res, dim3(rp->waves), dim3(64), 0, stream(), P);
     hipLaunchKernelGGL(k2_hdr_finish, dim3(ceil_div(rp->nu, 256)), dim3(256), 0, stream(), (const THdr *)rp->d_hdr, P.dyn, rp->nu, (const unsigned *)rp->d_ctl);

@@ -1089,11 +1089,9 @@ int funk_core(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_
     if (p->k2r_state == 0 && !hk) {
         p->k2r_state = -1;
         const int want = env_int("MFX_K2_RES", -1);          // 0 = off, 1 = forced (also tiny problems), default: by size
-        // measured at cfg 2: levels of ~16 K ratings (shuffled order) 1.25 ms per pass here against 1.35 on the
-        // single-XCD pass; levels of ~37 K (balanced order) 1.08 against 1.04 -- fat levels stay with the XCD pass where it applies
-        const bool fat = p->n_levels > 0 && p->nnz / p->n_levels >= 24576 && env_int("MFX_K2_XCD", -1) != 0 &&
-                         ceil_div((int64_t)p->nu, (int64_t)kXGroups) + 1 <= (150 * 1024) / 8;
-        if (want == 1 || (want != 0 && !fat)) {
+        // measured at cfg 2, mailbox form: shuffled order 0.98 ms per pass against 1.35 on the single-XCD pass,
+        // balanced order (levels of ~37 K) 0.76 against 1.03 -- the resident-side pass wherever every item gets a lane
+        if (want != 0) {
             if (res2_prepare(&p->res2, p->d_recs, p->nnz, p->nu, p->ni, want == 1) != MFX_OK) (void)hipGetLastError();
             if (p->res2) { p->k2r_state = 1; p->dev_bytes += res2_dev_bytes(p->res2); }
         }

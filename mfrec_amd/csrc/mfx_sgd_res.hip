@@ -933,7 +933,7 @@ __global__ void k2_box_seed(unsigned long long *box, const int32_t *__restrict__
     if (clash) atomicOr(ctl + kCtlStatus, 1u);              // the pass is not applied (same path as a failed registration)
 }
 
-template <int W>   // mailboxes seen per poll: 2 (one request) or 4 (two requests)
+template <int W>   // mailboxes seen per poll: 2 (one request); 4, 8: hot items look further (two / four requests)
 __global__ __launch_bounds__(64) void k2_res_box(Res2Params P)
 {
     const int lane = threadIdx.x;
@@ -1118,14 +1118,14 @@ int res2_prepare(Res2Plan **out, const Rec *d_recs, int64_t nnz, int nu, int ni,
     MFX_HIP(hipGetDeviceProperties(&prop, dev));
     // MFX_K2_BOX: 0 = granule form, 2 / 4 = mailbox form with that many mailboxes per poll
     int box_w = env_i("MFX_K2_BOX", -1);
-    if (box_w != 0 && box_w != 2 && box_w != 4) {          // default: the wide kernel only where some item is hot (it costs 3 % on uniform data)
+    if (box_w != 0 && box_w != 2 && box_w != 4 && box_w != 8) {          // default: the wide kernel only where some item is hot (it costs 3 % on uniform data)
         int mu_deg = 0, mi_deg = 0;
         int rc0 = res_max_degrees(d_recs, nnz, nu, ni, &mu_deg, &mi_deg);
         if (rc0) return rc0;
-        box_w = (int64_t)mi_deg >= 8 * (nnz / (ni > 0 ? ni : 1)) && mi_deg >= 64 ? 4 : 2;
+        box_w = (int64_t)mi_deg >= 8 * (nnz / (ni > 0 ? ni : 1)) && mi_deg >= 64 ? 8 : 2;
     }
     if (nnz >= ((int64_t)1 << 28) - 8) box_w = 0;           // (mailbox offsets are 32-bit byte offsets)
-    const void *fn = box_w == 4 ? (const void *)k2_res_box<4> : box_w == 2 ? (const void *)k2_res_box<2> : (const void *)k2_res;
+    const void *fn = box_w == 8 ? (const void *)k2_res_box<8> : box_w == 4 ? (const void *)k2_res_box<4> : box_w == 2 ? (const void *)k2_res_box<2> : (const void *)k2_res;
     MFX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 64, 0));
     const int waves = ceil_div(ni, 64);
     if (occ <= 0 || waves > occ * prop.multiProcessorCount * 7 / 8) return MFX_OK;
@@ -1197,7 +1197,8 @@ int res2_enqueue_pass(Res2Plan *rp, const void *d_dyn, const double *ib, const d
         hipLaunchKernelGGL(k2_box_fill, dim3(2048), dim3(256), 0, stream(), (unsigned long long *)rp->d_box, rp->nnz + 8);
         hipLaunchKernelGGL(k2_box_seed, dim3(ceil_div(n, 256)), dim3(256), 0, stream(), (unsigned long long *)rp->d_box, (const int32_t *)rp->d_first,
                            P.dyn, rp->nu, rp->ni, rp->d_ctl);
-        if (rp->box_w == 4) hipLaunchKernelGGL(k2_res_box<4>, dim3(rp->waves), dim3(64), 0, stream(), P);
+        if (rp->box_w == 8) hipLaunchKernelGGL(k2_res_box<8>, dim3(rp->waves), dim3(64), 0, stream(), P);
+        else if (rp->box_w == 4) hipLaunchKernelGGL(k2_res_box<4>, dim3(rp->waves), dim3(64), 0, stream(), P);
         else hipLaunchKernelGGL(k2_res_box<2>, dim3(rp->waves), dim3(64), 0, stream(), P);
         MFX_HIP(hipGetLastError());
         return MFX_OK;

@@ -1,7 +1,8 @@
-"""GPU: the resident-side Funk pass (mfx_sgd_res.hip k2_res: ONE persistent launch per feature-epoch over every CU, a lane
-owns an item and keeps U[f,item] in a register, V[f,user] travels inside its 16-byte {value, chain counter} granule) must give
-the SAME BITS as the oracle's sequential loops (gd_estimator.pyx:691-779, :489-582, :588-685).  It is the default from 65 536
-ratings on; forced here (MFX_K2_RES=1) also on tiny problems."""
+"""GPU: the resident-side Funk pass (mfx_sgd_res.hip: ONE persistent launch per feature-epoch over every CU, a lane owns an item and
+keeps U[f,item] in a register) must give the SAME BITS as the oracle's sequential loops (gd_estimator.pyx:691-779, :489-582,
+:588-685) -- in its mailbox form (k2_res_box: V[f,user] is sent straight to the 8-byte mailbox of the user's next rating; 2, 4 or 8
+mailboxes per poll) and in its granule form (k2_res: V[f,user] travels inside a per-user 16-byte {value, chain counter} granule).
+It is the default from 65 536 ratings on; forced here (MFX_K2_RES=1) also on tiny problems, every test in every form."""
 import numpy as np
 import pytest
 
@@ -10,13 +11,20 @@ from mfrec_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def _force(monkeypatch):
+@pytest.fixture(autouse=True, params=["mailbox-auto", "mailbox-2", "mailbox-4", "mailbox-8", "granule"])
+def _force(monkeypatch, request):
     from mfrec_amd import _shim as S
     from mfrec_amd import build as B
     B.build(verbose=False)
     S.init(0)
     monkeypatch.setenv("MFX_K2_RES", "1")
+    form = request.param
+    if form == "granule":
+        monkeypatch.setenv("MFX_K2_BOX", "0")
+    elif form != "mailbox-auto":
+        monkeypatch.setenv("MFX_K2_BOX", form.split("-")[1])
+    else:
+        monkeypatch.delenv("MFX_K2_BOX", raising=False)
 
 
 @pytest.mark.parametrize("nu,ni,nnz,k", [(3000, 2000, 200000, 3), (50000, 700, 400000, 2), (37, 29, 600, 4),
@@ -137,3 +145,22 @@ def test_goldens_through_the_resident_pass(golden):
         G.estimator_loop_with_bias_dev(E, E, 1e9, k, float(g["p_init"]), float(g["p_lr"]), 0.0, 0.0, float(g["p_K"]), float(g["p_mu"]),
                                        u, v, g["in_idx"], g["in_r"], g["in_ib"], g["in_ub"], 60, 40, *gate)
         assert np.array_equal(u, g["out_u_" + tag]) and np.array_equal(v, g["out_v_" + tag]), tag
+
+
+def test_input_holding_the_empty_mailbox_pattern_is_served_by_the_launch_path():
+    """The mailbox form marks an empty mailbox by ONE quiet-NaN payload; a factor that holds exactly these bits (here: the
+    V column of a user without ratings, so no arithmetic ever sees it) must not be mistaken for it -- the seeding kernel
+    notices, the pass is not applied and the run goes on with one launch per level: same bits as the oracle."""
+    from mfrec_amd.plan import SgdPlan
+    from oracle import oracle as O
+    nu, ni, nnz, k = 3000, 900, 120000, 3
+    idx, r = synth.make_ratings(nu - 1, ni, nnz, seed=9)           # user nu-1 has no ratings
+    u, v = synth.init_const(k, ni), synth.init_const(k, nu)
+    v.view(np.uint64)[:, nu - 1] = 0x7ff85eedb0c50001
+    u2, v2 = u.copy(), v.copy()
+    with SgdPlan(idx, r, nu, ni, k) as p:
+        p.set_factors(u, v)
+        p.run_funk(2, 1e9, 0.1, 0.001, 0.05)
+        p.get_factors(u, v)
+    O.estimator_loop_without_bias(2, 2, 1e9, k, 0.1, 0.001, 0.05, u2, v2, idx, r, nu, ni)
+    assert np.array_equal(u.view(np.uint64), u2.view(np.uint64)) and np.array_equal(v.view(np.uint64), v2.view(np.uint64))

@@ -770,6 +770,8 @@ struct Res2Params {
     THdr *hdr;                  // [nu] {V[f,user], chain counter}                (granule form)
     double *box;                // [nnz + 2] one 8-byte mailbox per grouped record  (mailbox form; recs[].seq = NEXT position)
     const int32_t *first_pos;   // [nu] grouped position of the user's first rating, -1: none
+    const int32_t *order;       // hot-wave form: [ni] items, the n_hot hot ones first (a WAVE each), then the others (a lane each); else null
+    int n_hot;
     unsigned *ctl;
     double *se_item;
     int ni, nu, upd_u, upd_i, window, hot_deg, reg_extra;
@@ -933,6 +935,86 @@ __global__ void k2_box_seed(unsigned long long *box, const int32_t *__restrict__
     if (clash) atomicOr(ctl + kCtlStatus, 1u);              // the pass is not applied (same path as a failed registration)
 }
 
+
+// ---- hot-wave role (skewed data) ------------------------------------------------------------------------------------------
+// On power-law data a pass is as long as the hottest item's chain (MovieLens-10M shape: 39 K ratings, Zipf-0.8 over cfg 2's shape:
+// 254 K), and a LANE walks its chain at one poll round trip per one or two ratings (~0.5 us per rating).  Here a hot item owns a
+// whole WAVE: lane j holds the record, cache word and mailbox of the item's rating pos + j -- contiguous, one coalesced request
+// each --, the leading run of filled mailboxes is walked by ONE uniform loop (values by v_readlane, U[f,item] in a register of
+// every lane: the reference's operations in the reference's order, gd_estimator.pyx:750-761), lane i keeps rating i's new
+// V[f,user] and the 64 results leave in one store instruction.  The next window's records, cache words and mailboxes are requested
+// BEFORE the walk (a filled mailbox stays filled; an empty one ends the run and is polled again), so a streak costs no round trip
+// at all: ~0.1 us per rating.  Same bits as the lane form.
+__device__ __forceinline__ unsigned long long ld_box8(__amdgpu_buffer_rsrc_t rB, unsigned off)
+{
+    const v2u t = __builtin_amdgcn_raw_buffer_load_b64(rB, off, 0, 16);
+    return ((unsigned long long)t[1] << 32) | t[0];
+}
+__device__ __forceinline__ void k2_hot_role(const Res2Params &P, int item, __amdgpu_buffer_rsrc_t rB, double *uf, double *vf, double trail)
+{
+    const int lane = threadIdx.x;
+    int pos = P.lo[item];
+    const int end = P.hi[item];
+    double x = uf[item], se = 0.0;
+    const double bi = P.ib ? P.ib[item] : 0.0;
+    URec rec{0, -1, 0.0};
+    double c = 0.0, ubv = 0.0;
+    unsigned long long m = kBoxEmpty;
+    if (pos + lane < end) {
+        rec = P.recs[pos + lane];
+        c = P.cache[pos + lane];
+        m = ld_box8(rB, (unsigned)(pos + lane) * 8u);
+        if (P.ib) ubv = P.ub[rec.trav];
+    }
+    int spins = 0;
+    while (pos < end) {
+        const unsigned long long okm = __ballot(pos + lane < end && m != kBoxEmpty);
+        const int depth = (okm == ~0ull) ? 64 : __builtin_ctzll(~okm);      // leading filled mailboxes of the window
+        if (depth == 0) {
+            if (++spins > kSpinRun || ((spins & 1023) == 0 && ldc_u32(P.ctl + kCtlStatus))) {
+                if (lane == 0) atomicOr(P.ctl + kCtlStatus, 3u);
+                return;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            if (pos + lane < end) m = ld_box8(rB, (unsigned)(pos + lane) * 8u);
+            continue;
+        }
+        spins = 0;
+        // the next window travels under the walk
+        const int np = pos + depth;
+        URec recn{0, -1, 0.0};
+        double cn = 0.0, ubn = 0.0;
+        unsigned long long mn = kBoxEmpty;
+        if (np + lane < end) {
+            recn = P.recs[np + lane];
+            cn = P.cache[np + lane];
+            mn = ld_box8(rB, (unsigned)(np + lane) * 8u);
+        }
+        double out = 0.0;
+        for (int i = 0; i < depth; ++i) {
+            const double cf = readlane64(__builtin_bit_cast(double, m), i), cq = readlane64(c, i), rr = readlane64(rec.r, i);
+            const double mf = x;
+            double base;
+            if (P.ib) base = P.mu + bi + readlane64(ubv, i);    // gd_estimator.pyx:553-554
+            else base = P.mu + 0.0 + 0.0;
+            const double p = funk_est(mf, cf, cq, base, trail, true);
+            const double err = rr - p;
+            se += err * err;
+            const double un = mf + P.lr * (err * cf - P.K * mf), vn = cf + P.lr * (err * mf - P.K * cf);
+            if (lane == i) out = P.upd_u ? vn : cf;
+            if (P.upd_i) x = un;
+        }
+        if (lane < depth) {
+            if (rec.seq >= 0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, out), rB, (unsigned)rec.seq * 8u, 0, 16);
+            else vf[rec.trav] = out;                            // the user's last rating of the pass
+        }
+        if (P.ib && np + lane < end) ubn = P.ub[recn.trav];
+        rec = recn; c = cn; m = mn; ubv = ubn;
+        pos = np;
+    }
+    if (lane == 0) { uf[item] = x; P.se_item[item] = se; }
+}
+
 template <int W>   // mailboxes seen per poll: 2 (one request); 4, 8: hot items look further (two / four requests)
 __global__ __launch_bounds__(64) void k2_res_box(Res2Params P)
 {
@@ -962,8 +1044,16 @@ __global__ __launch_bounds__(64) void k2_res_box(Res2Params P)
     double *const uf = dyn->uf;
     double *const vf = dyn->vf;
     const double trail = dyn->trail;
-    const int item = blockIdx.x * 64 + lane;
     const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(P.box, 0, 0x7fffffff, 0x27000);
+    int item = blockIdx.x * 64 + lane;
+    if (P.order) {                                              // hot-wave form: the first n_hot waves own one hot item each
+        if ((int)blockIdx.x < P.n_hot) {
+            k2_hot_role(P, P.order[blockIdx.x], rB, uf, vf, trail);
+            return;
+        }
+        const int64_t o = (int64_t)P.n_hot + ((int64_t)blockIdx.x - P.n_hot) * 64 + lane;
+        item = o < P.ni ? P.order[o] : P.ni;
+    }
     int pos = 0, end = 0;
     double x = 0.0, se = 0.0, bi = 0.0;
     if (item < P.ni) { pos = P.lo[item]; end = P.hi[item]; x = uf[item]; if (P.ib) bi = P.ib[item]; }
@@ -1092,6 +1182,8 @@ struct Res2Plan {
     THdr *d_hdr = nullptr;
     double *d_box = nullptr;            // mailbox form (box_w != 0): one mailbox per grouped record
     int32_t *d_first = nullptr;
+    int32_t *d_order = nullptr;         // hot-wave form: the items, hot ones first
+    int n_hot = 0, hot_deg = 0;
     int box_w = 0;
     unsigned *d_ctl = nullptr;
     size_t dev_bytes = 0;
@@ -1100,7 +1192,7 @@ struct Res2Plan {
 void res2_destroy(Res2Plan *rp)
 {
     if (!rp) return;
-    void *ptrs[] = {rp->d_recs, rp->d_lo, rp->d_hi, rp->d_pos_of, rp->d_ent_of, rp->d_cache, rp->d_se, rp->d_hdr, rp->d_box, rp->d_first, rp->d_ctl};
+    void *ptrs[] = {rp->d_recs, rp->d_lo, rp->d_hi, rp->d_pos_of, rp->d_ent_of, rp->d_cache, rp->d_se, rp->d_hdr, rp->d_box, rp->d_first, rp->d_order, rp->d_ctl};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     delete rp;
@@ -1128,7 +1220,8 @@ int res2_prepare(Res2Plan **out, const Rec *d_recs, int64_t nnz, int nu, int ni,
     const void *fn = box_w == 8 ? (const void *)k2_res_box<8> : box_w == 4 ? (const void *)k2_res_box<4> : box_w == 2 ? (const void *)k2_res_box<2> : (const void *)k2_res;
     MFX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 64, 0));
     const int waves = ceil_div(ni, 64);
-    if (occ <= 0 || waves > occ * prop.multiProcessorCount * 7 / 8) return MFX_OK;
+    const int wave_budget = occ > 0 ? occ * prop.multiProcessorCount * 7 / 8 : 0;
+    if (occ <= 0 || waves > wave_budget) return MFX_OK;
     Res2Plan *rp = new (std::nothrow) Res2Plan();
     if (!rp) return fail(MFX_E_NOMEM, "mfx_sgd_run_funk: out of host memory");
     rp->nu = nu; rp->ni = ni; rp->nnz = nnz; rp->waves = waves;
@@ -1157,13 +1250,54 @@ int res2_prepare(Res2Plan **out, const Rec *d_recs, int64_t nnz, int nu, int ni,
     }
     if (d_next) (void)hipFree(d_next);
     if (rc) return bail(rc);
+    // ---- hot-wave form (mailbox form, skewed data): the items whose chains would bound the pass get a wave each ----------------
+    // MFX_K2_HOT: 0 = off, n > 0 = every item with n ratings or more (tests, tuning); default: items with at least an eighth of
+    // the largest degree (and 1 024 ratings), when that degree is 4 096 or more and eight times the average
+    if (box_w) {
+        const int henv = env_i("MFX_K2_HOT", -1);
+        std::vector<int32_t> lo((size_t)ni), hi((size_t)ni);
+        if (henv != 0 && (hipMemcpy(lo.data(), rp->d_lo, (size_t)ni * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                          hipMemcpy(hi.data(), rp->d_hi, (size_t)ni * 4, hipMemcpyDeviceToHost) != hipSuccess))
+            return bail(fail(MFX_E_HIP, "mfx_sgd_run_funk: %s", hipGetErrorString(hipGetLastError())));
+        int thr = 0;
+        if (henv > 0) thr = henv;
+        else if (henv < 0) {
+            int maxd = 0;
+            for (int i = 0; i < ni; ++i) maxd = std::max(maxd, hi[(size_t)i] - lo[(size_t)i]);
+            if (maxd >= 4096 && (int64_t)maxd >= 8 * (nnz / ni)) thr = std::max(1024, maxd / 8);
+        }
+        if (thr > 0) {
+            std::vector<int32_t> hot;
+            for (int i = 0; i < ni; ++i)
+                if (hi[(size_t)i] - lo[(size_t)i] >= thr) hot.push_back(i);
+            std::stable_sort(hot.begin(), hot.end(), [&](int32_t a, int32_t b) { return hi[(size_t)a] - lo[(size_t)a] > hi[(size_t)b] - lo[(size_t)b]; });
+            size_t cap = 2048;                                // (a wave per hot item: the hottest first)
+            while (cap > 0 && (int64_t)cap + ceil_div((int64_t)ni - (int64_t)std::min(cap, hot.size()), (int64_t)64) > wave_budget) cap /= 2;
+            if (hot.size() > cap) hot.resize(cap);
+            if (!hot.empty()) {
+                std::vector<unsigned char> is_hot((size_t)ni, 0);
+                for (int32_t h : hot) is_hot[(size_t)h] = 1;
+                std::vector<int32_t> order(hot);
+                for (int i = 0; i < ni; ++i)
+                    if (!is_hot[(size_t)i]) order.push_back(i);
+                if (al((void **)&rp->d_order, (size_t)ni * 4)) return bail(last_code());
+                if (hipMemcpy(rp->d_order, order.data(), (size_t)ni * 4, hipMemcpyHostToDevice) != hipSuccess)
+                    return bail(fail(MFX_E_HIP, "mfx_sgd_run_funk: %s", hipGetErrorString(hipGetLastError())));
+                rp->n_hot = (int)hot.size();
+                rp->hot_deg = thr;
+                rp->waves = rp->n_hot + ceil_div(ni - rp->n_hot, 64);
+            }
+        }
+    }
     *out = rp;
     return MFX_OK;
 }
 
 size_t res2_dev_bytes(const Res2Plan *rp) { return rp ? rp->dev_bytes : 0; }
 int res2_box_width(const Res2Plan *rp) { return rp ? rp->box_w : 0; }
-int64_t res2_se_slots(const Res2Plan *rp) { return (int64_t)rp->waves * 64; }
+int res2_waves(const Res2Plan *rp) { return rp ? rp->waves : 0; }
+int res2_hot_waves(const Res2Plan *rp) { return rp ? rp->n_hot : 0; }
+int64_t res2_se_slots(const Res2Plan *rp) { return (int64_t)ceil_div(rp->ni, 64) * 64; }      // indexed by item
 const double *res2_se_partials(const Res2Plan *rp) { return rp->d_se; }
 int res2_reset_cache(Res2Plan *rp)
 {
@@ -1180,7 +1314,7 @@ static Res2Params res2_params(Res2Plan *rp, const void *d_dyn, const double *ib,
     Res2Params P;
     memset(&P, 0, sizeof(P));
     P.recs = rp->d_recs; P.lo = rp->d_lo; P.hi = rp->d_hi; P.cache = rp->d_cache; P.dyn = (const double *const *)d_dyn;
-    P.ib = ib; P.ub = ub; P.hdr = rp->d_hdr; P.box = rp->d_box; P.first_pos = rp->d_first; P.ctl = rp->d_ctl; P.se_item = rp->d_se; P.ni = rp->ni; P.nu = rp->nu;
+    P.ib = ib; P.ub = ub; P.hdr = rp->d_hdr; P.box = rp->d_box; P.first_pos = rp->d_first; P.order = rp->d_order; P.n_hot = rp->n_hot; P.ctl = rp->d_ctl; P.se_item = rp->d_se; P.ni = rp->ni; P.nu = rp->nu;
     P.upd_u = upd_u; P.upd_i = upd_i; P.lr = lr; P.K = K; P.mu = mu;
     P.window = env_i("MFX_K2_WIN", 1);                     // 0: no look-ahead (A/B hook)
     P.reg_extra = test_reg_extra();

@@ -2,6 +2,8 @@
 keeps U[f,item] in a register) must give the SAME BITS as the oracle's sequential loops (gd_estimator.pyx:691-779, :489-582,
 :588-685) -- in its mailbox form (k2_res_box: V[f,user] is sent straight to the 8-byte mailbox of the user's next rating; 2, 4 or 8
 mailboxes per poll) and in its granule form (k2_res: V[f,user] travels inside a per-user 16-byte {value, chain counter} granule).
+On skewed data the items whose chains would bound the pass own a whole WAVE each (k2_hot_role: 64 mailboxes per poll, one
+uniform walk); forced here by MFX_K2_HOT=<degree>.
 It is the default from 65 536 ratings on; forced here (MFX_K2_RES=1) also on tiny problems, every test in every form."""
 import numpy as np
 import pytest
@@ -11,7 +13,7 @@ from mfrec_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["mailbox-auto", "mailbox-2", "mailbox-4", "mailbox-8", "granule"])
+@pytest.fixture(autouse=True, params=["mailbox-auto", "mailbox-2", "mailbox-4", "mailbox-8", "granule", "hot-1", "hot-40"])
 def _force(monkeypatch, request):
     from mfrec_amd import _shim as S
     from mfrec_amd import build as B
@@ -19,7 +21,13 @@ def _force(monkeypatch, request):
     S.init(0)
     monkeypatch.setenv("MFX_K2_RES", "1")
     form = request.param
-    if form == "granule":
+    monkeypatch.delenv("MFX_K2_HOT", raising=False)
+    if form.startswith("hot-"):
+        # hot-wave role of the mailbox form: every item with that many ratings or more owns a whole wave (up to 2 048 of them,
+        # the hottest first); the rest stay one lane each.  hot-1: (almost) everything through the wave role; hot-40: a mix
+        monkeypatch.setenv("MFX_K2_HOT", form.split("-")[1])
+        monkeypatch.delenv("MFX_K2_BOX", raising=False)
+    elif form == "granule":
         monkeypatch.setenv("MFX_K2_BOX", "0")
     elif form != "mailbox-auto":
         monkeypatch.setenv("MFX_K2_BOX", form.split("-")[1])

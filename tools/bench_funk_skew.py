@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Funk passes on skewed data, resident-side pass in its granule form (MFX_K2_BOX=0) against the mailbox form (2 / 4 mailboxes per poll):
+"""Funk passes on skewed data, resident-side pass in its granule form (MFX_K2_BOX=0) against the mailbox form (2 / 4 / 8 mailboxes per poll;
+a trailing "h", e.g. 8h, or "auto": with the hot-wave role where the plan chooses it -- without the "h" it is switched off, MFX_K2_HOT=0):
 (a) the MovieLens-10M-shaped synthetic of bench_ml10m_shape.py, (b) Zipf-0.8 item degrees over cfg 2's shape, (c) cfg 2 uniform."""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -36,8 +37,12 @@ for make in (uniform, ml10m, zipf08):
     nnz = idx.shape[0]
     r = rs.randint(1, 6, nnz).astype(np.float64)
     outs = {}
-    for box in sys.argv[1:] or ["0", "2", "4"]:
-        os.environ["MFX_K2_BOX"] = box
+    for box in sys.argv[1:] or ["0", "2", "8", "auto"]:
+        os.environ.pop("MFX_K2_BOX", None); os.environ.pop("MFX_K2_HOT", None)
+        if box != "auto":
+            os.environ["MFX_K2_BOX"] = box.rstrip("h")
+            if not box.endswith("h"):
+                os.environ["MFX_K2_HOT"] = "0"
         with SgdPlan(idx, r, nu, ni, k) as p:
             u, v = synth.init_const(k, ni), synth.init_const(k, nu)
             p.set_factors(u, v)

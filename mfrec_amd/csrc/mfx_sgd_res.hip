@@ -29,6 +29,7 @@
 #include <string.h>
 #include <algorithm>
 #include <chrono>
+#include <type_traits>
 #include <vector>
 #include "mfx_common.h"
 #include "mfx_sgd_internal.h"
@@ -533,9 +534,11 @@ int ralloc(ResPlan *rp, T **ptr, size_t n)
 // plus 20 line operations per rating at ~67 G lines/s.
 // (levels too small for a launch of their own run in the tail kernel: 2.47 us each)
 static double est_level_ms(int64_t nnz, int64_t levels) { return levels * (nnz / levels >= 128 ? 3.7e-3 : 2.47e-3) + nnz * 0.30e-6; }
-static double est_res_ms(int64_t nnz, int64_t levels, bool stat)
+// (grouped = user-major input on the static binding: the travelling user's hops follow each other closely -- measured 3.8 us per
+//  level at cfg 2 against 4.15 on the ticket binding, tools/k1_pipe.hip's reference runs, profiles/r03_k1_pipe_cfg2_user_major.log)
+static double est_res_ms(int64_t nnz, int64_t levels, bool stat, bool grouped = false)
 {
-    const double chain = levels * (stat ? 4.6e-3 : 4.15e-3), stream = nnz * (stat ? 0.30e-6 : 0.265e-6);
+    const double chain = levels * (stat ? (grouped ? 3.8e-3 : 4.6e-3) : 4.15e-3), stream = nnz * (stat ? 0.30e-6 : 0.265e-6);
     return chain > stream ? chain : stream;
 }
 
@@ -609,7 +612,7 @@ int res_prepare(ResPlan **out, const int32_t *idx, const Rec *d_recs, int64_t nn
     const bool static_ok = waves_s > 0 && (int64_t)waves_s * Bs >= n_res && (int64_t)n_trav * k * 8 < ((int64_t)1 << 31);
     const double e_level = est_level_ms(nnz, n_levels);
     const double e_ticket = ticket_ok ? est_res_ms(nnz, n_levels, false) : 1e30;
-    double e_static = static_ok ? est_res_ms(nnz, n_levels, true) : 1e30;
+    double e_static = static_ok ? est_res_ms(nnz, n_levels, true, grouped && res_item) : 1e30;
     // ---- skewed data: the chain is a hot entity's own run.  When that entity is on the resident side, the burst variant walks it
     //      eight ratings per step (measured ~0.7 us per rating against 2.1 without, 2.47 per level in the tail kernel); a hot
     //      TRAVELLING entity hops from wave to wave at the full step.  MFX_K1_BURST = 0 / 1: off / forced (tuning, tests).
@@ -990,20 +993,31 @@ __device__ __forceinline__ void k2_hot_role(const Res2Params &P, int item, __amd
             cn = P.cache[np + lane];
             mn = ld_box8(rB, (unsigned)(np + lane) * 8u);
         }
+        // what an estimate starts from (gd_estimator.pyx:38-73, :553-554) does not depend on the chain: formed by every lane for its
+        // own rating before the walk
+        const double base = P.ib ? (P.mu + bi + ubv) : (P.mu + 0.0 + 0.0);
+        const double start = (c > 0) ? c : base;
+        const double mv = __builtin_bit_cast(double, m);
         double out = 0.0;
-        for (int i = 0; i < depth; ++i) {
-            const double cf = readlane64(__builtin_bit_cast(double, m), i), cq = readlane64(c, i), rr = readlane64(rec.r, i);
-            const double mf = x;
-            double base;
-            if (P.ib) base = P.mu + bi + readlane64(ubv, i);    // gd_estimator.pyx:553-554
-            else base = P.mu + 0.0 + 0.0;
-            const double p = funk_est(mf, cf, cq, base, trail, true);
-            const double err = rr - p;
-            se += err * err;
-            const double un = mf + P.lr * (err * cf - P.K * mf), vn = cf + P.lr * (err * mf - P.K * cf);
-            if (lane == i) out = P.upd_u ? vn : cf;
-            if (P.upd_i) x = un;
-        }
+        auto walk = [&](auto both) {
+            constexpr bool BOTH = decltype(both)::value;         // both update gates on: the common case without selects
+            for (int i = 0; i < depth; ++i) {
+                const double cf = readlane64(mv, i), s0 = readlane64(start, i), rr = readlane64(rec.r, i);
+                const double mf = x;
+                double sum = s0;                                 // funk_est(), trailing features included
+                sum += mf * cf;
+                sum = clamp15r(sum);
+                sum += trail;
+                sum = clamp15r(sum);
+                const double err = rr - sum;
+                se += err * err;
+                const double un = mf + P.lr * (err * cf - P.K * mf), vn = cf + P.lr * (err * mf - P.K * cf);
+                if (lane == i) out = (BOTH || P.upd_u) ? vn : cf;
+                if (BOTH || P.upd_i) x = un;
+            }
+        };
+        if (P.upd_u && P.upd_i) walk(std::true_type{});
+        else walk(std::false_type{});
         if (lane < depth) {
             if (rec.seq >= 0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, out), rB, (unsigned)rec.seq * 8u, 0, 16);
             else vf[rec.trav] = out;                            // the user's last rating of the pass
@@ -1210,7 +1224,8 @@ int res2_prepare(Res2Plan **out, const Rec *d_recs, int64_t nnz, int nu, int ni,
     MFX_HIP(hipGetDeviceProperties(&prop, dev));
     // MFX_K2_BOX: 0 = granule form, 2 / 4 = mailbox form with that many mailboxes per poll
     int box_w = env_i("MFX_K2_BOX", -1);
-    if (box_w != 0 && box_w != 2 && box_w != 4 && box_w != 8) {          // default: the wide kernel only where some item is hot (it costs 3 % on uniform data)
+    const bool box_auto = box_w != 0 && box_w != 2 && box_w != 4 && box_w != 8;
+    if (box_auto) {          // default: the wide kernel only where some item is hot (it costs 3 % on uniform data)
         int mu_deg = 0, mi_deg = 0;
         int rc0 = res_max_degrees(d_recs, nnz, nu, ni, &mu_deg, &mi_deg);
         if (rc0) return rc0;
@@ -1285,6 +1300,9 @@ int res2_prepare(Res2Plan **out, const Rec *d_recs, int64_t nnz, int nu, int ni,
                     return bail(fail(MFX_E_HIP, "mfx_sgd_run_funk: %s", hipGetErrorString(hipGetLastError())));
                 rp->n_hot = (int)hot.size();
                 rp->hot_deg = thr;
+                // with the long chains on waves of their own the lanes need no look-ahead, and an iteration of the narrow kernel is
+                // shorter: a hot USER's value hops from lane to lane faster (MovieLens-10M shape: 13.9 -> 11.3 ms per pass)
+                if (box_auto) rp->box_w = 2;
                 rp->waves = rp->n_hot + ceil_div(ni - rp->n_hot, 64);
             }
         }

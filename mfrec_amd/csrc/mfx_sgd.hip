@@ -866,8 +866,9 @@ int mfx_sgd_plan_kernel_name(const mfx_sgd_plan *p, int mode, char *buf, int buf
 {
     if (!p || !buf || buflen < 1 || mode < 0 || mode > 3) return fail(MFX_E_ARG, "mfx_sgd_plan_kernel_name: bad argument");
     if (mode == 3) {                      // the Funk pass: known once a Funk run has decided
-        if (p->k2r_state == 1 && res2_box_width(p->res2) && res2_hot_waves(p->res2))
-            snprintf(buf, (size_t)buflen, "k2_res<lane = item, mailboxes, %d per poll, %d waves of which %d own ONE hot item>", res2_box_width(p->res2), res2_waves(p->res2), res2_hot_waves(p->res2));
+        if (p->k2r_state == 1 && res2_box_width(p->res2) && (res2_hot_waves(p->res2) || res2_hot_user_waves(p->res2)))
+            snprintf(buf, (size_t)buflen, "k2_res<lane = item, mailboxes, %d per poll, %d waves: %d own ONE hot item, %d ONE hot user>", res2_box_width(p->res2),
+                     res2_waves(p->res2), res2_hot_waves(p->res2), res2_hot_user_waves(p->res2));
         else if (p->k2r_state == 1 && res2_box_width(p->res2))
             snprintf(buf, (size_t)buflen, "k2_res<lane = item, user values sent to the next rating's mailbox, %d per poll, %d waves>", res2_box_width(p->res2), (p->ni + 63) / 64);
         else if (p->k2r_state == 1) snprintf(buf, (size_t)buflen, "k2_res<lane = item, user values in 16-byte granules, %d waves>", (p->ni + 63) / 64);

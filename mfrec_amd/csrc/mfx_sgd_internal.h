@@ -61,6 +61,7 @@ size_t res2_dev_bytes(const Res2Plan *rp);
 int res2_box_width(const Res2Plan *rp);
 int res2_waves(const Res2Plan *rp);
 int res2_hot_waves(const Res2Plan *rp);
+int res2_hot_user_waves(const Res2Plan *rp);
 int64_t res2_se_slots(const Res2Plan *rp);
 const double *res2_se_partials(const Res2Plan *rp);
 int res2_reset_cache(Res2Plan *rp);

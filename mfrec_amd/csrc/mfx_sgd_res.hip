@@ -764,6 +764,7 @@ int res_status(ResPlan *rp, unsigned *status, unsigned *applied)
 // granule round trip (~1.9 us under load) instead of a level hand-off, and the pass runs on every CU of the chip.
 // Static owners: needs every lane resident (registration barrier as above; ni <= waves x 64).
 // ================================================================================================
+struct __attribute__((aligned(16))) HURec { int32_t pos; int32_t item; double r; };   // grouped position (cache word, reply mailbox), item, rating
 struct Res2Params {
     const URec *recs;           // grouped by item (stable); trav = user
     const int32_t *lo, *hi;     // [ni]
@@ -775,6 +776,12 @@ struct Res2Params {
     const int32_t *first_pos;   // [nu] grouped position of the user's first rating, -1: none
     const int32_t *order;       // hot-wave form: [ni] items, the n_hot hot ones first (a WAVE each), then the others (a lane each); else null
     int n_hot;
+    // hot USERS (their V[f,user] resident in a wave of their own; recs[].seq <= -2 marks such a rating: mailbox -2 - seq of ubox)
+    const struct HURec *urec;   // [hu_off[n_hu]] a hot user's ratings in input order
+    const int32_t *hu_ids, *hu_off;
+    double *ubox;               // item -> hot user: U[f,item] as it stands in front of the rating
+    double *se_user;            // [n_hu]
+    int n_hu;
     unsigned *ctl;
     double *se_item;
     int ni, nu, upd_u, upd_i, window, hot_deg, reg_extra;
@@ -953,7 +960,8 @@ __device__ __forceinline__ unsigned long long ld_box8(__amdgpu_buffer_rsrc_t rB,
     const v2u t = __builtin_amdgcn_raw_buffer_load_b64(rB, off, 0, 16);
     return ((unsigned long long)t[1] << 32) | t[0];
 }
-__device__ __forceinline__ void k2_hot_role(const Res2Params &P, int item, __amdgpu_buffer_rsrc_t rB, double *uf, double *vf, double trail)
+__device__ __forceinline__ void k2_hot_role(const Res2Params &P, int item, __amdgpu_buffer_rsrc_t rB, __amdgpu_buffer_rsrc_t rU, double *uf, double *vf,
+                                            double trail)
 {
     const int lane = threadIdx.x;
     int pos = P.lo[item];
@@ -969,9 +977,39 @@ __device__ __forceinline__ void k2_hot_role(const Res2Params &P, int item, __amd
         m = ld_box8(rB, (unsigned)(pos + lane) * 8u);
         if (P.ib) ubv = P.ub[rec.trav];
     }
-    int spins = 0;
+    int spins = 0, sent_pos = -1;
     while (pos < end) {
-        const unsigned long long okm = __ballot(pos + lane < end && m != kBoxEmpty);
+        const unsigned long long filled = __ballot(pos + lane < end && m != kBoxEmpty);
+        const unsigned long long rem = __ballot(pos + lane < end && rec.seq <= -2);
+        if (rem & 1ull) {
+            // the head is a HOT USER's rating: U[f,item] goes to that user's wave and comes back updated (two hand-offs on this
+            // chain instead of one on the user's -- the user's chain is the longer one)
+            if (sent_pos != pos) {
+                if (lane == 0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, x), rU, (unsigned)(-2 - rec.seq) * 8u, 0, 16);
+                sent_pos = pos;
+            }
+            if (filled & 1ull) {
+                x = readlane64(__builtin_bit_cast(double, m), 0);
+                pos += 1;
+                spins = 0;
+                rec = URec{0, -1, 0.0}; c = 0.0; ubv = 0.0; m = kBoxEmpty;
+                if (pos + lane < end) {
+                    rec = P.recs[pos + lane];
+                    c = P.cache[pos + lane];
+                    m = ld_box8(rB, (unsigned)(pos + lane) * 8u);
+                    if (P.ib) ubv = P.ub[rec.trav];
+                }
+                continue;
+            }
+            if (++spins > kSpinRun || ((spins & 1023) == 0 && ldc_u32(P.ctl + kCtlStatus))) {
+                if (lane == 0) atomicOr(P.ctl + kCtlStatus, 3u);
+                return;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            if (pos + lane < end) m = ld_box8(rB, (unsigned)(pos + lane) * 8u);
+            continue;
+        }
+        const unsigned long long okm = filled & ~rem;            // (a hot user's rating further on ends the run)
         const int depth = (okm == ~0ull) ? 64 : __builtin_ctzll(~okm);      // leading filled mailboxes of the window
         if (depth == 0) {
             if (++spins > kSpinRun || ((spins & 1023) == 0 && ldc_u32(P.ctl + kCtlStatus))) {
@@ -1001,7 +1039,7 @@ __device__ __forceinline__ void k2_hot_role(const Res2Params &P, int item, __amd
         double out = 0.0;
         auto walk = [&](auto both) {
             constexpr bool BOTH = decltype(both)::value;         // both update gates on: the common case without selects
-            for (int i = 0; i < depth; ++i) {
+            auto step = [&](int i) {
                 const double cf = readlane64(mv, i), s0 = readlane64(start, i), rr = readlane64(rec.r, i);
                 const double mf = x;
                 double sum = s0;                                 // funk_est(), trailing features included
@@ -1014,7 +1052,10 @@ __device__ __forceinline__ void k2_hot_role(const Res2Params &P, int item, __amd
                 const double un = mf + P.lr * (err * cf - P.K * mf), vn = cf + P.lr * (err * mf - P.K * cf);
                 if (lane == i) out = (BOTH || P.upd_u) ? vn : cf;
                 if (BOTH || P.upd_i) x = un;
-            }
+            };
+            int i = 0;
+            for (; i + 1 < depth; i += 2) { step(i); step(i + 1); }      // (pairs: the second rating's values are fetched under the first's chain)
+            if (i < depth) step(i);
         };
         if (P.upd_u && P.upd_i) walk(std::true_type{});
         else walk(std::false_type{});
@@ -1027,6 +1068,90 @@ __device__ __forceinline__ void k2_hot_role(const Res2Params &P, int item, __amd
         pos = np;
     }
     if (lane == 0) { uf[item] = x; P.se_item[item] = se; }
+}
+
+
+// ---- hot-USER role ----------------------------------------------------------------------------------------------------------
+// A user's value hops from item to item -- one hand-off between waves (~1.5 us) per rating, so the hottest user's chain bounds a pass
+// (MovieLens-10M shape: 7 369 ratings = 11 ms).  A hot user owns a wave instead: V[f,user] stays in a register of every lane, and
+// for ITS ratings the item value travels -- the item's owner stores U[f,item] into the rating's mailbox in `ubox` when its chain
+// gets there and waits for the updated value in the rating's own mailbox (two hand-offs on the item's chain, none on the user's).
+// The wave walks the user's ratings exactly as k2_hot_role walks an item's: 64 mailboxes per poll, the leading filled run in one
+// uniform loop, the next window requested under the walk.  Same operations in the same order (gd_estimator.pyx:750-761).
+__device__ __forceinline__ void k2_hot_user_role(const Res2Params &P, int h, __amdgpu_buffer_rsrc_t rB, __amdgpu_buffer_rsrc_t rU, double *vf, double trail)
+{
+    const int lane = threadIdx.x;
+    const int u = P.hu_ids[h];
+    int pos = P.hu_off[h];
+    const int end = P.hu_off[h + 1];
+    double v = vf[u], se = 0.0;
+    const double bu = P.ib ? P.ub[u] : 0.0;
+    HURec rec{-1, 0, 0.0};
+    double c = 0.0, ibv = 0.0;
+    unsigned long long m = kBoxEmpty;
+    if (pos + lane < end) {
+        rec = P.urec[pos + lane];
+        m = ld_box8(rU, (unsigned)(pos + lane) * 8u);
+        c = P.cache[rec.pos];
+        if (P.ib) ibv = P.ib[rec.item];
+    }
+    int spins = 0;
+    while (pos < end) {
+        const unsigned long long okm = __ballot(pos + lane < end && m != kBoxEmpty);
+        const int depth = (okm == ~0ull) ? 64 : __builtin_ctzll(~okm);
+        if (depth == 0) {
+            if (++spins > kSpinRun || ((spins & 1023) == 0 && ldc_u32(P.ctl + kCtlStatus))) {
+                if (lane == 0) atomicOr(P.ctl + kCtlStatus, 3u);
+                return;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            if (pos + lane < end) m = ld_box8(rU, (unsigned)(pos + lane) * 8u);
+            continue;
+        }
+        spins = 0;
+        const int np = pos + depth;
+        HURec recn{-1, 0, 0.0};
+        double cn = 0.0, ibn = 0.0;
+        unsigned long long mn = kBoxEmpty;
+        if (np + lane < end) {
+            recn = P.urec[np + lane];
+            mn = ld_box8(rU, (unsigned)(np + lane) * 8u);
+        }
+        const double base = P.ib ? (P.mu + ibv + bu) : (P.mu + 0.0 + 0.0);      // gd_estimator.pyx:553-554: item bias, then user bias
+        const double start = (c > 0) ? c : base;
+        const double mv = __builtin_bit_cast(double, m);
+        double out = 0.0;
+        auto walk = [&](auto both) {
+            constexpr bool BOTH = decltype(both)::value;
+            auto step = [&](int i) {
+                const double mf = readlane64(mv, i), s0 = readlane64(start, i), rr = readlane64(rec.r, i);
+                const double cf = v;
+                double sum = s0;
+                sum += mf * cf;
+                sum = clamp15r(sum);
+                sum += trail;
+                sum = clamp15r(sum);
+                const double err = rr - sum;
+                se += err * err;
+                const double un = mf + P.lr * (err * cf - P.K * mf), vn = cf + P.lr * (err * mf - P.K * cf);
+                if (lane == i) out = (BOTH || P.upd_i) ? un : mf;
+                if (BOTH || P.upd_u) v = vn;
+            };
+            int i = 0;
+            for (; i + 1 < depth; i += 2) { step(i); step(i + 1); }
+            if (i < depth) step(i);
+        };
+        if (P.upd_u && P.upd_i) walk(std::true_type{});
+        else walk(std::false_type{});
+        if (lane < depth) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, out), rB, (unsigned)rec.pos * 8u, 0, 16);
+        if (np + lane < end) {
+            cn = P.cache[recn.pos];
+            if (P.ib) ibn = P.ib[recn.item];
+        }
+        rec = recn; c = cn; m = mn; ibv = ibn;
+        pos = np;
+    }
+    if (lane == 0) { vf[u] = v; P.se_user[h] = se; }
 }
 
 template <int W>   // mailboxes seen per poll: 2 (one request); 4, 8: hot items look further (two / four requests)
@@ -1059,13 +1184,18 @@ __global__ __launch_bounds__(64) void k2_res_box(Res2Params P)
     double *const vf = dyn->vf;
     const double trail = dyn->trail;
     const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(P.box, 0, 0x7fffffff, 0x27000);
+    const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc(P.ubox ? P.ubox : P.box, 0, 0x7fffffff, 0x27000);
     int item = blockIdx.x * 64 + lane;
-    if (P.order) {                                              // hot-wave form: the first n_hot waves own one hot item each
-        if ((int)blockIdx.x < P.n_hot) {
-            k2_hot_role(P, P.order[blockIdx.x], rB, uf, vf, trail);
+    if (P.order) {                                              // hot-wave form: the first n_hot waves own one hot item each,
+        if ((int)blockIdx.x < P.n_hot) {                        // the next n_hu one hot user each, the rest 64 items each
+            k2_hot_role(P, P.order[blockIdx.x], rB, rU, uf, vf, trail);
             return;
         }
-        const int64_t o = (int64_t)P.n_hot + ((int64_t)blockIdx.x - P.n_hot) * 64 + lane;
+        if ((int)blockIdx.x < P.n_hot + P.n_hu) {
+            k2_hot_user_role(P, (int)blockIdx.x - P.n_hot, rB, rU, vf, trail);
+            return;
+        }
+        const int64_t o = (int64_t)P.n_hot + ((int64_t)blockIdx.x - P.n_hot - P.n_hu) * 64 + lane;
         item = o < P.ni ? P.order[o] : P.ni;
     }
     int pos = 0, end = 0;
@@ -1081,7 +1211,7 @@ __global__ __launch_bounds__(64) void k2_res_box(Res2Params P)
             if (i >= i0 && pos + i < end) { rec[i] = P.recs[pos + i]; c[i] = P.cache[pos + i]; }
     };
     load_from(0);
-    int spins = 0;
+    int spins = 0, sent_pos = -1;
     // W = 4: only a HOT item (eight times the average degree or more: the chains that bound a pass on skewed data) pays the second
     // request; the others look at their head's pair like the W = 2 kernel
     const bool wide = W > 2 && end - pos >= P.hot_deg;
@@ -1122,7 +1252,16 @@ __global__ __launch_bounds__(64) void k2_res_box(Res2Params P)
                 unsigned long long b = kBoxEmpty;
 #pragma unroll
                 for (int w = 0; w < W; ++w) if (w == sh + i) b = m[w];
-                if (n == i && pos + i < end && b != kBoxEmpty) { apply(rec[i], c[i], __builtin_bit_cast(double, b)); ++n; }
+                if (n == i && pos + i < end) {
+                    if (rec[i].seq <= -2) {
+                        // a HOT USER's rating: U[f,item] goes to that user's wave once, the updated value comes back in this mailbox
+                        if (sent_pos != pos + i) {
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, x), rU, (unsigned)(-2 - rec[i].seq) * 8u, 0, 16);
+                            sent_pos = pos + i;
+                        }
+                        if (b != kBoxEmpty) { x = __builtin_bit_cast(double, b); ++n; }
+                    } else if (b != kBoxEmpty) { apply(rec[i], c[i], __builtin_bit_cast(double, b)); ++n; }
+                }
             }
         }
         const bool ready = n > 0;
@@ -1175,6 +1314,30 @@ __global__ __launch_bounds__(256) void k2_commit_res(Res2Params P, const int32_t
         P.cache[s] = funk_est(uf[item], vf[rec.trav], P.cache[s], base, 0.0, false);
     }
 }
+// hot users: degrees, then each hot user's chain is walked once (the records are linked through seq = next grouped position) into
+// its own list; the ratings are marked (seq = -2 - list position) and the user is taken out of the seeding (first_pos = -1)
+__global__ void k2_user_degrees(const URec *__restrict__ recs, int64_t nnz, int *deg)
+{
+    for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < nnz; s += (int64_t)gridDim.x * blockDim.x) atomicAdd(deg + recs[s].trav, 1);
+}
+__global__ void k2_build_hot_users(URec *recs, const int32_t *__restrict__ ent_of, int32_t *first_pos, const int32_t *__restrict__ hu_ids,
+                                   const int32_t *__restrict__ hu_off, int n_hu, HURec *urec)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_hu) return;
+    const int u = hu_ids[t];
+    int p = first_pos[u], j = hu_off[t];
+    const int jend = hu_off[t + 1];
+    while (p >= 0 && j < jend) {
+        const URec r = recs[p];
+        HURec h; h.pos = p; h.item = ent_of[p]; h.r = r.r;
+        urec[j] = h;
+        recs[p].seq = -2 - j;
+        p = r.seq;
+        ++j;
+    }
+    first_pos[u] = -1;
+}
 // grouped cache -> the level-major cache of the other Funk kernels (a fallback in the middle of a run)
 __global__ void k2_set_next(URec *recs, const int32_t *__restrict__ next, int64_t nnz)
 {
@@ -1187,6 +1350,7 @@ __global__ void k2_cache_scatter(const double *src, const int32_t *pos_of, int64
 
 }  // namespace
 
+constexpr int kMaxHotUsers = 256;
 struct Res2Plan {
     int nu = 0, ni = 0, waves = 0;
     int64_t nnz = 0;
@@ -1198,6 +1362,11 @@ struct Res2Plan {
     int32_t *d_first = nullptr;
     int32_t *d_order = nullptr;         // hot-wave form: the items, hot ones first
     int n_hot = 0, hot_deg = 0;
+    HURec *d_urec = nullptr;            // hot users: their lists, ids, offsets, item -> user mailboxes
+    int32_t *d_hu_ids = nullptr, *d_hu_off = nullptr;
+    double *d_ubox = nullptr;
+    int n_hu = 0, hu_deg = 0;
+    int64_t n_urec = 0;
     int box_w = 0;
     unsigned *d_ctl = nullptr;
     size_t dev_bytes = 0;
@@ -1206,7 +1375,8 @@ struct Res2Plan {
 void res2_destroy(Res2Plan *rp)
 {
     if (!rp) return;
-    void *ptrs[] = {rp->d_recs, rp->d_lo, rp->d_hi, rp->d_pos_of, rp->d_ent_of, rp->d_cache, rp->d_se, rp->d_hdr, rp->d_box, rp->d_first, rp->d_order, rp->d_ctl};
+    void *ptrs[] = {rp->d_recs, rp->d_lo, rp->d_hi, rp->d_pos_of, rp->d_ent_of, rp->d_cache, rp->d_se, rp->d_hdr, rp->d_box, rp->d_first, rp->d_order, rp->d_urec,
+                    rp->d_hu_ids, rp->d_hu_off, rp->d_ubox, rp->d_ctl};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     delete rp;
@@ -1247,10 +1417,10 @@ int res2_prepare(Res2Plan **out, const Rec *d_recs, int64_t nnz, int nu, int ni,
         return (int)MFX_OK;
     };
     if (al((void **)&rp->d_recs, (size_t)nnz * sizeof(URec)) || al((void **)&rp->d_lo, (size_t)ni * 4) || al((void **)&rp->d_hi, (size_t)ni * 4) ||
-        al((void **)&rp->d_pos_of, (size_t)nnz * 4) || al((void **)&rp->d_ent_of, (size_t)nnz * 4) || al((void **)&rp->d_cache, (size_t)nnz * 8) || al((void **)&rp->d_se, (size_t)waves * 64 * 8) ||
+        al((void **)&rp->d_pos_of, (size_t)nnz * 4) || al((void **)&rp->d_ent_of, (size_t)nnz * 4) || al((void **)&rp->d_cache, (size_t)nnz * 8) || al((void **)&rp->d_se, ((size_t)waves * 64 + kMaxHotUsers) * 8) ||
         al((void **)&rp->d_hdr, (size_t)nu * sizeof(THdr)) || al((void **)&rp->d_ctl, kCtlWords * sizeof(unsigned)))
         return bail(last_code());
-    if (hipMemset(rp->d_ctl, 0, kCtlWords * sizeof(unsigned)) != hipSuccess || hipMemset(rp->d_se, 0, (size_t)waves * 64 * 8) != hipSuccess)
+    if (hipMemset(rp->d_ctl, 0, kCtlWords * sizeof(unsigned)) != hipSuccess || hipMemset(rp->d_se, 0, ((size_t)waves * 64 + kMaxHotUsers) * 8) != hipSuccess)
         return bail(fail(MFX_E_HIP, "mfx_sgd_run_funk: %s", hipGetErrorString(hipGetLastError())));
     rp->box_w = box_w;
     int32_t *d_next = nullptr;
@@ -1306,6 +1476,65 @@ int res2_prepare(Res2Plan **out, const Rec *d_recs, int64_t nnz, int nu, int ni,
                 rp->waves = rp->n_hot + ceil_div(ni - rp->n_hot, 64);
             }
         }
+        // ---- hot users: a wave each, their V[f,user] resident; for their ratings the ITEM value travels (there and back) -------
+        // MFX_K2_HOTU: 0 = off, n > 0 = every user with n ratings or more (tests, tuning; at most 256, the hottest first); default:
+        // users with at least 0.4 of the largest user degree (and 512 ratings), when that degree is 2 048 or more and eight
+        // times the average -- few enough that a hot ITEM's chain, which pays two hand-offs per such rating, does not become the
+        // longest (MovieLens-10M shape: 9 users 6.07 ms per pass, 31 users 6.49, 153 users 8.4)
+        const int uenv = env_i("MFX_K2_HOTU", -1);
+        if (uenv != 0) {
+            int *d_deg = nullptr;
+            if (hipMalloc((void **)&d_deg, (size_t)nu * 4) != hipSuccess) { (void)hipGetLastError(); return bail(fail(MFX_E_NOMEM, "hipMalloc(%zu bytes)", (size_t)nu * 4)); }
+            std::vector<int32_t> deg((size_t)nu);
+            bool okc = hipMemsetAsync(d_deg, 0, (size_t)nu * 4, stream()) == hipSuccess;
+            if (okc) {
+                hipLaunchKernelGGL(k2_user_degrees, dim3(2048), dim3(256), 0, stream(), (const URec *)rp->d_recs, nnz, d_deg);
+                okc = hipStreamSynchronize(stream()) == hipSuccess && hipMemcpy(deg.data(), d_deg, (size_t)nu * 4, hipMemcpyDeviceToHost) == hipSuccess;
+            }
+            (void)hipFree(d_deg);
+            if (!okc) return bail(fail(MFX_E_HIP, "mfx_sgd_run_funk: %s", hipGetErrorString(hipGetLastError())));
+            int uthr = 0;
+            if (uenv > 0) uthr = uenv;
+            else {
+                int maxd = 0;
+                for (int u = 0; u < nu; ++u) maxd = std::max(maxd, deg[(size_t)u]);
+                if (maxd >= 2048 && (int64_t)maxd >= 8 * (nnz / nu)) uthr = std::max(512, (int)(maxd * 0.4));
+            }
+            std::vector<int32_t> hu;
+            if (uthr > 0)
+                for (int u = 0; u < nu; ++u)
+                    if (deg[(size_t)u] >= uthr) hu.push_back(u);
+            std::stable_sort(hu.begin(), hu.end(), [&](int32_t a, int32_t b) { return deg[(size_t)a] > deg[(size_t)b]; });
+            size_t cap = kMaxHotUsers;
+            while (cap > 0 && (int64_t)rp->waves + (int64_t)std::min(cap, hu.size()) > wave_budget) cap /= 2;
+            if (hu.size() > cap) hu.resize(cap);
+            if (!hu.empty()) {
+                std::vector<int32_t> off(hu.size() + 1, 0);
+                for (size_t t = 0; t < hu.size(); ++t) off[t + 1] = off[t] + deg[(size_t)hu[t]];
+                const int64_t M = off.back();
+                if (!rp->d_order) {                             // (the role dispatch goes through order[]: identity when no item is hot)
+                    std::vector<int32_t> order((size_t)ni);
+                    for (int i = 0; i < ni; ++i) order[(size_t)i] = i;
+                    if (al((void **)&rp->d_order, (size_t)ni * 4)) return bail(last_code());
+                    if (hipMemcpy(rp->d_order, order.data(), (size_t)ni * 4, hipMemcpyHostToDevice) != hipSuccess)
+                        return bail(fail(MFX_E_HIP, "mfx_sgd_run_funk: %s", hipGetErrorString(hipGetLastError())));
+                }
+                if (al((void **)&rp->d_urec, (size_t)M * sizeof(HURec)) || al((void **)&rp->d_hu_ids, hu.size() * 4) || al((void **)&rp->d_hu_off, off.size() * 4) ||
+                    al((void **)&rp->d_ubox, (size_t)(M + 8) * 8))
+                    return bail(last_code());
+                if (hipMemcpy(rp->d_hu_ids, hu.data(), hu.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                    hipMemcpy(rp->d_hu_off, off.data(), off.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+                    return bail(fail(MFX_E_HIP, "mfx_sgd_run_funk: %s", hipGetErrorString(hipGetLastError())));
+                hipLaunchKernelGGL(k2_build_hot_users, dim3(ceil_div((int)hu.size(), 64)), dim3(64), 0, stream(), rp->d_recs, (const int32_t *)rp->d_ent_of,
+                                   rp->d_first, (const int32_t *)rp->d_hu_ids, (const int32_t *)rp->d_hu_off, (int)hu.size(), rp->d_urec);
+                if (hipStreamSynchronize(stream()) != hipSuccess) return bail(fail(MFX_E_HIP, "mfx_sgd_run_funk: %s", hipGetErrorString(hipGetLastError())));
+                rp->n_hu = (int)hu.size();
+                rp->hu_deg = uthr;
+                if (box_auto) rp->box_w = 2;                    // (as with hot items: the lanes need no look-ahead)
+                rp->n_urec = M;
+                rp->waves += rp->n_hu;
+            }
+        }
     }
     *out = rp;
     return MFX_OK;
@@ -1315,7 +1544,8 @@ size_t res2_dev_bytes(const Res2Plan *rp) { return rp ? rp->dev_bytes : 0; }
 int res2_box_width(const Res2Plan *rp) { return rp ? rp->box_w : 0; }
 int res2_waves(const Res2Plan *rp) { return rp ? rp->waves : 0; }
 int res2_hot_waves(const Res2Plan *rp) { return rp ? rp->n_hot : 0; }
-int64_t res2_se_slots(const Res2Plan *rp) { return (int64_t)ceil_div(rp->ni, 64) * 64; }      // indexed by item
+int res2_hot_user_waves(const Res2Plan *rp) { return rp ? rp->n_hu : 0; }
+int64_t res2_se_slots(const Res2Plan *rp) { return (int64_t)ceil_div(rp->ni, 64) * 64 + rp->n_hu; }      // indexed by item, then by hot user
 const double *res2_se_partials(const Res2Plan *rp) { return rp->d_se; }
 int res2_reset_cache(Res2Plan *rp)
 {
@@ -1332,7 +1562,10 @@ static Res2Params res2_params(Res2Plan *rp, const void *d_dyn, const double *ib,
     Res2Params P;
     memset(&P, 0, sizeof(P));
     P.recs = rp->d_recs; P.lo = rp->d_lo; P.hi = rp->d_hi; P.cache = rp->d_cache; P.dyn = (const double *const *)d_dyn;
-    P.ib = ib; P.ub = ub; P.hdr = rp->d_hdr; P.box = rp->d_box; P.first_pos = rp->d_first; P.order = rp->d_order; P.n_hot = rp->n_hot; P.ctl = rp->d_ctl; P.se_item = rp->d_se; P.ni = rp->ni; P.nu = rp->nu;
+    P.ib = ib; P.ub = ub; P.hdr = rp->d_hdr; P.box = rp->d_box; P.first_pos = rp->d_first; P.order = rp->d_order; P.n_hot = rp->n_hot;
+    P.urec = rp->d_urec; P.hu_ids = rp->d_hu_ids; P.hu_off = rp->d_hu_off; P.ubox = rp->d_ubox; P.n_hu = rp->n_hu;
+    P.se_user = rp->d_se + (size_t)ceil_div(rp->ni, 64) * 64;
+    P.ctl = rp->d_ctl; P.se_item = rp->d_se; P.ni = rp->ni; P.nu = rp->nu;
     P.upd_u = upd_u; P.upd_i = upd_i; P.lr = lr; P.K = K; P.mu = mu;
     P.window = env_i("MFX_K2_WIN", 1);                     // 0: no look-ahead (A/B hook)
     P.reg_extra = test_reg_extra();
@@ -1347,6 +1580,7 @@ int res2_enqueue_pass(Res2Plan *rp, const void *d_dyn, const double *ib, const d
     if (rp->box_w) {
         const int n = rp->nu > rp->ni ? rp->nu : rp->ni;
         hipLaunchKernelGGL(k2_box_fill, dim3(2048), dim3(256), 0, stream(), (unsigned long long *)rp->d_box, rp->nnz + 8);
+        if (rp->n_hu) hipLaunchKernelGGL(k2_box_fill, dim3(256), dim3(256), 0, stream(), (unsigned long long *)rp->d_ubox, rp->n_urec + 8);
         hipLaunchKernelGGL(k2_box_seed, dim3(ceil_div(n, 256)), dim3(256), 0, stream(), (unsigned long long *)rp->d_box, (const int32_t *)rp->d_first,
                            P.dyn, rp->nu, rp->ni, rp->d_ctl);
         if (rp->box_w == 8) hipLaunchKernelGGL(k2_res_box<8>, dim3(rp->waves), dim3(64), 0, stream(), P);

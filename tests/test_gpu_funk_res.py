@@ -3,7 +3,8 @@ keeps U[f,item] in a register) must give the SAME BITS as the oracle's sequentia
 :588-685) -- in its mailbox form (k2_res_box: V[f,user] is sent straight to the 8-byte mailbox of the user's next rating; 2, 4 or 8
 mailboxes per poll) and in its granule form (k2_res: V[f,user] travels inside a per-user 16-byte {value, chain counter} granule).
 On skewed data the items whose chains would bound the pass own a whole WAVE each (k2_hot_role: 64 mailboxes per poll, one
-uniform walk); forced here by MFX_K2_HOT=<degree>.
+uniform walk), and so do the hottest users (k2_hot_user_role: V[f,user] resident, the item value travels there and back); forced
+here by MFX_K2_HOT=<degree> / MFX_K2_HOTU=<degree>.
 It is the default from 65 536 ratings on; forced here (MFX_K2_RES=1) also on tiny problems, every test in every form."""
 import numpy as np
 import pytest
@@ -13,7 +14,7 @@ from mfrec_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["mailbox-auto", "mailbox-2", "mailbox-4", "mailbox-8", "granule", "hot-1", "hot-40"])
+@pytest.fixture(autouse=True, params=["mailbox-auto", "mailbox-2", "mailbox-4", "mailbox-8", "granule", "hot-1", "hot-40", "hotu-1", "hotu-25+hot-60"])
 def _force(monkeypatch, request):
     from mfrec_amd import _shim as S
     from mfrec_amd import build as B
@@ -22,10 +23,15 @@ def _force(monkeypatch, request):
     monkeypatch.setenv("MFX_K2_RES", "1")
     form = request.param
     monkeypatch.delenv("MFX_K2_HOT", raising=False)
-    if form.startswith("hot-"):
-        # hot-wave role of the mailbox form: every item with that many ratings or more owns a whole wave (up to 2 048 of them,
-        # the hottest first); the rest stay one lane each.  hot-1: (almost) everything through the wave role; hot-40: a mix
-        monkeypatch.setenv("MFX_K2_HOT", form.split("-")[1])
+    monkeypatch.delenv("MFX_K2_HOTU", raising=False)
+    if form.startswith("hot"):
+        # hot-wave roles of the mailbox form.  hot-<d>: every item with d ratings or more owns a whole wave (up to 2 048 of them,
+        # the hottest first), the rest stay one lane each -- hot-1: (almost) everything through the wave role, hot-40: a mix.
+        # hotu-<d>: every USER with d ratings or more owns a wave (up to 256, the hottest first) and for its ratings the item
+        # value travels there and back -- alone (items on lanes, or on waves where the plan finds hot ones) and with hot items
+        for part in form.split("+"):
+            name, d = part.split("-")
+            monkeypatch.setenv("MFX_K2_HOT" if name == "hot" else "MFX_K2_HOTU", d)
         monkeypatch.delenv("MFX_K2_BOX", raising=False)
     elif form == "granule":
         monkeypatch.setenv("MFX_K2_BOX", "0")

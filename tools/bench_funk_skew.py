@@ -38,8 +38,12 @@ for make in (uniform, ml10m, zipf08):
     r = rs.randint(1, 6, nnz).astype(np.float64)
     outs = {}
     for box in sys.argv[1:] or ["0", "2", "8", "auto"]:
-        os.environ.pop("MFX_K2_BOX", None); os.environ.pop("MFX_K2_HOT", None)
-        if box != "auto":
+        os.environ.pop("MFX_K2_BOX", None); os.environ.pop("MFX_K2_HOT", None); os.environ.pop("MFX_K2_HOTU", None)
+        if box.endswith("-nou"):                                # hot items only (no hot-user waves)
+            os.environ["MFX_K2_HOTU"] = "0"
+        elif box.startswith("auto-u"):                          # auto-u<degree>: hot users from that degree on
+            os.environ["MFX_K2_HOTU"] = box[6:]
+        if not box.startswith("auto"):
             os.environ["MFX_K2_BOX"] = box.rstrip("h")
             if not box.endswith("h"):
                 os.environ["MFX_K2_HOT"] = "0"

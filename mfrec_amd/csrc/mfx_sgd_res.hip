@@ -796,6 +796,13 @@ __device__ __forceinline__ double clamp15r(double x)        // gd_estimator.pyx:
     if (x < 1.0) x = 1.0;
     return x;
 }
+// the same function of every input, NaN included (a NaN passes both comparisons of clamp15r unchanged), in three dependent
+// instructions instead of four compare-select pairs: the walks of the hot-wave roles are chains of dependent operations
+__device__ __forceinline__ double clamp15w(double x)
+{
+    const double r = __builtin_fmax(__builtin_fmin(x, 5.0), 1.0);
+    return (x != x) ? x : r;
+}
 __device__ __forceinline__ double funk_est(double uf, double vf, double cache, double base, double trail, bool trailing)
 {
     double sum = (cache > 0) ? cache : base;                  // gd_estimator.pyx:38-73
@@ -1044,9 +1051,9 @@ __device__ __forceinline__ void k2_hot_role(const Res2Params &P, int item, __amd
                 const double mf = x;
                 double sum = s0;                                 // funk_est(), trailing features included
                 sum += mf * cf;
-                sum = clamp15r(sum);
+                sum = clamp15w(sum);
                 sum += trail;
-                sum = clamp15r(sum);
+                sum = clamp15w(sum);
                 const double err = rr - sum;
                 se += err * err;
                 const double un = mf + P.lr * (err * cf - P.K * mf), vn = cf + P.lr * (err * mf - P.K * cf);
@@ -1128,9 +1135,9 @@ __device__ __forceinline__ void k2_hot_user_role(const Res2Params &P, int h, __a
                 const double cf = v;
                 double sum = s0;
                 sum += mf * cf;
-                sum = clamp15r(sum);
+                sum = clamp15w(sum);
                 sum += trail;
-                sum = clamp15r(sum);
+                sum = clamp15w(sum);
                 const double err = rr - sum;
                 se += err * err;
                 const double un = mf + P.lr * (err * cf - P.K * mf), vn = cf + P.lr * (err * mf - P.K * cf);
@@ -1441,8 +1448,8 @@ int res2_prepare(Res2Plan **out, const Rec *d_recs, int64_t nnz, int nu, int ni,
     if (box_w) {
         const int henv = env_i("MFX_K2_HOT", -1);
         std::vector<int32_t> lo((size_t)ni), hi((size_t)ni);
-        if (henv != 0 && (hipMemcpy(lo.data(), rp->d_lo, (size_t)ni * 4, hipMemcpyDeviceToHost) != hipSuccess ||
-                          hipMemcpy(hi.data(), rp->d_hi, (size_t)ni * 4, hipMemcpyDeviceToHost) != hipSuccess))
+        if (hipMemcpy(lo.data(), rp->d_lo, (size_t)ni * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(hi.data(), rp->d_hi, (size_t)ni * 4, hipMemcpyDeviceToHost) != hipSuccess)
             return bail(fail(MFX_E_HIP, "mfx_sgd_run_funk: %s", hipGetErrorString(hipGetLastError())));
         int thr = 0;
         if (henv > 0) thr = henv;
@@ -1478,9 +1485,9 @@ int res2_prepare(Res2Plan **out, const Rec *d_recs, int64_t nnz, int nu, int ni,
         }
         // ---- hot users: a wave each, their V[f,user] resident; for their ratings the ITEM value travels (there and back) -------
         // MFX_K2_HOTU: 0 = off, n > 0 = every user with n ratings or more (tests, tuning; at most 256, the hottest first); default:
-        // users with at least 0.4 of the largest user degree (and 512 ratings), when that degree is 2 048 or more and eight
-        // times the average -- few enough that a hot ITEM's chain, which pays two hand-offs per such rating, does not become the
-        // longest (MovieLens-10M shape: 9 users 6.07 ms per pass, 31 users 6.49, 153 users 8.4)
+        // the h hottest users that a cost model picks (below) -- few enough that a hot ITEM's chain, which pays two hand-offs per
+        // such rating, does not become the longest (MovieLens-10M shape, measured: 9 users 6.07 ms per pass, 31 users 6.49, 153
+        // users 8.4; the model picks 8-9)
         const int uenv = env_i("MFX_K2_HOTU", -1);
         if (uenv != 0) {
             int *d_deg = nullptr;
@@ -1493,18 +1500,41 @@ int res2_prepare(Res2Plan **out, const Rec *d_recs, int64_t nnz, int nu, int ni,
             }
             (void)hipFree(d_deg);
             if (!okc) return bail(fail(MFX_E_HIP, "mfx_sgd_run_funk: %s", hipGetErrorString(hipGetLastError())));
+            // the candidates: the (at most) 257 largest degrees, descending (ties by ascending id)
+            std::vector<int32_t> top((size_t)nu);
+            for (int u = 0; u < nu; ++u) top[(size_t)u] = u;
+            const size_t ntop = std::min((size_t)nu, (size_t)kMaxHotUsers + 1);
+            auto by_deg = [&](int32_t a, int32_t b) { return deg[(size_t)a] != deg[(size_t)b] ? deg[(size_t)a] > deg[(size_t)b] : a < b; };
+            std::partial_sort(top.begin(), top.begin() + (std::ptrdiff_t)ntop, top.end(), by_deg);
+            top.resize(ntop);
             int uthr = 0;
-            if (uenv > 0) uthr = uenv;
-            else {
-                int maxd = 0;
-                for (int u = 0; u < nu; ++u) maxd = std::max(maxd, deg[(size_t)u]);
-                if (maxd >= 2048 && (int64_t)maxd >= 8 * (nnz / nu)) uthr = std::max(512, (int)(maxd * 0.4));
+            size_t n_take = 0;
+            if (uenv > 0) {
+                uthr = uenv;
+                while (n_take < top.size() && n_take < (size_t)kMaxHotUsers && deg[(size_t)top[n_take]] >= uthr) ++n_take;
+            } else if (deg[(size_t)top[0]] >= 2048) {
+                // cost model (measured constants, DESIGN.md K2 hot-wave roles): with the h hottest users on waves the pass is as long
+                // as the longer of (a) the hottest REMAINING user's chain of hand-offs, 1.5 us each, and (b) the hottest item's
+                // chain: 0.115 us per rating on a wave (0.5 on a lane) plus two hand-offs (3 us) for every rating by one of the
+                // h users (their share of all ratings, assumed the same on that item).  Taken when it saves a tenth or more.
+                int max_item = 0;
+                for (int i = 0; i < ni; ++i) max_item = std::max(max_item, hi[(size_t)i] - lo[(size_t)i]);
+                const double c_item = rp->n_hot ? 0.115 : 0.5;
+                double best = 0.0, cost0 = 0.0, share = 0.0;
+                size_t best_h = 0;
+                for (size_t h = 0; h < top.size() && h <= (size_t)kMaxHotUsers; ++h) {      // h users taken: top[h] is the hottest one left
+                    const double user_chain = deg[(size_t)top[h]] * 1.5;
+                    const double item_chain = max_item * (c_item + 3.0 * share / (double)nnz);
+                    const double cost = std::max(user_chain, item_chain);
+                    if (h == 0) cost0 = best = cost;
+                    else if (cost < best) { best = cost; best_h = h; }
+                    share += deg[(size_t)top[h]];
+                }
+                if (best > 0.9 * cost0) best_h = 0;
+                n_take = best_h;
+                if (n_take) uthr = deg[(size_t)top[n_take - 1]];
             }
-            std::vector<int32_t> hu;
-            if (uthr > 0)
-                for (int u = 0; u < nu; ++u)
-                    if (deg[(size_t)u] >= uthr) hu.push_back(u);
-            std::stable_sort(hu.begin(), hu.end(), [&](int32_t a, int32_t b) { return deg[(size_t)a] > deg[(size_t)b]; });
+            std::vector<int32_t> hu(top.begin(), top.begin() + (std::ptrdiff_t)n_take);
             size_t cap = kMaxHotUsers;
             while (cap > 0 && (int64_t)rp->waves + (int64_t)std::min(cap, hu.size()) > wave_budget) cap /= 2;
             if (hu.size() > cap) hu.resize(cap);

@@ -409,8 +409,8 @@ def also_funk_ml10m(with_cpu):
     """K2 on the SHAPE of the reference's only published workload (gradient_descent.py:41-45: MovieLens-10M, 69 878 users x
     10 677 items, 10 M ratings, 40 features, 49 minutes on a Core i5 2.3 GHz with the class defaults = 275 epochs per
     feature): a synthetic with power-law degrees on both sides (the real file is not available offline), shuffled order,
-    k = 40 features x 2 epochs each timed.  A pass is as long as the longest chain of the data (hottest item ~39 K ratings:
-    it owns a whole wave; hottest user ~7 K ratings: 7 K hand-offs between waves)."""
+    k = 40 features x 2 epochs each timed.  A pass is as long as the longest chain of the data: the hottest items (~39 K ratings)
+    and the hottest users (~7 K ratings) own a whole wave each (DESIGN.md section 4, K2 hot-wave roles)."""
     from mfrec_amd import synth
     from mfrec_amd.plan import SgdPlan, Timer
     nu, ni, nnz, k = 69878, 10677, 10000000, 40
@@ -442,7 +442,7 @@ def also_funk_ml10m(with_cpu):
            "roofline": {"bound": "hbm", "achieved": rate * 24 / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": rate * 24 / HBM_PEAK,
                         "bytes_per_scalar_update": 24, "kernel": kname, "avg_launch_us": ms_pass * 1e3,
                         "us_per_level": ms_pass * 1e3 / max(info["n_levels"], 1), "traffic": None,
-                        "note": "a latency chain, not a stream: the pass is as long as the hottest user's chain of hand-offs"}}
+                        "note": "a latency chain, not a stream: the pass is as long as the hottest item's chain (0.115 us per rating on its own wave)"}}
     if with_cpu:
         try:
             out["cpu_baseline"] = cpu_baseline_funk(idx, r, nu, ni, budget_s=6.0)

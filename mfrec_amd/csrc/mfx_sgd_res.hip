@@ -1522,13 +1522,13 @@ int res2_prepare(Res2Plan **out, const Rec *d_recs, int64_t nnz, int nu, int ni,
                 const double c_item = rp->n_hot ? 0.115 : 0.5;
                 double best = 0.0, cost0 = 0.0, share = 0.0;
                 size_t best_h = 0;
-                for (size_t h = 0; h < top.size() && h <= (size_t)kMaxHotUsers; ++h) {      // h users taken: top[h] is the hottest one left
-                    const double user_chain = deg[(size_t)top[h]] * 1.5;
+                for (size_t h = 0; h <= top.size() && h <= (size_t)kMaxHotUsers; ++h) {     // h users taken: top[h] is the hottest one left
+                    const double user_chain = h < top.size() ? deg[(size_t)top[h]] * 1.5 : 0.0;      // (h = nu: every user on a wave)
                     const double item_chain = max_item * (c_item + 3.0 * share / (double)nnz);
                     const double cost = std::max(user_chain, item_chain);
                     if (h == 0) cost0 = best = cost;
                     else if (cost < best) { best = cost; best_h = h; }
-                    share += deg[(size_t)top[h]];
+                    if (h < top.size()) share += deg[(size_t)top[h]];
                 }
                 if (best > 0.9 * cost0) best_h = 0;
                 n_take = best_h;

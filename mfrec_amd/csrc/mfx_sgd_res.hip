@@ -1500,10 +1500,16 @@ int res2_prepare(Res2Plan **out, const Rec *d_recs, int64_t nnz, int nu, int ni,
             }
             (void)hipFree(d_deg);
             if (!okc) return bail(fail(MFX_E_HIP, "mfx_sgd_run_funk: %s", hipGetErrorString(hipGetLastError())));
-            // the candidates: the (at most) 257 largest degrees, descending (ties by ascending id)
-            std::vector<int32_t> top((size_t)nu);
-            for (int u = 0; u < nu; ++u) top[(size_t)u] = u;
-            const size_t ntop = std::min((size_t)nu, (size_t)kMaxHotUsers + 1);
+            // the candidates: the (at most) 257 largest degrees, descending (ties by ascending id) -- only looked for when some user
+            // has a chain worth a wave (or the override asks)
+            int max_udeg = 0;
+            for (int u = 0; u < nu; ++u) max_udeg = std::max(max_udeg, deg[(size_t)u]);
+            std::vector<int32_t> top;
+            if (uenv > 0 || max_udeg >= 2048) {
+                top.resize((size_t)nu);
+                for (int u = 0; u < nu; ++u) top[(size_t)u] = u;
+            }
+            const size_t ntop = std::min(top.size(), (size_t)kMaxHotUsers + 1);
             auto by_deg = [&](int32_t a, int32_t b) { return deg[(size_t)a] != deg[(size_t)b] ? deg[(size_t)a] > deg[(size_t)b] : a < b; };
             std::partial_sort(top.begin(), top.begin() + (std::ptrdiff_t)ntop, top.end(), by_deg);
             top.resize(ntop);
@@ -1512,7 +1518,7 @@ int res2_prepare(Res2Plan **out, const Rec *d_recs, int64_t nnz, int nu, int ni,
             if (uenv > 0) {
                 uthr = uenv;
                 while (n_take < top.size() && n_take < (size_t)kMaxHotUsers && deg[(size_t)top[n_take]] >= uthr) ++n_take;
-            } else if (deg[(size_t)top[0]] >= 2048) {
+            } else if (!top.empty() && max_udeg >= 2048) {
                 // cost model (measured constants, DESIGN.md K2 hot-wave roles): with the h hottest users on waves the pass is as long
                 // as the longer of (a) the hottest REMAINING user's chain of hand-offs, 1.5 us each, and (b) the hottest item's
                 // chain: 0.115 us per rating on a wave (0.5 on a lane) plus two hand-offs (3 us) for every rating by one of the

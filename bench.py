@@ -959,6 +959,43 @@ def main():
                 del i3u, r3u
             except Exception as e:
                 out["k1_user_resident_cfg3"] = {"error": repr(e)}
+            # the same 100 M ratings on the item-block order (sharding.DsgdKMF, world = 1): 200 K items do not fit the register file
+            # at once, five blocks of ~40 K do -- every block on the static resident-side epoch; exact on that order.  Twice: the
+            # given order inside the blocks, and every block in its own minimum-level (balanced) order (`value`)
+            try:
+                from mfrec_amd.sharding import DsgdKMF
+                from mfrec_amd.plan import Timer
+                nb = -(-ni3 // 42000)
+                res_b = {}
+                for bal in (False, True):
+                    t0 = time.perf_counter()
+                    dk = DsgdKMF(idx3, r3, nu3, ni3, k3, -1, 1, balanced=bal, item_blocks_1gpu=nb)
+                    build_s = time.perf_counter() - t0
+                    dk.set_factors(synth.init_normal(k3, ni3, synth.SEED_INIT), synth.init_normal(k3, nu3, synth.SEED_INIT + 1),
+                                   np.zeros(ni3), np.zeros(nu3))
+                    dk.train(LINEAR, max(a.warmup, 1), LR, KU, KI, KB)
+                    with Timer() as tmb:
+                        se_b = dk.train(LINEAR, a.steps, LR, KU, KI, KB)
+                    info_b = dk.info()
+                    dk.close()
+                    res_b[bal] = (nnz3 * a.steps / (tmb.ms * 1e-3), tmb.ms / a.steps, info_b, build_s, float(np.sqrt(se_b[-1] / nnz3)))
+                rate_b, ms_b, info_b, build_s, rm_b = res_b[True]
+                br3 = algorithmic_bytes(k3, nnz3, nu3)[0]
+                out["k1_cfg3_item_blocks_1gpu"] = {
+                    "value": rate_b, "unit": "rating-updates/s", "device_ms_per_step": ms_b, "item_blocks": nb,
+                    "blocks_on_the_resident_epoch": info_b["resident_blocks"], "levels_total": info_b["levels_total"],
+                    "plan_build_s": round(build_s, 1), "rmse_online_last": rm_b,
+                    "given_order_inside_the_blocks": {"value": res_b[False][0], "device_ms_per_step": res_b[False][1],
+                                                      "levels_total": res_b[False][2]["levels_total"], "plan_build_s": round(res_b[False][3], 1)},
+                    "roofline": {"bound": "hbm", "achieved": rate_b * br3 / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                 "frac": rate_b * br3 / HBM_PEAK, "traffic": None,
+                                 "kernel": "k1_res (static), one persistent launch per item block and epoch",
+                                 "note": "measured ceiling of the access pattern: 5.5 G ratings/s (tools/rmw_ceiling.hip)"},
+                    "workload": "cfg3 whole on ONE GPU, ITEM-BLOCK order: the given (shuffled) ratings grouped by %d item blocks (stable), "
+                                "every block in its own minimum-level order; exact on that order (bit-identical to the sequential loop: "
+                                "tests/test_gpu_fakeworld.py)" % nb}
+            except Exception as e:
+                out["k1_cfg3_item_blocks_1gpu"] = {"error": repr(e)}
             del r3
             t = time.perf_counter()
             try:
@@ -968,7 +1005,7 @@ def main():
                 out["k3_als_cfg4"] = {"error": repr(e)}
             return out
 
-        if not only or (only & {"k1_cfg3_whole_1gpu", "k1_user_resident_cfg3", "k3_als_cfg4"}):
+        if not only or (only & {"k1_cfg3_whole_1gpu", "k1_user_resident_cfg3", "k1_cfg3_item_blocks_1gpu", "k3_als_cfg4"}):
             if os.environ.get("MFX_BENCH_TRACE") == "1":
                 sys.stderr.write("[bench] leg cfg3 + als\n"); sys.stderr.flush()
             try:

@@ -143,7 +143,7 @@ class DsgdKMF(object):
     """Exact multi-GPU full-k SGD (mfx_dsgd_*).  rank = -1: every rank in this process on this GPU."""
 
     def __init__(self, ratings_index, ratings, nbr_users, nbr_items, dim, rank, world,
-                 user_bounds=None, item_bounds=None, overlap=False, balanced=False):
+                 user_bounds=None, item_bounds=None, overlap=False, balanced=False, item_blocks_1gpu=None):
         """overlap: 2 * world item blocks (a block rests one step in transit: hand-offs under the next step's
         levels) instead of world -- twice as many, half as large dependency levels, which at BASELINE cfg 3 costs
         more than the hidden hand-offs save, hence off by default; balanced: every block in
@@ -156,6 +156,13 @@ class DsgdKMF(object):
         self.user_bounds = np.ascontiguousarray(
             user_blocks(ratings_index, nbr_users, world) if user_bounds is None else user_bounds, dtype=np.int64)
         nb = (2 * self.world if (overlap and self.world > 1) else self.world)
+        if item_blocks_1gpu is not None:
+            # ONE GPU, catalogue larger than the register file: the items in n blocks (balanced by rating count), the epoch = the
+            # sequential loop on the item-block order (block 0's ratings in the given order, then block 1's, ...); every block small
+            # enough runs the static resident-side epoch (its items resident, the users travel)
+            if self.world != 1:
+                raise ValueError("item_blocks_1gpu needs world = 1")
+            nb = int(item_blocks_1gpu)
         self.item_bounds = np.ascontiguousarray(
             item_blocks(ratings_index, nbr_items, nb) if item_bounds is None else item_bounds, dtype=np.int64)
         self.n_item_blocks = len(self.item_bounds) - 1

@@ -166,3 +166,26 @@ def test_dsgd_argument_errors():
     bad = idx.copy(); bad[3, 1] = 40
     with pytest.raises(ValueError, match="outside"):
         DsgdKMF(bad, r, 50, 40, 8, -1, 2)
+
+
+@pytest.mark.parametrize("nb,balanced", [(3, False), (5, True)])
+def test_item_block_order_on_one_gpu_equals_the_oracle(nb, balanced):
+    """world = 1 with ANY number of item blocks (a catalogue larger than the register file, block by block on the static resident-side
+    epoch): bit-identical to the sequential loop (kmf_train.pyx:243-270) on the order the object reports."""
+    from mfrec_amd.sharding import DsgdKMF
+    from oracle import oracle as O
+    nu, ni, nnz, k = 3000, 1700, 120000, 18
+    idx, r = synth.make_ratings(nu, ni, nnz, seed=31)
+    u0, v0 = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
+    d = DsgdKMF(idx, r, nu, ni, k, -1, 1, balanced=balanced, item_blocks_1gpu=nb)
+    assert d.info()["item_blocks"] == nb
+    u, v, ib, ub = u0.copy(), v0.copy(), np.zeros(ni), np.zeros(nu)
+    d.set_factors(u, v, ib, ub)
+    d.train(0, 2, 0.01, 0.1, 0.1, 0.007)
+    d.get_factors(u, v, ib, ub)
+    perm = d.order()
+    d.close()
+    assert sorted(perm.tolist()) == list(range(nnz))
+    u2, v2, ib2, ub2 = u0.copy(), v0.copy(), np.zeros(ni), np.zeros(nu)
+    O.train_linear_kernel(2, k, 0.1, 0.01, 0, 0, 0.1, 0.1, 0.007, 0.0, u2, v2, np.ascontiguousarray(idx[perm]), np.ascontiguousarray(r[perm]), ib2, ub2)
+    assert np.array_equal(u, u2) and np.array_equal(v, v2) and np.array_equal(ib, ib2) and np.array_equal(ub, ub2)

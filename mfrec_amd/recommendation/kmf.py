@@ -51,11 +51,20 @@ class KMFRecommender(MFRecommender):
         self._mark_csc_due()                         # kmf.py:207 (relationship_matrix_csc: formed on first use)
         if initialize_model:
             self.init_feature_normal(0.0, 0.1)
-        # order=True: the reference's shuffle; order="balanced": fewest dependency levels (extension)
-        ratings_index, ratings = self.get_ratings(randomize_order=order)
+        # order=True: the reference's shuffle; order="balanced": fewest dependency levels (extension); order="blocks": the
+        # reference's shuffle, then grouped by (user block, item block) -- for problems whose smaller side does not fit the register
+        # file of one GPU (sharding.kmf_train_block_order: every block on the static resident-side epoch; exact on that order)
+        blocks = order == "blocks"
+        ratings_index, ratings = self.get_ratings(randomize_order=True if blocks else order)
         self.compute_overall_avg()
         self.items_bias = np.zeros(self.nbr_items)
         self.users_bias = np.zeros(self.nbr_users)
+        if blocks:
+            from ..sharding import kmf_train_block_order
+            self.block_order = kmf_train_block_order(1 if kernel == "train_logistic_kernel" else 0, self.nbr_epochs, self.dimensionality,
+                                                     self.learning_rate, self.K_users, self.K_items, self.K_bias, self.svd_u, self.svd_v,
+                                                     ratings_index, ratings, self.items_bias, self.users_bias)
+            return
         getattr(_kernels, kernel)(self.nbr_epochs, self.dimensionality, self.feature_init,
                                   self.learning_rate, self.learning_rate_users,
                                   self.learning_rate_items, self.K_users, self.K_items, self.K_bias,

@@ -189,3 +189,52 @@ def test_item_block_order_on_one_gpu_equals_the_oracle(nb, balanced):
     u2, v2, ib2, ub2 = u0.copy(), v0.copy(), np.zeros(ni), np.zeros(nu)
     O.train_linear_kernel(2, k, 0.1, 0.01, 0, 0, 0.1, 0.1, 0.007, 0.0, u2, v2, np.ascontiguousarray(idx[perm]), np.ascontiguousarray(r[perm]), ib2, ub2)
     assert np.array_equal(u, u2) and np.array_equal(v, v2) and np.array_equal(ib, ib2) and np.array_equal(ub, ub2)
+
+
+@pytest.mark.parametrize("world,nb", [(3, 9), (2, 8)])
+def test_many_item_blocks_per_rank_in_one_process(world, nb):
+    """rank = -1 with stride = nb / world > 2 (a block rests stride - 1 steps in transit): still the sequential loop on the block order."""
+    from mfrec_amd.sharding import DsgdKMF
+    from oracle import oracle as O
+    nu, ni, nnz, k = 2500, 1900, 100000, 18
+    idx, r = synth.make_ratings(nu, ni, nnz, seed=33)
+    u0, v0 = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
+    d = DsgdKMF(idx, r, nu, ni, k, -1, world, item_blocks_1gpu=nb)
+    u, v, ib, ub = u0.copy(), v0.copy(), np.zeros(ni), np.zeros(nu)
+    d.set_factors(u, v, ib, ub)
+    d.train(0, 2, *HP)
+    d.get_factors(u, v, ib, ub)
+    perm = d.order()
+    d.close()
+    assert sorted(perm.tolist()) == list(range(nnz))
+    u2, v2, ib2, ub2 = u0.copy(), v0.copy(), np.zeros(ni), np.zeros(nu)
+    O.train_linear_kernel(2, k, 0.1, HP[0], 0, 0, HP[1], HP[2], HP[3], 0.0, u2, v2, np.ascontiguousarray(idx[perm]), np.ascontiguousarray(r[perm]), ib2, ub2)
+    assert np.array_equal(u, u2) and np.array_equal(v, v2) and np.array_equal(ib, ib2) and np.array_equal(ub, ub2)
+
+
+def test_recommender_train_on_the_block_order(monkeypatch):
+    """KMFRecommender.train(order="blocks"): the reference's RNG calls (N(0, 0.1) init, one shuffle), then the block order; equal to
+    the oracle's loop on the order the trainer reports.  Small row budgets force several user and item blocks."""
+    from mfrec_amd import sharding
+    from mfrec_amd.recommendation import KMFRecommender
+    from oracle import oracle as O
+    monkeypatch.setattr(sharding, "ROWS_PER_BLOCK", 300)
+    monkeypatch.setattr(sharding, "TRAVELLING_BYTES", 1500 * 64 * 8)
+    nu, ni, nnz, k = 4000, 1100, 90000, 64
+    idx, r = synth.make_ratings(nu, ni, nnz, seed=35)
+    assert sharding.one_gpu_block_counts(nu, ni, k) == (3, 6)
+    R = KMFRecommender(nu, ni, {"nbr_features": k, "nbr_epochs": 2})
+    R.set_ratings(idx, r)
+    np.random.seed(5)
+    R.train(kernel="train_linear_kernel", order="blocks")
+    # replay: same RNG calls, then the oracle on the reported order
+    R2 = KMFRecommender(nu, ni, {"nbr_features": k, "nbr_epochs": 2})
+    R2.set_ratings(idx, r)
+    np.random.seed(5)
+    R2.init_feature_normal(0.0, 0.1)
+    i2, r2 = R2.get_ratings(randomize_order=True)
+    perm = R.block_order
+    u2, v2, ib2, ub2 = R2.svd_u.copy(), R2.svd_v.copy(), np.zeros(ni), np.zeros(nu)
+    O.train_linear_kernel(2, k, R.feature_init, R.learning_rate, 0, 0, R.K_users, R.K_items, R.K_bias, 0.0, u2, v2,
+                          np.ascontiguousarray(i2[perm]), np.ascontiguousarray(r2[perm]), ib2, ub2)
+    assert np.array_equal(R.svd_u, u2) and np.array_equal(R.svd_v, v2) and np.array_equal(R.items_bias, ib2) and np.array_equal(R.users_bias, ub2)

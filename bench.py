@@ -870,7 +870,11 @@ def main():
             from mfrec_amd import sharding as SH
             plan.close()
             plan = None
-            d = SH.DsgdKMF(idx, r, nu, ni, k, rank, world, user_bounds=bounds, balanced=True)
+            # item blocks per GPU: as many as it takes for a block's items to fit the static resident-side epoch (cfg 3: 3 at
+            # N = 2, 2 at N = 4, 1 at N = 8; a block rests m - 1 steps in transit)
+            m_blocks = max(1, -(-(ni // world) // 42000))
+            d = SH.DsgdKMF(idx, r, nu, ni, k, rank, world, user_bounds=bounds, balanced=True,
+                           item_blocks_1gpu=(world * m_blocks if m_blocks > 1 else None))
             d.set_factors(u0, v0, np.zeros(ni), np.zeros(max(nu_local, 1)))
             d.train(LINEAR, max(a.warmup, 1), LR, KU, KI, KB)
             barrier()
@@ -885,7 +889,8 @@ def main():
                                   "workload": "%s: the same ratings, %d x %d user/item blocks, every block in its own "
                                               "minimum-level (balanced) order, block rotation over a ncclSend/Recv ring; "
                                               "bit-identical to the sequential loop on that order "
-                                              "(tests/test_gpu_fakeworld.py)" % (cfg_name, world, world)}
+                                              "(tests/test_gpu_fakeworld.py)" % (cfg_name, world, world * m_blocks),
+                                  "blocks_on_the_resident_epoch": di.get("resident_blocks")}
             d.close()
         except Exception as e:
             fail_line(rank, world, "dsgd leg", e)

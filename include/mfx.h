@@ -346,8 +346,8 @@ int mfx_als_wrmf_sharded(int nbr_epochs, int dim, double *u, double *v,
                          double lambda);
 
 /* ------------------------------------------------ exact multi-GPU mode (DSGD block rotation)
- * Users are cut into `world` blocks (one per GPU), items into n_item_blocks = world or 2 * world blocks (world = 1: any number --
- * no hand-offs; the epoch is the sequential loop on the item-block order, every block small enough on the static resident-side epoch)
+ * Users are cut into `world` blocks (one per GPU), items into n_item_blocks = any positive multiple of world blocks (in ONE process --
+ * world = 1 or rank = -1 -- the epoch is the sequential loop on the block order, every block small enough on the static resident-side epoch)
  * (stride = n_item_blocks / world).  In step h GPU g trains the ratings of block
  * (g, (stride * g + h) mod n_item_blocks) and then passes that item block (rows + biases) to GPU g-1 over xGMI
  * (ncclSend/ncclRecv), which trains it `stride` steps later: with 2 * world blocks a block rests one whole

@@ -93,14 +93,14 @@ mfx_dsgd *mfx_dsgd_create(const int32_t *idx, const double *r, int64_t nnz, int 
     TraceRange trace_("mfx:dsgd_create (block split + schedules)");
     if ((nnz > 0 && (!idx || !r)) || nnz < 0 || nu <= 0 || ni <= 0 || dim < 1 || !user_bounds || !item_bounds ||
         world < 1 || rank < -1 || rank >= world ||
-        (n_item_blocks != world && n_item_blocks != 2 * world &&
-         !((world == 1 || rank < 0) && n_item_blocks >= 1 && n_item_blocks % world == 0)) ||
+        n_item_blocks < 1 || n_item_blocks % world != 0 ||
         (flags & ~MFX_DSGD_BALANCED)) {
-        // (ONE process -- world = 1, or every rank in this process, rank = -1: any multiple of world item blocks.  The epoch is
-        //  the sequential loop on that block order: the way to put a catalogue that is larger than the register file -- and, with
-        //  several user blocks, a user side whose rows exceed the 2 GB a travelling side may have -- on the static resident-side
-        //  epoch, block by block.  Real ranks keep the two rotations that were rehearsed: world and 2 * world)
-        fail(MFX_E_ARG, "mfx_dsgd_create: bad argument (item blocks must be world or 2 * world; any multiple of world in ONE process)");
+        // (any multiple of world item blocks: stride = n_item_blocks / world, a block rests stride - 1 steps in transit.  In ONE
+        //  process -- world = 1, or every rank in this process, rank = -1 -- the epoch is the sequential loop on that block order:
+        //  the way to put a catalogue that is larger than the register file -- and, with several user blocks, a user side whose
+        //  rows exceed the 2 GB a travelling side may have -- on the static resident-side epoch, block by block; over real ranks
+        //  the same choice keeps every GPU's blocks small enough for it: tests/test_gpu_multiproc.py rehearses stride 3)
+        fail(MFX_E_ARG, "mfx_dsgd_create: bad argument (item blocks must be a positive multiple of world)");
         return nullptr;
     }
     const int B = n_item_blocks;

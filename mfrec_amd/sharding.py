@@ -162,8 +162,7 @@ class DsgdKMF(object):
             # enough runs the static resident-side epoch (its items resident, the users travel)
             # (with rank = -1 and world = G > 1: G user blocks as well -- a user side whose rows exceed the 2 GB a travelling side may
             #  have -- and any multiple of G item blocks; the order is dsgd_block_order's)
-            if self.world != 1 and self.rank >= 0:
-                raise ValueError("item_blocks_1gpu needs ONE process (world = 1, or rank = -1)")
+            # (real ranks: the same block counts keep every GPU's blocks small enough for the static epoch)
             nb = int(item_blocks_1gpu)
             if nb % self.world:
                 raise ValueError("item_blocks_1gpu must be a multiple of world")

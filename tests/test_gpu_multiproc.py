@@ -68,7 +68,8 @@ u0, v0 = synth.init_normal(K, NI, 1), synth.init_normal(K, NU, 2)
 res = {}
 if mode.startswith("dsgd"):
     overlap, balanced = "overlap" in mode, "balanced" in mode
-    d = SH.DsgdKMF(idx, r, NU, NI, K, rank, world, overlap=overlap, balanced=balanced)
+    d = SH.DsgdKMF(idx, r, NU, NI, K, rank, world, overlap=overlap, balanced=balanced,
+                   item_blocks_1gpu=3 * world if "stride3" in mode else None)
     lo, hi = int(d.user_bounds[rank]), int(d.user_bounds[rank + 1])
     d.set_factors(u0, np.ascontiguousarray(v0[:, lo:hi]), np.zeros(NI), np.zeros(hi - lo))
     se = d.train(0, E, *HP)
@@ -143,12 +144,14 @@ def _problem():
     return idx, r, synth.init_normal(K, NI, 1), synth.init_normal(K, NU, 2)
 
 
-@pytest.mark.parametrize("world,mode,port", [(2, "dsgd", 29711), (3, "dsgd,balanced", 29712), (2, "dsgd,overlap", 29713)])
+@pytest.mark.parametrize("world,mode,port", [(2, "dsgd", 29711), (3, "dsgd,balanced", 29712), (2, "dsgd,overlap", 29713),
+                                             (2, "dsgd,stride3,balanced", 29714)])
 def test_block_rotation_over_real_processes_equals_the_fake_world(mock_lib, tmp_path, world, mode, port):
     from mfrec_amd import sharding as SH
     idx, r, u0, v0 = _problem()
     res = _launch(mock_lib, tmp_path, world, mode, port)
-    d = SH.DsgdKMF(idx, r, NU, NI, K, -1, world, overlap="overlap" in mode, balanced="balanced" in mode)
+    d = SH.DsgdKMF(idx, r, NU, NI, K, -1, world, overlap="overlap" in mode, balanced="balanced" in mode,
+                   item_blocks_1gpu=3 * world if "stride3" in mode else None)
     d.set_factors(u0, v0, np.zeros(NI), np.zeros(NU))
     se = d.train(0, E, *HP)
     u, v, ib, ub = np.zeros((K, NI)), np.zeros((K, NU)), np.zeros(NI), np.zeros(NU)

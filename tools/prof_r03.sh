@@ -12,6 +12,8 @@ export MFX_BENCH_TRACE=1
 echo "[prof] default bench, one process, kernel trace"
 MFX_GRAPH=0 timeout -k 5 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/all -- python3 bench.py --steps 5 --warmup 1 --no-cpu > $O/bench_all.json 2> $O/all.log
 echo "[prof] rc=$? ; $(grep -c 'stage\|leg' $O/all.log) stage lines; last: $(grep 'stage\|leg' $O/all.log | tail -1)"
+echo "[prof] headline leg alone, kernel trace"
+MFX_GRAPH=0 timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/head -- python3 bench.py --no-cpu --no-also > $O/bench_head.json 2> $O/head.log
 echo "[prof] fetch"; timeout -k 5 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-also > $O/bench_fetch.json 2> $O/fetch.log
 echo "[prof] write"; timeout -k 5 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-also > $O/bench_write.json 2> $O/write.log
 echo "[prof] cfg3 user-resident fetch"; timeout -k 5 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch3 -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-also --users 1000000 --items 200000 --nnz 100000000 --order user-major > $O/bench_fetch3.json 2> $O/fetch3.log

@@ -589,6 +589,9 @@ def main():
                          "GPU gets a job-sized user shard of its own")
     ap.add_argument("--epoch", choices=["auto", "levels", "ticket", "static"], default="auto",
                     help="kernel of a full-k epoch (include/mfx.h MFX_EPOCH_*): auto = the library's cost model")
+    ap.add_argument("--avg-epoch", choices=["blocks", "levels"], default="blocks",
+                    help="N > 1: the local epoch of a user shard -- `blocks`: its ratings on the item-block order, every block on the "
+                         "static resident-side epoch, one all-reduce per item block; `levels`: the given order on the level schedule")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--no-also", action="store_true", help="skip the `also` block (secondary kernels)")
     ap.add_argument("--no-extra", action="store_true", help=argparse.SUPPRESS)   # accepted, no-op
@@ -714,8 +717,40 @@ def main():
     else:
         v0 = v0_full
     my_nnz = my_r.shape[0]
-    # (N > 1: the user-sharded averaging mode combines after every epoch through a hook and runs on the level schedule)
-    plan = SgdPlan(my_idx, my_r, max(nu_local, 1), ni, k, storage=a.storage, epoch=a.epoch if not multi else "levels")
+    # (N > 1: the user-sharded averaging mode.  A shard holds ALL items -- too many for the static resident-side epoch at cfg 3 --, so
+    #  its local epoch runs on the item-block order (sharding.ShardedKMFBlocks: every block on the static epoch, one all-reduce of the
+    #  item deltas per block), or, --avg-epoch levels, the given order on the level schedule with one all-reduce per epoch)
+    use_blocks = multi and a.avg_epoch == "blocks" and a.storage == "f64" and a.order == "shuffled" and ni > 42000
+    sb = None
+    if use_blocks:
+        from mfrec_amd.sharding import ShardedKMFBlocks
+
+        class BlocksPlan(object):                       # what the code below asks of a plan
+            def __init__(self):
+                t0 = time.perf_counter()
+                self.sb = ShardedKMFBlocks(my_idx, my_r, max(nu_local, 1), ni, k, rank, world, already_local=True)
+                self.build_us = (time.perf_counter() - t0) * 1e6
+
+            def set_factors(self, u, v, ib, ub):
+                self.sb.d.set_factors(u, v, ib, ub)
+
+            def info(self):
+                i = self.sb.info()
+                res = i["resident_blocks"] == i["item_blocks"]
+                return {"n_levels": i["levels_total"], "launches_per_epoch": i["item_blocks"] if res else i["launches_per_epoch"],
+                        "schedule_us": self.build_us, "epoch_kernel": "static, one launch per item block (%d blocks)" % i["item_blocks"]
+                        if res else "levels per item block (%d blocks)" % i["item_blocks"], "item_blocks": i["item_blocks"]}
+
+            def kernel_name(self, mode):
+                return "k1_res (static), one persistent launch per item block; RCCL all-reduce of the block's item deltas behind it"
+
+            def close(self):
+                self.sb.close()
+
+        plan = BlocksPlan()
+        sb = plan.sb
+    else:
+        plan = SgdPlan(my_idx, my_r, max(nu_local, 1), ni, k, storage=a.storage, epoch=a.epoch if not multi else "levels")
     plan.set_factors(u0, v0, np.zeros(ni), np.zeros(max(nu_local, 1)))
     info = plan.info()
     kernel_name = plan.kernel_name(LINEAR)          # the instantiation the library launches, from the library
@@ -724,7 +759,10 @@ def main():
     def run(n):
         if n <= 0:
             return
-        if multi:
+        if use_blocks:
+            se = sb.train(LINEAR, n, LR, KU, KI, KB, 1.0 / world)
+            last_rmse["se_local"] = float(se[-1])
+        elif multi:
             rm, se = plan.run_kmf_sharded(LINEAR, n, LR, KU, KI, KB, 1.0 / world)
             last_rmse["se_local"] = float(se[-1])
         else:
@@ -767,8 +805,8 @@ def main():
     # kernels (and, at N > 1, the delta / all-reduce / combine step), so this is an upper bound of the
     # kernel's own duration and agrees with rocprofv3's average (profiles/).
     mark("per-launch event pairs (profile_kmf)")
-    resident = (not multi) and info.get("epoch_kernel", "levels") != "levels" and a.storage == "f64"
-    launches = epoch_launches(info) if resident else info["launches_per_epoch"]
+    resident = use_blocks or ((not multi) and info.get("epoch_kernel", "levels") != "levels" and a.storage == "f64")
+    launches = info["launches_per_epoch"] if use_blocks else (epoch_launches(info) if resident else info["launches_per_epoch"])
     b_read, b_total = algorithmic_bytes(k, nnz, nu)
     avg_launch_s = dev_ms * 1e-3 / (a.steps * launches)
     achieved = (b_read * my_nnz / launches) / avg_launch_s
@@ -806,14 +844,15 @@ def main():
                                    "(train_linear_kernel), %s order, exact (bit-identical to the sequential loop), epoch kernel: %s%s" % (
                                        cfg_name, nu // 1000, ni // 1000, nnz // 1000000,
                                        " per GPU" if (world > 1 and a.scaling == "weak") else "", k, a.order,
-                                       info.get("epoch_kernel", "levels") if not multi else "levels",
+                                       info.get("epoch_kernel", "levels") if (not multi or use_blocks) else "levels",
                                        "" if not multi else
                                        ", users sharded over %d GPUs, item factors replicated, RCCL all-reduce of the "
                                        "item deltas every epoch (parameter averaging, scale 1/%d)" % (world, world)),
                        "users": nu, "items": ni, "ratings": job_nnz, "ratings_this_gpu": my_nnz, "k": k,
                        "levels": info["n_levels"], "launches_per_epoch": launches,
-                       "epoch_kernel": info.get("epoch_kernel", "levels") if not multi else "levels",
-                       "sharding": "users x%d, item-delta all-reduce (RCCL)" % world if multi else "none"},
+                       "epoch_kernel": info.get("epoch_kernel", "levels") if (not multi or use_blocks) else "levels",
+                       "sharding": ("users x%d, item-delta all-reduce (RCCL)%s" % (world, " per item block; a shard's local order: "
+                                    "its item-block order" if use_blocks else "")) if multi else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_read * my_nnz / launches,

@@ -387,6 +387,12 @@ int mfx_dsgd_set_factors(mfx_dsgd *d, const double *u, const double *v, const do
 /* se_out: nullable f64[nbr_epochs], squared-error sum of every epoch over all ratings of the job */
 int mfx_dsgd_run_kmf(mfx_dsgd *d, int mode, int nbr_epochs, double learning_rate, double K_users,
                      double K_items, double K_bias, double *se_out);
+/* The averaging scheme of mfx_sgd_run_kmf_sharded (gradient_descent.py:124-211: user shards, parameter averaging) with the shard's
+ * local epoch on the block order: `d` was created with world = 1 over ONE rank's ratings (local user ids) and any number of item
+ * blocks; per epoch and item block the block is trained, then its rows and biases become start + scale * allreduce_sum(delta) over
+ * the communicator of mfx_comm_init (none / world 1: no combine).  se_out (nullable): f64[nbr_epochs], this rank's squared errors. */
+int mfx_dsgd_run_kmf_averaged(mfx_dsgd *d, int mode, int nbr_epochs, double learning_rate, double K_users, double K_items,
+                              double K_bias, double scale, double *se_out);
 int mfx_dsgd_get_factors(mfx_dsgd *d, double *u, double *v, double *items_bias, double *users_bias);
 
 #ifdef __cplusplus

@@ -152,6 +152,19 @@ int comm_allgather_f64(double *buf, size_t count)
     MFX_NCCL(R.AllGather(buf + (size_t)g_rank * count, buf, count, ncclFloat64, g_comm, mfx::stream()));
     return MFX_OK;
 }
+// cur <- start + scale * allreduce_sum(cur - start), start <- the same value (the next epoch's start): the combine step of the
+// averaging scheme (shard_hook above) for one array on the library stream.  No communicator: nothing happens (a single shard is the
+// sequential algorithm itself).
+int comm_average_f64(double *cur, double *start, size_t n, double scale)
+{
+    if (!g_comm || !n) return MFX_OK;
+    hipStream_t s = mfx::stream();
+    hipLaunchKernelGGL(k_sub, dim3(grid_for(n)), dim3(256), 0, s, cur, (const double *)start, n);
+    MFX_NCCL(R.AllReduce(cur, cur, n, ncclFloat64, ncclSum, g_comm, s));
+    hipLaunchKernelGGL(k_combine, dim3(grid_for(n)), dim3(256), 0, s, cur, start, scale, n);
+    MFX_HIP(hipGetLastError());
+    return MFX_OK;
+}
 int comm_allreduce_sum_f64(double *buf, size_t count)
 {
     if (!g_comm || !count) return MFX_OK;

@@ -63,6 +63,8 @@ struct mfx_dsgd {
     std::vector<DsgdRank> ranks;            // 1 (a real rank) or world (fake world)
     bool have_factors = false;
     int64_t nnz_local = 0;
+    std::vector<double *> avg_startU, avg_startib;   // averaging mode on the block order: the epoch's start of every item block
+    bool avg_fresh = false;                          // start buffers hold the current rows
     hipStream_t xfer = nullptr;             // transfer stream
 };
 
@@ -83,6 +85,8 @@ void mfx_dsgd_destroy(mfx_dsgd *d)
             if (r.plans[j]) mfx_sgd_plan_destroy(r.plans[j]);
     }
     if (d->xfer) (void)hipStreamDestroy(d->xfer);
+    for (double *q : d->avg_startU) if (q) (void)hipFree(q);
+    for (double *q : d->avg_startib) if (q) (void)hipFree(q);
     delete d;
 }
 
@@ -356,6 +360,7 @@ int mfx_dsgd_set_factors(mfx_dsgd *d, const double *u, const double *v, const do
         }
     }
     d->have_factors = true;
+    d->avg_fresh = false;
     return MFX_OK;
 }
 
@@ -461,6 +466,67 @@ int mfx_dsgd_run_kmf(mfx_dsgd *d, int mode, int nbr_epochs, double lr, double Ku
             }
         }
         memcpy(se_out, se.data(), (size_t)nbr_epochs * sizeof(double));
+    }
+    return MFX_OK;
+}
+
+// north_star's averaging scheme (user shards + an RCCL all-reduce of the item deltas per epoch, mfx_sgd_run_kmf_sharded) with the
+// shard's local epoch on the BLOCK ORDER: this object was created with world = 1 over ONE rank's ratings (local user ids) and any
+// number of item blocks, so that every block runs the static resident-side epoch instead of the level schedule (a shard holds ALL
+// items: 200 K at cfg 3).  Per epoch and item block j: train the block, then U_j <- U_start_j + scale * allreduce_sum(U_j -
+// U_start_j) (items_bias alike) -- element for element the arithmetic of the whole-array all-reduce; with no communicator (one
+// rank) nothing is combined and the epoch is the sequential loop on the block order.  se_out (nullable): this rank's squared-error
+// sums per epoch.
+int mfx_dsgd_run_kmf_averaged(mfx_dsgd *d, int mode, int nbr_epochs, double lr, double Ku, double Ki, double Kb, double scale,
+                              double *se_out)
+{
+    TraceRange trace_("mfx:dsgd_run_kmf_averaged (block order + RCCL all-reduce per item block)");
+    if (!d) return fail(MFX_E_ARG, "mfx_dsgd_run_kmf_averaged: NULL");
+    if (d->world != 1) return fail(MFX_E_ARG, "mfx_dsgd_run_kmf_averaged: the object must hold ONE rank's ratings (created with world = 1)");
+    if (!d->have_factors) return fail(MFX_E_STATE, "mfx_dsgd_run_kmf_averaged: mfx_dsgd_set_factors has not been called");
+    if (mode != MFX_MODE_LINEAR && mode != MFX_MODE_LOGISTIC) return fail(MFX_E_ARG, "mfx_dsgd_run_kmf_averaged: mode %d", mode);
+    if (nbr_epochs <= 0) return MFX_OK;
+    const int B = d->B;
+    DsgdRank &R = d->ranks[0];
+    hipStream_t s = stream();
+    int rc;
+    const bool comm = comm_active() && comm_world() > 1;
+    if (comm) {
+        if (d->avg_startU.empty()) { d->avg_startU.assign((size_t)B, nullptr); d->avg_startib.assign((size_t)B, nullptr); }
+        for (int j = 0; j < B; ++j) {
+            const size_t nb = (size_t)plan_ni(R.plans[j]), nU = nb * d->k;
+            if (!d->avg_startU[j]) {
+                MFX_HIP(hipMalloc((void **)&d->avg_startU[j], nU * sizeof(double)));
+                MFX_HIP(hipMalloc((void **)&d->avg_startib[j], nb * sizeof(double)));
+            }
+            if (!d->avg_fresh) {
+                MFX_HIP(hipMemcpyAsync(d->avg_startU[j], plan_U(R.plans[j]), nU * sizeof(double), hipMemcpyDeviceToDevice, s));
+                MFX_HIP(hipMemcpyAsync(d->avg_startib[j], plan_ib(R.plans[j]), nb * sizeof(double), hipMemcpyDeviceToDevice, s));
+            }
+        }
+        d->avg_fresh = true;
+    }
+    for (mfx_sgd_plan *p : R.plans)
+        if ((rc = sgd_reset_se(p, nbr_epochs))) return rc;
+    for (int ep = 0; ep < nbr_epochs; ++ep)
+        for (int j = 0; j < B; ++j) {
+            if ((rc = sgd_enqueue_k1(R.plans[j], mode, lr, Ku, Ki, Kb))) return rc;
+            if (comm) {
+                const size_t nb = (size_t)plan_ni(R.plans[j]);
+                if ((rc = comm_average_f64(plan_U(R.plans[j]), d->avg_startU[j], nb * d->k, scale))) return rc;
+                if ((rc = comm_average_f64(plan_ib(R.plans[j]), d->avg_startib[j], nb, scale))) return rc;
+            }
+        }
+    MFX_HIP(hipStreamSynchronize(s));
+    for (mfx_sgd_plan *p : R.plans)
+        if ((rc = sgd_res_check(p))) return rc;
+    if (se_out) {
+        std::vector<double> per((size_t)nbr_epochs);
+        for (int ep = 0; ep < nbr_epochs; ++ep) se_out[ep] = 0.0;
+        for (int j = 0; j < B; ++j) {
+            if ((rc = sgd_fetch_se(R.plans[j], nbr_epochs, per.data()))) return rc;
+            for (int ep = 0; ep < nbr_epochs; ++ep) se_out[ep] += per[(size_t)ep];
+        }
     }
     return MFX_OK;
 }

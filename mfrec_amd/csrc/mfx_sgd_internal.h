@@ -107,6 +107,7 @@ int comm_rank();
 int comm_world();
 int comm_allgather_f64(double *buf, size_t count);          // in place: rank g's part at buf + g*count
 int comm_allreduce_sum_f64(double *buf, size_t count);      // in place, library stream
+int comm_average_f64(double *cur, double *start, size_t n, double scale);   // cur <- start + scale * allreduce(cur - start); start <- cur
 int comm_broadcast_f64(double *buf, size_t count, int root);
 // one fused group on stream `st` (nullptr: the library stream): send every (ptr, count) of `out` to `to`,
 // receive every (ptr, count) of `in` from `from`

@@ -217,6 +217,16 @@ class DsgdKMF(object):
                                          float(K_users), float(K_items), float(K_bias), S.f64(se, "se", 1)))
         return se[:int(nbr_epochs)]
 
+    def train_averaged(self, mode, nbr_epochs, learning_rate, K_users, K_items, K_bias, scale):
+        """world = 1 objects only (ONE rank's ratings): the averaging scheme with the local epoch on the block order -- per item block
+        an all-reduce of its deltas over the communicator of mfx_comm_init (mfx_dsgd_run_kmf_averaged).  -> this rank's squared-error
+        sums per epoch."""
+        from . import _shim as S
+        se = np.zeros(max(int(nbr_epochs), 1))
+        S.check(S.lib().mfx_dsgd_run_kmf_averaged(self._h, int(mode), int(nbr_epochs), float(learning_rate), float(K_users),
+                                                  float(K_items), float(K_bias), float(scale), S.f64(se, "se", 1)))
+        return se[:int(nbr_epochs)]
+
     def get_factors(self, u, v, items_bias=None, users_bias=None):
         from . import _shim as S
         S.check(S.lib().mfx_dsgd_get_factors(self._h, *self._args(u, v, items_bias, users_bias)))
@@ -265,6 +275,59 @@ class ShardedKMF(object):
 
     def close(self):
         self.plan.close()
+
+
+class ShardedKMFBlocks(object):
+    """One rank of the user-sharded averaging scheme (ShardedKMF) with its local epoch on the BLOCK ORDER: the rank's shard holds ALL
+    items (200 K at cfg 3: too many for the static resident-side epoch, so ShardedKMF's plan runs on the level schedule); cut into
+    item blocks every block runs the static epoch, and the item deltas are all-reduced per block (mfx_dsgd_run_kmf_averaged).  Same
+    scheme, same arithmetic per element; the shard's local order is the block order (order())."""
+
+    def __init__(self, ratings_index, ratings, nbr_users, nbr_items, dim, rank, world, bounds=None, balanced=True,
+                 item_blocks=None, already_local=False):
+        """already_local: ratings_index / ratings are THIS rank's shard already (user ids local, nbr_users = its user count)."""
+        self.rank, self.world, self.k = int(rank), int(world), int(dim)
+        if already_local:
+            self.bounds = None
+            idx, r, self.user_lo, self.nu_local = ratings_index, ratings, 0, int(nbr_users)
+        else:
+            self.bounds = user_blocks(ratings_index, nbr_users, world) if bounds is None else bounds
+            idx, r, self.user_lo, self.nu_local = shard(ratings_index, ratings, self.bounds, rank)
+        self.ni = int(nbr_items)
+        self.nnz_local = r.shape[0]
+        ub, nb = one_gpu_block_counts(max(self.nu_local, 1), nbr_items, dim)
+        if ub != 1:
+            raise ValueError("ShardedKMFBlocks: this rank's user rows exceed 2 GB (%d users): more ranks, or ShardedKMF" % self.nu_local)
+        nb = int(item_blocks) if item_blocks else nb
+        # the SAME item bounds on every rank (an all-reduce pairs block j with block j): equal id ranges, not balanced by a
+        # shard's own rating counts
+        item_bounds = (np.arange(nb + 1, dtype=np.int64) * int(nbr_items)) // nb
+        self.d = DsgdKMF(idx, r, max(self.nu_local, 1), nbr_items, dim, -1, 1, balanced=balanced, item_bounds=item_bounds,
+                         item_blocks_1gpu=nb)
+
+    def set_factors(self, u, v_full, items_bias, users_bias_full):
+        lo, n = self.user_lo, self.nu_local
+        self.d.set_factors(u, np.ascontiguousarray(v_full[:, lo:lo + max(n, 1)]), items_bias,
+                           np.ascontiguousarray(users_bias_full[lo:lo + max(n, 1)]))
+
+    def train(self, mode, nbr_epochs, learning_rate, K_users, K_items, K_bias, scale=None):
+        scale = 1.0 / self.world if scale is None else scale
+        return self.d.train_averaged(mode, nbr_epochs, learning_rate, K_users, K_items, K_bias, scale)
+
+    def get_local(self):
+        u = np.zeros((self.k, self.ni)); v = np.zeros((self.k, max(self.nu_local, 1)))
+        ib = np.zeros(self.ni); ub = np.zeros(max(self.nu_local, 1))
+        self.d.get_factors(u, v, ib, ub)
+        return u, v, ib, ub
+
+    def info(self):
+        return self.d.info()
+
+    def order(self):
+        return self.d.order()
+
+    def close(self):
+        self.d.close()
 
 
 # ------------------------------------------------------------------------------------------

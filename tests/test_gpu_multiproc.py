@@ -84,6 +84,14 @@ elif mode == "avg":
     u, v, ib, ub = s.get_local()
     res = dict(u=u, v=v[:, :s.nu_local], ib=ib, ub=ub[:s.nu_local], se=np.asarray(se), lo=s.user_lo, hi=s.user_lo + s.nu_local)
     s.close()
+elif mode == "avgblocks":
+    s = SH.ShardedKMFBlocks(idx, r, NU, NI, K, rank, world, item_blocks=3)
+    s.set_factors(u0, v0, np.zeros(NI), np.zeros(NU))
+    se = s.train(0, E, *HP)
+    u, v, ib, ub = s.get_local()
+    res = dict(u=u, v=v[:, :s.nu_local], ib=ib, ub=ub[:s.nu_local], se=np.asarray(se), lo=s.user_lo, hi=s.user_lo + s.nu_local,
+               order=s.order())
+    s.close()
 elif mode == "funk":
     from mfrec_amd.plan import SgdPlan
     rs = np.random.RandomState(4)
@@ -178,6 +186,37 @@ def test_averaging_mode_over_real_processes_equals_the_fake_world(mock_lib, tmp_
     f.train(0, E, *HP)
     u, v, ib, ub = f.get_factors()
     f.close()
+    for z in res:
+        lo, hi = int(z["lo"]), int(z["hi"])
+        assert np.array_equal(z["u"], u) and np.array_equal(z["ib"], ib)
+        assert np.array_equal(z["v"], v[:, lo:hi]) and np.array_equal(z["ub"], ub[lo:hi])
+
+
+def test_averaging_mode_on_the_block_order_over_real_processes_equals_its_simulation(mock_lib, tmp_path):
+    """ShardedKMFBlocks (mfx_dsgd_run_kmf_averaged): the averaging scheme with every shard's local epoch on ITS block order and one
+    all-reduce per item block, two real ranks -- against the CPU simulation of the same scheme: per epoch every shard runs the
+    oracle's epoch (kmf_train.pyx:243-270) on its ratings in the order the rank reports, from the common item state; the deltas
+    are added in rank order and combined with scale 1/2 (sharding.combine)."""
+    from mfrec_amd import sharding as SH
+    from oracle import oracle as O
+    idx, r, u0, v0 = _problem()
+    res = _launch(mock_lib, tmp_path, 2, "avgblocks", 29761)
+    bounds = SH.user_blocks(idx, NU, 2)
+    shards = [SH.shard(idx, r, bounds, g) for g in range(2)]
+    u, ib, v, ub = u0.copy(), np.zeros(NI), v0.copy(), np.zeros(NU)
+    for _ in range(E):
+        du, dib = np.zeros_like(u), np.zeros_like(ib)
+        for g, (sidx, sr, lo, n) in enumerate(shards):
+            perm = res[g]["order"]
+            assert sorted(perm.tolist()) == list(range(sr.shape[0]))
+            ug, ibg = u.copy(), ib.copy()
+            vg, ubg = np.ascontiguousarray(v[:, lo:lo + n]), np.ascontiguousarray(ub[lo:lo + n])
+            O.train_linear_kernel(1, K, 0.1, HP[0], 0, 0, HP[1], HP[2], HP[3], 0.0, ug, vg, np.ascontiguousarray(sidx[perm]),
+                                  np.ascontiguousarray(sr[perm]), ibg, ubg)
+            v[:, lo:lo + n] = vg; ub[lo:lo + n] = ubg
+            du += ug - u
+            dib += ibg - ib
+        u, ib = SH.combine(u, du, 0.5), SH.combine(ib, dib, 0.5)
     for z in res:
         lo, hi = int(z["lo"]), int(z["hi"])
         assert np.array_equal(z["u"], u) and np.array_equal(z["ib"], ib)

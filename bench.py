@@ -742,7 +742,10 @@ def main():
                         if res else "levels per item block (%d blocks)" % i["item_blocks"], "item_blocks": i["item_blocks"]}
 
             def kernel_name(self, mode):
-                return "k1_res (static), one persistent launch per item block; RCCL all-reduce of the block's item deltas behind it"
+                i = self.sb.info()
+                if i["resident_blocks"] == i["item_blocks"]:
+                    return "k1_res (static), one persistent launch per item block; RCCL all-reduce of the block's item deltas behind it"
+                return "k1_level per item block (%d of %d blocks on the static epoch); RCCL all-reduce per block" % (i["resident_blocks"], i["item_blocks"])
 
             def close(self):
                 self.sb.close()

@@ -576,7 +576,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=["auto", "cfg2", "cfg3"], default="auto",
                     help="auto = cfg2 at N=1 (the config the metric is quoted on), cfg3 user-sharded at N>1")
     ap.add_argument("--users", type=int, default=None)

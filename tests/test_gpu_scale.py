@@ -14,7 +14,10 @@
     rows in registers and runs taken by ticket (MFX_EPOCH_TICKET, chosen by the cost model), ONE epoch, bit for bit
     against the oracle;
   * cfg 5 WHOLE (10 M x 1 M, 1 B ratings, k=64) on one GPU: properties -- device-built schedule and its level
-    count, finite and strictly decreasing online RMSE, host and device builders agree on a 100 M-rating prefix."""
+    count, finite and strictly decreasing online RMSE, host and device builders agree on a 100 M-rating prefix; and the same
+    billion ratings on the ONE-GPU block order (3 user x 24 item blocks, all 72 on the static resident-side epoch);
+  * cfg 3 whole on the ONE-GPU block order (5 item blocks, each in its minimum-level order): one epoch, bit for bit against the
+    oracle on the order the trainer reports."""
 import ctypes as C
 import time
 
@@ -112,6 +115,30 @@ def _sampled_residuals(Y, X, off, col, rows, c_pos, lam):
     return worst
 
 
+def test_cfg3_whole_block_order_bitexact_vs_oracle(cfg3_data):
+    """cfg 3 whole on the ONE-GPU block order (sharding.kmf_train_block_order: 200 K items do not fit the static resident-side epoch
+    at once, five item blocks do; every block in its own minimum-level order): one epoch, bit for bit against the oracle's
+    sequential loop (kmf_train.pyx:243-270) ON THE ORDER THE TRAINER REPORTS."""
+    from mfrec_amd import sharding
+    from oracle import oracle as O
+    nu, ni, nnz, idx, r = cfg3_data
+    k = 64
+    assert sharding.one_gpu_block_counts(nu, ni, k) == (1, 5)
+    u0, v0 = synth.init_normal(k, ni, 7), synth.init_normal(k, nu, 8)
+    u, v, ib, ub = u0.copy(), v0.copy(), np.zeros(ni), np.zeros(nu)
+    perm = sharding.kmf_train_block_order(0, 1, k, HP[0], HP[1], HP[2], HP[3], u, v, idx, r, ib, ub)
+    assert perm.shape[0] == nnz and int(perm.sum()) == nnz * (nnz - 1) // 2
+    pidx, pr = np.ascontiguousarray(idx[perm]), np.ascontiguousarray(r[perm])
+    # the order groups the ratings by item block: block ids never decrease along it
+    bounds = sharding.item_blocks(idx, ni, 5)
+    jb = np.searchsorted(bounds, pidx[:, 1], side="right") - 1
+    assert jb[0] == 0 and jb[-1] == 4 and np.all(np.diff(jb) >= 0)
+    ib2, ub2 = np.zeros(ni), np.zeros(nu)
+    O.train_linear_kernel(1, k, 0.1, HP[0], 0, 0, HP[1], HP[2], HP[3], 0.0, u0, v0, pidx, pr, ib2, ub2)
+    assert np.array_equal(u, u0) and np.array_equal(v, v0)          # u0 / v0 now hold the oracle's result
+    assert np.array_equal(ib, ib2) and np.array_equal(ub, ub2)
+
+
 def test_cfg4_full_size_als_epoch_residuals(cfg3_data):
     import scipy.sparse as sp
     from mfrec_amd import _shim as S
@@ -197,6 +224,20 @@ def test_cfg5_whole_one_gpu_properties():
     assert np.all(np.isfinite(rm)) and np.all(np.diff(rm) < 0), rm
     assert np.isfinite(u0).all() and np.isfinite(v0).all() and np.isfinite(ib).all() and np.isfinite(ub).all()
     del u0, v0
+    # the same billion ratings on the ONE-GPU block order (3 user x 24 item blocks: a user side above 2 GB is cut too): every block
+    # on the static resident-side epoch, the order a permutation, online RMSE finite and strictly decreasing
+    from mfrec_amd import sharding
+    assert sharding.one_gpu_block_counts(nu, ni, k) == (3, 24)
+    d = sharding.DsgdKMF(idx, r, nu, ni, k, -1, 3, item_blocks_1gpu=24)
+    dinfo = d.info()
+    d.set_factors(synth.init_normal(k, ni, 7), synth.init_normal(k, nu, 8), np.zeros(ni), np.zeros(nu))
+    se = np.concatenate([d.train(0, 2, *HP), d.train(0, 1, *HP)])
+    perm = d.order()
+    d.close()
+    assert dinfo["item_blocks"] == 24 and dinfo["resident_blocks"] == 72, dinfo
+    assert perm.shape[0] == nnz and int(perm.sum()) == nnz * (nnz - 1) // 2
+    del perm
+    assert np.all(np.isfinite(se)) and np.all(np.diff(se) < 0), se
     # host and device builders on the first 100 M ratings of the same tables: same level structure
     n = 100000000
     pidx, pr = np.ascontiguousarray(idx[:n]), np.ascontiguousarray(r[:n])

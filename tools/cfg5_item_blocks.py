@@ -16,6 +16,7 @@ ap.add_argument("--k", type=int, default=64)
 ap.add_argument("--epochs", type=int, default=2)
 ap.add_argument("--blocks", type=int, default=0)
 ap.add_argument("--user-blocks", type=int, default=3, help="user blocks (rows of a travelling side must stay below 2 GB)")
+ap.add_argument("--balanced", action="store_true", help="every block in its own minimum-level order")
 ap.add_argument("--workers", type=int, default=min(16, os.cpu_count() or 1))
 a = ap.parse_args()
 nu, ni, nnz, k = a.users, a.items, a.nnz, a.k
@@ -34,13 +35,13 @@ def heartbeat():
 
 threading.Thread(target=heartbeat, daemon=True).start()
 S.init(0)
-out = {"config": "cfg5 whole on one GPU, block order: %d users x %d items, %d ratings, k=%d, %d user x %d item blocks" % (nu, ni, nnz, k, a.user_blocks, nb)}
+out = {"balanced": bool(a.balanced), "config": "cfg5 whole on one GPU, block order: %d users x %d items, %d ratings, k=%d, %d user x %d item blocks" % (nu, ni, nnz, k, a.user_blocks, nb)}
 t0 = time.time()
 idx, r = synth.make_ratings(nu, ni, nnz, workers=a.workers)
 out["data_s"] = time.time() - t0
 print("data %.1f s" % out["data_s"], flush=True)
 t0 = time.time()
-d = DsgdKMF(idx, r, nu, ni, k, -1, a.user_blocks, item_blocks_1gpu=nb)
+d = DsgdKMF(idx, r, nu, ni, k, -1, a.user_blocks, balanced=a.balanced, item_blocks_1gpu=nb)
 out["create_s"] = time.time() - t0
 info = d.info()
 out.update({"resident_blocks": info["resident_blocks"], "levels_total": info["levels_total"], "largest_block": info["max_block"]})

@@ -1040,7 +1040,8 @@ def main():
                                  "note": "measured ceiling of the access pattern: 5.5 G ratings/s (tools/rmw_ceiling.hip)"},
                     "workload": "cfg3 whole on ONE GPU, ITEM-BLOCK order: the given (shuffled) ratings grouped by %d item blocks (stable), "
                                 "every block in its own minimum-level order; exact on that order (bit-identical to the sequential loop: "
-                                "tests/test_gpu_fakeworld.py)" % nb}
+                                "tests/test_gpu_fakeworld.py, tests/test_gpu_scale.py).  The N = 1 point of the curve `--gpus N` continues: "
+                                "at N > 1 every user shard runs this very local epoch (item blocks on the static resident-side epoch)" % nb}
             except Exception as e:
                 out["k1_cfg3_item_blocks_1gpu"] = {"error": repr(e)}
             del r3

@@ -1007,12 +1007,13 @@ def main():
             except Exception as e:
                 out["k1_user_resident_cfg3"] = {"error": repr(e)}
             # the same 100 M ratings on the item-block order (sharding.DsgdKMF, world = 1): 200 K items do not fit the register file
-            # at once, five blocks of ~40 K do -- every block on the static resident-side epoch; exact on that order.  Twice: the
+            # at once, four blocks of 50 K do -- every block on the static resident-side epoch; exact on that order.  Twice: the
             # given order inside the blocks, and every block in its own minimum-level (balanced) order (`value`)
             try:
                 from mfrec_amd.sharding import DsgdKMF
                 from mfrec_amd.plan import Timer
-                nb = -(-ni3 // 42000)
+                from mfrec_amd.sharding import one_gpu_block_counts
+                nb = one_gpu_block_counts(nu3, ni3, k3)[1]
                 res_b = {}
                 for bal in (False, True):
                     t0 = time.perf_counter()

@@ -261,7 +261,9 @@ mfx_dsgd *mfx_dsgd_create(const int32_t *idx, const double *r, int64_t nnz, int 
                         borig[b].swap(no2);
                     }
                 }
-                R.plans[j] = plan_create_ex(bidx[b].data(), br[b].data(), cnt[b], nul, nil, dim, MFX_SCHED_AUTO, MFX_EPOCH_AUTO | kEpochHeadroom);
+                // (headroom: an eighth of the wave slots stays free for the transfer kernels that run beside a block -- none with world = 1)
+                R.plans[j] = plan_create_ex(bidx[b].data(), br[b].data(), cnt[b], nul, nil, dim, MFX_SCHED_AUTO,
+                                            MFX_EPOCH_AUTO | (world > 1 ? kEpochHeadroom : 0));
                 if (!R.plans[j] || (j > 0 && plan_alias_users(R.plans[j], R.plans[0])) ||
                     hipEventCreateWithFlags(&R.trained[j], hipEventDisableTiming) != hipSuccess ||
                     hipEventCreateWithFlags(&R.arrived[j], hipEventDisableTiming) != hipSuccess) {

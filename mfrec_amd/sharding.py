@@ -334,6 +334,7 @@ class ShardedKMFBlocks(object):
 # ONE GPU, a problem whose smaller side does not fit the register file: the block order
 # ------------------------------------------------------------------------------------------
 ROWS_PER_BLOCK = 42000          # what the static resident-side epoch holds at k = 64 with headroom (18 slots x 3 072 waves x 7/8)
+ROWS_PER_BLOCK_ALONE = 52000    # ... and with the whole grid (one user block: nothing runs beside a block; 18 x 3 072 = 55 296)
 TRAVELLING_BYTES = 1.9e9        # rows of a travelling side stay below 2 GB (32-bit buffer offsets)
 
 
@@ -341,8 +342,8 @@ def one_gpu_block_counts(nbr_users, nbr_items, dim):
     """-> (user blocks, item blocks) for DsgdKMF(rank=-1): item blocks small enough for the static resident-side epoch (the item
     rows of a block live in registers; fewer fit at larger k), user blocks small enough for a travelling side; the item block count
     is a multiple of the user block count."""
-    rows = max(1, int(ROWS_PER_BLOCK * 64 // max(int(dim), 64)))
     ub = max(1, int(-(-(int(nbr_users) * int(dim) * 8) // TRAVELLING_BYTES)))
+    rows = max(1, int((ROWS_PER_BLOCK_ALONE if ub == 1 and ROWS_PER_BLOCK == 42000 else ROWS_PER_BLOCK) * 64 // max(int(dim), 64)))
     nb = max(1, -(-int(nbr_items) // rows))
     return ub, -(-nb // ub) * ub
 

@@ -16,7 +16,7 @@
   * cfg 5 WHOLE (10 M x 1 M, 1 B ratings, k=64) on one GPU: properties -- device-built schedule and its level
     count, finite and strictly decreasing online RMSE, host and device builders agree on a 100 M-rating prefix; and the same
     billion ratings on the ONE-GPU block order (3 user x 24 item blocks, all 72 on the static resident-side epoch);
-  * cfg 3 whole on the ONE-GPU block order (5 item blocks, each in its minimum-level order): one epoch, bit for bit against the
+  * cfg 3 whole on the ONE-GPU block order (4 item blocks, each in its minimum-level order): one epoch, bit for bit against the
     oracle on the order the trainer reports."""
 import ctypes as C
 import time
@@ -117,22 +117,22 @@ def _sampled_residuals(Y, X, off, col, rows, c_pos, lam):
 
 def test_cfg3_whole_block_order_bitexact_vs_oracle(cfg3_data):
     """cfg 3 whole on the ONE-GPU block order (sharding.kmf_train_block_order: 200 K items do not fit the static resident-side epoch
-    at once, five item blocks do; every block in its own minimum-level order): one epoch, bit for bit against the oracle's
+    at once, four item blocks do; every block in its own minimum-level order): one epoch, bit for bit against the oracle's
     sequential loop (kmf_train.pyx:243-270) ON THE ORDER THE TRAINER REPORTS."""
     from mfrec_amd import sharding
     from oracle import oracle as O
     nu, ni, nnz, idx, r = cfg3_data
     k = 64
-    assert sharding.one_gpu_block_counts(nu, ni, k) == (1, 5)
+    assert sharding.one_gpu_block_counts(nu, ni, k) == (1, 4)
     u0, v0 = synth.init_normal(k, ni, 7), synth.init_normal(k, nu, 8)
     u, v, ib, ub = u0.copy(), v0.copy(), np.zeros(ni), np.zeros(nu)
     perm = sharding.kmf_train_block_order(0, 1, k, HP[0], HP[1], HP[2], HP[3], u, v, idx, r, ib, ub)
     assert perm.shape[0] == nnz and int(perm.sum()) == nnz * (nnz - 1) // 2
     pidx, pr = np.ascontiguousarray(idx[perm]), np.ascontiguousarray(r[perm])
     # the order groups the ratings by item block: block ids never decrease along it
-    bounds = sharding.item_blocks(idx, ni, 5)
+    bounds = sharding.item_blocks(idx, ni, 4)
     jb = np.searchsorted(bounds, pidx[:, 1], side="right") - 1
-    assert jb[0] == 0 and jb[-1] == 4 and np.all(np.diff(jb) >= 0)
+    assert jb[0] == 0 and jb[-1] == 3 and np.all(np.diff(jb) >= 0)
     ib2, ub2 = np.zeros(ni), np.zeros(nu)
     O.train_linear_kernel(1, k, 0.1, HP[0], 0, 0, HP[1], HP[2], HP[3], 0.0, u0, v0, pidx, pr, ib2, ub2)
     assert np.array_equal(u, u0) and np.array_equal(v, v0)          # u0 / v0 now hold the oracle's result

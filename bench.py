@@ -390,19 +390,51 @@ def also_funk(idx, r, nu, ni, k, order, epochs_per_feature=2):
         kname = p.kernel_name(3)
     n = len(hist)
     rate = nnz * n / (tm.ms * 1e-3)
-    xcd = kname.startswith("k2_xcd_pass")
-    launches = 1 if xcd else info["funk_launches_per_epoch"]
+    # k2_res / k2_res_box / k2_xcd_pass: ONE persistent launch per (feature, epoch) pass (the mailbox fill / seed and the
+    # squared-error reduction beside it are inside the timed region and count against it); k2_level: one launch per level
+    persistent = kname.startswith("k2_xcd_pass") or kname.startswith("k2_res")
+    launches = 1 if persistent else info["funk_launches_per_epoch"]
     ms_pass = tm.ms / n
+    how = ("one persistent launch per pass, lane = item, V[f,user] travels through per-rating mailboxes" if kname.startswith("k2_res_box")
+           else "one persistent launch per pass, lane = item, V[f,user] travels inside 16-byte granules" if kname.startswith("k2_res")
+           else "one persistent single-XCD launch per pass" if kname.startswith("k2_xcd_pass") else "one launch per dependency level")
     # algorithmic bytes: 24 B per scalar update (16-B record + 8-B cache word)
+    roof = {"bound": "hbm", "achieved": rate * 24 / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": rate * 24 / HBM_PEAK, "bytes_per_scalar_update": 24, "kernel": kname,
+            "avg_launch_us": ms_pass * 1e3 / max(launches, 1), "launches_per_pass": launches, "traffic": None}
+    if persistent:
+        # the pass is a chain of `levels` dependent hand-offs inside one launch: what one hop of the chain costs
+        roof["us_per_chain_level"] = ms_pass * 1e3 / max(info["n_levels"], 1)
+    else:
+        roof["us_per_level"] = ms_pass * 1e3 / max(info["n_levels"], 1)
+    tr = k2_traffic(kname) if order == "shuffled" and (nu, ni, nnz, k) == CFG2 else None
+    if tr:
+        roof["traffic"] = tr["bytes_per_pass"]
+        roof["traffic_unit"] = "HBM-side bytes per launch = per pass (PMC, %s): %.1f B read + %.1f B written per scalar update" % (
+            tr["source"], tr["read_bytes_per_update"], tr["write_bytes_per_update"])
     return {"value": rate, "unit": "scalar-updates/s", "row_equivalents_per_s": rate / k,
             "feature_epochs": n, "ms_per_pass": ms_pass, "levels": info["n_levels"],
             "launches_per_pass": launches, "rmse_online_last": float(hist[-1]),
             "workload": "cfg2 shape, %s order, k=%d features x %d epochs each + cache-commit passes "
-                        "(estimator_loop_without_bias), exact level schedule" % (order, k, epochs_per_feature),
-            "roofline": {"bound": "hbm", "achieved": rate * 24 / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": rate * 24 / HBM_PEAK, "bytes_per_scalar_update": 24, "kernel": kname,
-                         "avg_launch_us": ms_pass * 1e3 / max(launches, 1),
-                         "us_per_level": ms_pass * 1e3 / max(info["n_levels"], 1), "traffic": None}}
+                        "(estimator_loop_without_bias), exact (bit-identical to the sequential loop); %s" % (order, k, epochs_per_feature, how),
+            "roofline": roof}
+
+
+def k2_traffic(kname):
+    """HBM-side bytes per pass of the Funk kernel from the committed rocprofv3 PMC summary (profiles/rNN_k2_traffic.json: FETCH_SIZE
+    / WRITE_SIZE in separate passes, tools/prof_k2.sh); only when it was taken on the kernel that ran here."""
+    try:
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_k2_traffic.json")))
+        if not cands:
+            return None
+        tj = json.load(open(cands[-1]))
+        if tj.get("kernel") != kname:
+            return None
+        tj["source"] = os.path.basename(cands[-1])
+        return tj
+    except Exception:
+        return None
 
 
 def also_funk_ml10m(with_cpu):
@@ -572,6 +604,58 @@ def fail_line(rank, world, what, err):
     sys.stderr.flush()
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` started WITHOUT a launcher (no WORLD_SIZE in the environment): this process becomes the launcher.
+    It has not touched the GPU, loaded libmfx or imported the shim; it starts N fresh child processes of this same script with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would set them (one rank per GPU, device = LOCAL_RANK),
+    lets rank 0 print the one JSON line on the inherited stdout (the other ranks' stdout goes to stderr), and returns the worst
+    child exit code.  No exec.  A rank that dies takes the job with it: the survivors get a grace period (their own watchdogs
+    print where they were), then they are ended by pid."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env0 = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                TORCHELASTIC_RUN_ID="selflaunch%d" % os.getpid(), TORCHELASTIC_RESTART_COUNT="0")
+    kids = []
+    for rk in range(n):
+        env = dict(env0, RANK=str(rk), LOCAL_RANK=str(rk))
+        kids.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                     stdout=None if rk == 0 else sys.stderr))
+    grace = float(os.environ.get("MFX_BENCH_LAUNCH_GRACE", "60"))
+    failed_at = None
+    while True:
+        codes = [p.poll() for p in kids]
+        if all(c is not None for c in codes):
+            break
+        if failed_at is None and any(c not in (None, 0) for c in codes):
+            failed_at = time.time()
+            sys.stderr.write("[bench launcher] rank(s) %s ended with an error; the others get %.0f s\n"
+                             % ([i for i, c in enumerate(codes) if c not in (None, 0)], grace))
+            sys.stderr.flush()
+        if failed_at is not None and time.time() - failed_at > grace:
+            for p in kids:
+                if p.poll() is None:
+                    p.terminate()
+            t_end = time.time() + 10.0
+            while time.time() < t_end and any(p.poll() is None for p in kids):
+                time.sleep(0.1)
+            for p in kids:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.05)
+    codes = [p.wait() for p in kids]
+    worst = 0
+    for c in codes:
+        if c != 0:
+            worst = c if c > 0 else 128 - c          # a signal's negative code -> the shell's 128 + n
+            break
+    if worst:
+        sys.stderr.write("[bench launcher] child exit codes: %r\n" % (codes,))
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -605,12 +689,15 @@ def main():
         a.users = a.users or CFG2[0]; a.items = a.items or CFG2[1]
         return cpu_replica_main(a)
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process is only the launcher (nothing above has touched the GPU or loaded
+        # the library) -- N fresh child ranks, rank 0's JSON line relayed, worst child exit code returned
+        return self_launch(a.gpus)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus %d needs torchrun (one process per GPU)" % a.gpus)
         a.gpus = world
     if world > 1:
         os.environ.setdefault("NCCL_DEBUG", "WARN")
@@ -1084,4 +1171,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

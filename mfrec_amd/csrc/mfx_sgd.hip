@@ -400,16 +400,17 @@ K1Params k1_params(mfx_sgd_plan *p, double lr, double Ku, double Ki, double Kb, 
 // one resident-side epoch + its squared-error reduction (mfx_sgd_res.hip)
 int enqueue_res_epoch(mfx_sgd_plan *p, int mode, const K1Params &P)
 {
-    int rc = res_enqueue_epoch(p->res, mode, (double *)P.U, (double *)P.V, P.ib, P.ub, P.lr, P.Ku, P.Ki, P.Kb);
+    int rc = res_enqueue_epoch(p->res, mode, (double *)P.U, (double *)P.V, P.ib, P.ub, P.lr, P.Ku, P.Ki, P.Kb, p->dot != 0);
     if (rc) return rc;
     return enqueue_reduce(p, res_se_slots(p->res), res_se_partials(p->res));
 }
 
-// the resident-side epoch serves the plain linear / logistic run: f64 rows, ordered dot, both sides trained
+// the resident-side epoch serves the plain linear / logistic run: f64 rows, both sides trained; the ordered dot, or -- round 4 --
+// the butterfly-dot tolerance mode (every binding but the burst variant)
+bool res_on(const mfx_sgd_plan *p) { return p->res && p->res_state == 1 && !p->f32 && (!p->dot || res_dot_ok(p->res)); }
 bool res_applies(const mfx_sgd_plan *p, int mode, const K1Params &P)
 {
-    return p->res && p->res_state == 1 && (mode == K1_LINEAR || mode == K1_LOGISTIC) && !p->f32 && !p->dot &&
-           P.upd_u && P.upd_i;
+    return res_on(p) && (mode == K1_LINEAR || mode == K1_LOGISTIC) && P.upd_u && P.upd_i;
 }
 
 template <typename Hook>
@@ -538,7 +539,7 @@ int sgd_res_check(mfx_sgd_plan *p)
 }
 int plan_epoch_kernel(const mfx_sgd_plan *p)
 {
-    return (p->res && p->res_state == 1 && !p->f32 && !p->dot) ? res_kind(p->res) + 1 : MFX_EPOCH_LEVELS;
+    return res_on(p) ? res_kind(p->res) + 1 : MFX_EPOCH_LEVELS;
 }
 int sgd_fetch_se(mfx_sgd_plan *p, int64_t n, double *se_out) { return fetch_rmse(p, n, nullptr, se_out); }
 double *plan_U(mfx_sgd_plan *p) { return p->d_U_nk; }
@@ -854,7 +855,7 @@ int mfx_sgd_plan_info(const mfx_sgd_plan *p, int64_t info[8])
 int mfx_sgd_plan_res_info(const mfx_sgd_plan *p, int64_t info[4])
 {
     if (!p || !info) return MFX_E_ARG;
-    const bool on = p->res && p->res_state == 1 && !p->f32 && !p->dot;     // (narrow storage / butterfly dot: level kernels)
+    const bool on = res_on(p);                                             // (narrow storage: level kernels)
     info[0] = on ? res_kind(p->res) + 1 : MFX_EPOCH_LEVELS;          // (kind 1 = ticket, 2 = static)
     info[1] = p->res ? res_kind(p->res) + 1 : MFX_EPOCH_LEVELS;      // prepared (switched off by a failed registration?)
     info[2] = p->res ? (int64_t)res_dev_bytes(p->res) : 0;
@@ -876,7 +877,7 @@ int mfx_sgd_plan_kernel_name(const mfx_sgd_plan *p, int mode, char *buf, int buf
         else snprintf(buf, (size_t)buflen, "k2_level<%d threads>%s", kK2Block, p->k2x_state == 0 ? " (undecided: no Funk run yet)" : "");
         return MFX_OK;
     }
-    if (mode < 2 && p->res && p->res_state == 1 && !p->f32 && !p->dot) return res_describe(p->res, mode, buf, buflen);
+    if (mode < 2 && res_on(p)) return res_describe(p->res, mode, buf, buflen, p->dot != 0);
     static const char *const mode_name[] = {"linear", "logistic", "learned"};
     snprintf(buf, (size_t)buflen, "k1_level<%s,%s%s>", k1_select<false>(p->k, mode, p->batch, p->f32, p->dot).tag,
              mode_name[mode], p->f32 == 1 ? ",f32" : "");

@@ -81,6 +81,36 @@ __device__ __forceinline__ ResRec ldrec(const ResRec *p)
     return *p;
 #endif
 }
+// every outstanding vector-memory operation of the wave has returned -- as a REAL s_waitcnt instruction (vmcnt 0, the other counters
+// untouched), which the compiler's wait-count pass sees and accounts for; an `asm volatile` wait is opaque to it.  Placed in uniform
+// control flow behind a block of exec-masked loads: without it the compiler only waits INSIDE the masked blocks that use a loaded
+// register, must assume the load still pending where such a block was skipped, and protects the register's next write with a
+// vmcnt(0) of its own -- which in a step of k1_res sat right behind the FIRST row store and made every step wait for that store's
+// acknowledge before the other stores were even issued (a fourth memory round trip per step; round 4, from the ISA).
+__device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+// Diagnostic builds only (MFX_EXTRA_FLAGS=-DMFX_RES_STAMPS -> libmfx_diag.so, tools/res_stamps.py): where a step of the resident-side
+// epoch spends its time.  Every 64th wave accumulates the shader-clock ticks between the phase boundaries of its steps.
+#ifdef MFX_RES_STAMPS
+__device__ unsigned long long g_res_stamps[64 * 16];
+#define RS_DECL unsigned long long rs_t = clock64(), rs_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long rs_steps = 0, rs_spins = 0, rs_moved = 0
+#define RS(i) do { const unsigned long long t_ = clock64(); rs_acc[i] += t_ - rs_t; rs_t = t_; } while (0)
+#define RS_STEP(n) do { ++rs_steps; rs_moved += (n); } while (0)
+#define RS_SPIN() do { ++rs_spins; } while (0)
+#define RS_PARAM , unsigned long long &rs_t, unsigned long long (&rs_acc)[10]
+#define RS_ARG , rs_t, rs_acc
+#define RS_FLUSH() do { if ((blockIdx.x & 63) == 0 && (blockIdx.x >> 6) < 64 && threadIdx.x == 0) {                  \
+        unsigned long long *o_ = g_res_stamps + (blockIdx.x >> 6) * 16;                                               \
+        for (int i_ = 0; i_ < 10; ++i_) o_[i_] = rs_acc[i_];                                                          \
+        o_[10] = rs_steps; o_[11] = rs_spins; o_[12] = rs_moved; } } while (0)
+#else
+#define RS_DECL
+#define RS(i)
+#define RS_STEP(n)
+#define RS_SPIN()
+#define RS_FLUSH()
+#define RS_PARAM
+#define RS_ARG
+#endif
 __device__ __forceinline__ unsigned ldc_u32(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __device__ __forceinline__ double shfl64(double x, int src)
@@ -91,12 +121,118 @@ __device__ __forceinline__ double shfl64(double x, int src)
     return __hiloint2double(hi, lo);
 }
 
+// Registration barrier of the static launches (k1_res STATIC, k2_res, k2_res_box): lane 0 of every wave calls this; NOTHING is
+// modified unless it returns 1 in EVERY wave of the grid.  One word: arrivals count up; a wave that has waited kSpinReg polls gives
+// up by raising kRegFail -- with a compare-and-swap that only succeeds on an INCOMPLETE count, so the flag and a complete count
+// exclude each other: either every wave sees the complete count (whenever it looks) and passes, or the flag goes up first and every
+// wave -- the pollers, and the late arrivals through the value their own increment returns -- leaves with 0.  (Round 3 raised the
+// flag with an atomicOr and let the wave go on when the count had just completed: pollers that then read count | flag left, and
+// the grid ran the epoch without them until its chain counters timed out.)
+// reg_extra > 0 (test hook): that many waves more are expected than the grid has -- the check must fail; < 0 (test hook): wave 0
+// takes the give-up path at the very moment it sees the count complete -- the check must still pass everywhere.
+__device__ __forceinline__ int register_wave(unsigned *ctl, int reg_extra)
+{
+    if (ldc_u32(ctl + kCtlStatus)) return 0;
+    const unsigned want = gridDim.x + (reg_extra > 0 ? (unsigned)reg_extra : 0u);
+    unsigned v = atomicAdd(ctl + kCtlReg, 1u) + 1u;
+    int spins = 0;
+    for (;;) {
+        if (v & kRegFail) return 0;
+        const bool late = reg_extra < 0 && blockIdx.x == 0 && v == want;
+        if (v == want && !late) return 1;
+        if (late || ++spins > kSpinReg) {
+            unsigned cur = late ? v : ldc_u32(ctl + kCtlReg);
+            for (;;) {
+                if (cur == want) return 1;
+                if (cur & kRegFail) return 0;
+                const unsigned old = atomicCAS(ctl + kCtlReg, cur, cur | kRegFail);
+                if (old == cur) { atomicOr(ctl + kCtlStatus, 1u); return 0; }
+                cur = old;
+            }
+        }
+        __builtin_amdgcn_s_sleep(8);
+        v = ldc_u32(ctl + kCtlReg);
+    }
+}
+
+// value of lane (base + j * SPW + g) for every lane of half-group g, j and base compile-time / uniform: v_readlane (scalar result,
+// no LDS traffic, no address register per set, reads a lane whatever EXEC says) + one select per extra slot of the set
+template <int SPW>
+__device__ __forceinline__ int set_bcast_i(int v, int first, int g)
+{
+    int out = __builtin_amdgcn_readlane(v, first);
+#pragma unroll
+    for (int x = 1; x < SPW; ++x) {
+        const int t = __builtin_amdgcn_readlane(v, first + x);
+        out = g == x ? t : out;
+    }
+    return out;
+}
+template <int SPW>
+__device__ __forceinline__ double set_bcast_d(double v, int first, int g)
+{
+    const int lo = set_bcast_i<SPW>(__double2loint(v), first, g), hi = set_bcast_i<SPW>(__double2hiint(v), first, g);
+    return __hiloint2double(hi, lo);
+}
+
+// kmf_train.pyx:92-95: the k products of one rating, added strictly left to right to `sum` by ONE lane, from its row of the LDS
+// product tile.  The chain of k dependent f64 adds is the longest serial piece of a step; the reads of the next eight products
+// are issued before the current eight are added, so the chain waits for the adder only (round 3's loop waited for LDS in every
+// iteration: ~17 clocks per add; tools/res_stamps.py).
+__device__ __forceinline__ double ordered_sum(double sum, const double *row, int k)
+{
+    int f = 0;
+    if (k >= 8) {
+        d2 a = *reinterpret_cast<const d2 *>(row), b = *reinterpret_cast<const d2 *>(row + 2);
+        d2 c = *reinterpret_cast<const d2 *>(row + 4), d = *reinterpret_cast<const d2 *>(row + 6);
+        for (; f + 16 <= k; f += 8) {
+            const d2 na = *reinterpret_cast<const d2 *>(row + f + 8), nb = *reinterpret_cast<const d2 *>(row + f + 10);
+            const d2 nc = *reinterpret_cast<const d2 *>(row + f + 12), nd = *reinterpret_cast<const d2 *>(row + f + 14);
+            sum += a.x; sum += a.y; sum += b.x; sum += b.y; sum += c.x; sum += c.y; sum += d.x; sum += d.y;
+            a = na; b = nb; c = nc; d = nd;
+        }
+        sum += a.x; sum += a.y; sum += b.x; sum += b.y; sum += c.x; sum += c.y; sum += d.x; sum += d.y;
+        f += 8;
+    }
+    for (; f < k; ++f) sum += row[f];
+    return sum;
+}
+
+__device__ __forceinline__ double readlane64(double x, int l)          // l wave-uniform
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), l), hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+    return __hiloint2double(hi, lo);
+}
+
+// ---- tolerance mode (DOT): the k-term dot as north_star words it -- per-lane partial products (FMA), then a wave butterfly over
+// the KP lanes of a slot (quad swaps, half-row and row mirrors on DPP, then the cross-row swaps) -- and FMA in the row updates.
+// The SAME association and the same operations as the level kernels' DOT mode (mfx_sgd_kernels.h group_sum / k1_body<DOT = 1>), so a
+// plan gives the same bits whichever kernel serves it; NOT the reference's left-to-right sum (kmf_train.pyx:75-97).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64r(double x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int KP>
+__device__ __forceinline__ double group_sum_r(double x, int lane)
+{
+    if constexpr (KP >= 2) x = x + dpp_f64r<0xB1>(x);     // quad_perm [1,0,3,2]
+    if constexpr (KP >= 4) x = x + dpp_f64r<0x4E>(x);     // quad_perm [2,3,0,1]
+    if constexpr (KP >= 8) x = x + dpp_f64r<0x141>(x);    // row_half_mirror
+    if constexpr (KP >= 16) x = x + dpp_f64r<0x140>(x);   // row_mirror
+    if constexpr (KP >= 32) x = x + shfl64(x, lane ^ 16);
+    if constexpr (KP >= 64) x = x + shfl64(x, lane ^ 32);
+    return x;
+}
+
 // One step of a wave: the slots in `mask` apply their head rating.  FULL: every slot (no branches around
 // memory operations: one basic block of loads, one of stores).  Lane s < B owns slot s's scalar state.
-template <int KP, int NR, int MODE, bool FULL>
+template <int KP, int NR, int MODE, bool FULL, bool DOT>
 __device__ __forceinline__ void res_step(const ResParams &P, unsigned long long mask, bool ready, const URec &rec, double tbv,
                                          double &rbv, double &se, d2 (&vv)[NR], double *prod, __amdgpu_buffer_rsrc_t rT,
-                                         int lane, int g, int q, double &tbn)
+                                         int lane, int g, int q, double &tbn RS_PARAM)
 {
     constexpr int SPW = 64 / KP, B = NR * SPW;
     constexpr int stride = 2 * KP + 2;                       // rows 16-B aligned, stride / 2 odd (k1_stride at k = 2 KP)
@@ -105,33 +241,58 @@ __device__ __forceinline__ void res_step(const ResParams &P, unsigned long long 
     bool rdy[NR];
     d2 uu[NR];
     const unsigned qoff = (unsigned)q * 16u, rowb = (unsigned)(k * 8);
+    constexpr unsigned SETM = (1u << SPW) - 1u;
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
         const int src = j * SPW + g;
         rdy[j] = fl && (FULL || ((mask >> src) & 1ull));
         uu[j] = d2{0.0, 0.0};
-        // (the cross-lane read stays OUTSIDE the branch: ds_bpermute returns 0 for a source lane that is masked off)
-        const unsigned o = (unsigned)__shfl(rec.trav, src, 64) * rowb + qoff;
-        if (rdy[j]) uu[j] = __builtin_bit_cast(d2, ld16c(rT, o));
+        // a set none of whose slots moves is skipped as a whole -- a UNIFORM branch (the ballot is a scalar): no broadcast, no
+        // address, no memory instruction for it.  (The cross-lane reads are v_readlane: they do not depend on EXEC.)
+        if (FULL || ((unsigned)(mask >> (j * SPW)) & SETM)) {
+            const unsigned o = (unsigned)set_bcast_i<SPW>(rec.trav, j * SPW, g) * rowb + qoff;
+            if (rdy[j]) uu[j] = __builtin_bit_cast(d2, ld16c(rT, o));
+        }
     }
+    wait_vm0();
+    RS(2);
+    double dotv = 0.0;
+    if constexpr (DOT) {
+        // per-lane partials (features ascending, FMA) + butterfly over the slot's lanes; lane n (< B) owns slot n = j * SPW + g':
+        // its dot sits in every lane of half-group g' of register set j (lanes that hold no row to apply contribute 0).
+        // Set by set behind the uniform skips: a step moves ~4 of 18 slots.  (Measured against a stage-major form over ALL sets, whose
+        // independent adds cover each other's latency: 3.23 against 3.66 G/s on cfg 2 shuffled -- nine butterflies cost more issue
+        // slots than the three or four a step needs cost latency; profiles/r04_k1_res_stamps.txt.)
 #pragma unroll
-    for (int j = 0; j < NR; ++j)
-        if (rdy[j]) *reinterpret_cast<d2 *>(prod + (j * SPW + g) * stride + 2 * q) = d2{uu[j].x * vv[j].x, uu[j].y * vv[j].y};
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (int j = 0; j < NR; ++j) {
+            if (!(FULL || ((unsigned)(mask >> (j * SPW)) & SETM))) continue;                 // uniform
+            double a = __builtin_fma(uu[j].x, vv[j].x, 0.0);
+            a = __builtin_fma(uu[j].y, vv[j].y, a);
+            a = group_sum_r<KP>(rdy[j] ? a : 0.0, lane);
+            double t = readlane64(a, 0);
+#pragma unroll
+            for (int x = 1; x < SPW; ++x) {
+                const double tx = readlane64(a, x * KP);
+                t = (lane % SPW) == x ? tx : t;
+            }
+            if (lane / SPW == j) dotv = t;
+        }
+        RS(7);
+    } else {
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+            if (rdy[j]) *reinterpret_cast<d2 *>(prod + (j * SPW + g) * stride + 2 * q) = d2{uu[j].x * vv[j].x, uu[j].y * vv[j].y};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        RS(7);                                               // 7: products to the LDS tile
+    }
     double grad = 0.0;
     if (FULL ? (lane < B) : ready) {
         // kmf_train.pyx:92: 0 + item bias + user bias, then the products left to right
         double sum = P.res_item ? (0.0 + rbv + tbv) : (0.0 + tbv + rbv);
-        const double *row = prod + lane * stride;
-        int f = 0;
-        for (; f + 8 <= k; f += 8) {
-            const d2 a = *reinterpret_cast<const d2 *>(row + f), b = *reinterpret_cast<const d2 *>(row + f + 2);
-            const d2 c = *reinterpret_cast<const d2 *>(row + f + 4), d = *reinterpret_cast<const d2 *>(row + f + 6);
-            sum += a.x; sum += a.y; sum += b.x; sum += b.y; sum += c.x; sum += c.y; sum += d.x; sum += d.y;
-        }
-        for (; f < k; ++f) sum += row[f];
+        if constexpr (DOT) sum += dotv;
+        else sum = ordered_sum(sum, prod + lane * stride, k);
         double err;
         if constexpr (MODE == 0) {
             err = rec.r - sum;                               // kmf_train.pyx:251-256
@@ -146,29 +307,33 @@ __device__ __forceinline__ void res_step(const ResParams &P, unsigned long long 
         rbv = rbv + P.lr * (grad - P.Kb * rbv);              // :259-260 (both gates on in this path)
         tbn = tbv + P.lr * (grad - P.Kb * tbv);
     }
-    __builtin_amdgcn_wave_barrier();
+    if constexpr (!DOT) __builtin_amdgcn_wave_barrier();
+    RS(8);                                                   // 8: ordered sums, errors, bias updates
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
-        const double gr = shfl64(grad, j * SPW + g);
-        const unsigned o = (unsigned)__shfl(rec.trav, j * SPW + g, 64) * rowb + qoff;    // formed again rather than kept: a register per slot pair less
+        if (!(FULL || ((unsigned)(mask >> (j * SPW)) & SETM))) continue;                     // uniform
+        const double gr = set_bcast_d<SPW>(grad, j * SPW, g);
+        const unsigned o = (unsigned)set_bcast_i<SPW>(rec.trav, j * SPW, g) * rowb + qoff;   // formed again rather than kept: a register per slot pair less
         if (rdy[j]) {
             const d2 mf = uu[j], cf = vv[j];
             d2 un, vn;
-            un.x = mf.x + P.lr * (gr * cf.x - P.Ktrav * mf.x);   // :267-270, both rows from the OLD values
-            un.y = mf.y + P.lr * (gr * cf.y - P.Ktrav * mf.y);
-            vn.x = cf.x + P.lr * (gr * mf.x - P.Kres * cf.x);
-            vn.y = cf.y + P.lr * (gr * mf.y - P.Kres * cf.y);
+            if constexpr (DOT) {
+                un.x = __builtin_fma(P.lr, __builtin_fma(gr, cf.x, -(P.Ktrav * mf.x)), mf.x);
+                un.y = __builtin_fma(P.lr, __builtin_fma(gr, cf.y, -(P.Ktrav * mf.y)), mf.y);
+                vn.x = __builtin_fma(P.lr, __builtin_fma(gr, mf.x, -(P.Kres * cf.x)), cf.x);
+                vn.y = __builtin_fma(P.lr, __builtin_fma(gr, mf.y, -(P.Kres * cf.y)), cf.y);
+            } else {
+                un.x = mf.x + P.lr * (gr * cf.x - P.Ktrav * mf.x);   // :267-270, both rows from the OLD values
+                un.y = mf.y + P.lr * (gr * cf.y - P.Ktrav * mf.y);
+                vn.x = cf.x + P.lr * (gr * mf.x - P.Kres * cf.x);
+                vn.y = cf.y + P.lr * (gr * mf.y - P.Kres * cf.y);
+            }
             st16c(__builtin_bit_cast(v4u, un), rT, o);
             vv[j] = vn;
         }
     }
 }
 
-__device__ __forceinline__ double readlane64(double x, int l)          // l wave-uniform
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(x), l), hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
-    return __hiloint2double(hi, lo);
-}
 
 // BURST (static binding, skewed data): a resident entity with a long run ahead -- the hot item of a power-law catalogue:
 // its ratings come from different, mostly idle travelling entities -- walks up to eight of its ratings in ONE step.  The
@@ -307,9 +472,10 @@ __device__ __forceinline__ int res_burst(const ResParams &P, int s, int &pos, in
 }
 
 // KP lanes per row (16 bytes = one feature pair per lane: k <= 2 KP), NR register sets per lane, B = NR * 64/KP slots
-template <int KP, int NR, int MODE, bool STATIC, bool BURST = false>
+template <int KP, int NR, int MODE, bool STATIC, bool BURST = false, bool DOT = false>
 __global__ __launch_bounds__(64, STATIC ? ((NR <= 9 && !BURST) ? 3 : 2) : 4) void k1_res(ResParams P)
 {
+    static_assert(!(BURST && DOT), "the burst walk keeps the ordered sum");
     constexpr int SPW = 64 / KP, B = NR * SPW;
     extern __shared__ __attribute__((aligned(16))) double prod[];       // [B][stride]
     const int lane = threadIdx.x, g = lane / KP, q = lane % KP;
@@ -321,24 +487,7 @@ __global__ __launch_bounds__(64, STATIC ? ((NR <= 9 && !BURST) ? 3 : 2) : 4) voi
     if (STATIC) {
         // ---- registration: nothing is modified unless every wave of the grid is running ----------------
         int ok = 1;
-        if (lane == 0) {
-            if (ldc_u32(P.ctl + kCtlStatus)) ok = 0;
-            else {
-                const unsigned want = gridDim.x + (unsigned)P.reg_extra;
-                unsigned v = atomicAdd(P.ctl + kCtlReg, 1u) + 1u;
-                int spins = 0;
-                while (v != want) {
-                    if (v & kRegFail) { ok = 0; break; }
-                    if (++spins > kSpinReg) {
-                        const unsigned old = atomicOr(P.ctl + kCtlReg, kRegFail);
-                        if (old != want) { ok = 0; atomicOr(P.ctl + kCtlStatus, 1u); }   // (complete before the flag: go on)
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(8);
-                    v = ldc_u32(P.ctl + kCtlReg);
-                }
-            }
-        }
+        if (lane == 0) ok = register_wave(P.ctl, P.reg_extra);
         if (!__builtin_amdgcn_readfirstlane(ok)) return;
         if (blockIdx.x == 0 && lane == 0) atomicAdd(P.ctl + kCtlDone, 1u);       // this launch of the batch is being applied
     }
@@ -383,10 +532,12 @@ __global__ __launch_bounds__(64, STATIC ? ((NR <= 9 && !BURST) ? 3 : 2) : 4) voi
         bool bail = false;
         THdr h; h.bias = 0.0; h.cnt = -1; h.pad = 0;
         if (pos < end) h = __builtin_bit_cast(THdr, ld16c(rH, (unsigned)rec.trav * 16u));
+        RS_DECL;
         while (__any(pos < end)) {
             const bool act = pos < end;
             const bool ready = act && h.cnt == rec.seq;
             const unsigned long long mask = __ballot(ready);
+            RS(0);
             if (!mask) {
                 if (++spins > kSpinRun || ((spins & 1023) == 0 && ldc_u32(P.ctl + kCtlStatus))) {
                     if (lane == 0) atomicOr(P.ctl + kCtlStatus, 3u);
@@ -395,6 +546,8 @@ __global__ __launch_bounds__(64, STATIC ? ((NR <= 9 && !BURST) ? 3 : 2) : 4) voi
                 }
                 __builtin_amdgcn_s_sleep(1);
                 if (act) h = __builtin_bit_cast(THdr, ld16c(rH, (unsigned)rec.trav * 16u));
+                RS_SPIN();
+                RS(1);
                 continue;
             }
             if constexpr (BURST) {
@@ -411,10 +564,12 @@ __global__ __launch_bounds__(64, STATIC ? ((NR <= 9 && !BURST) ? 3 : 2) : 4) voi
                 }
             }
             double tbn = 0.0;
-            if (!STATIC && mask == ALL) res_step<KP, NR, MODE, true>(P, mask, ready, rec, h.bias, rbv, se, vv, prod, rT, lane, g, q, tbn);
-            else res_step<KP, NR, MODE, false>(P, mask, ready, rec, h.bias, rbv, se, vv, prod, rT, lane, g, q, tbn);
+            if (!STATIC && mask == ALL) res_step<KP, NR, MODE, true, DOT>(P, mask, ready, rec, h.bias, rbv, se, vv, prod, rT, lane, g, q, tbn RS_ARG);
+            else res_step<KP, NR, MODE, false, DOT>(P, mask, ready, rec, h.bias, rbv, se, vv, prod, rT, lane, g, q, tbn RS_ARG);
+            RS(3);                                                        // 2 + 3: loads, products, sums, updates, stores issued (res_step stamps 2)
             // publish: every row store of this wave has been acknowledged, then bias + chain counter in one granule
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            RS(5);
             const bool more = ready ? (pos + 1 < end) : act;
             const int ntrav = ready ? nxt.trav : rec.trav;
             if (ready) {
@@ -427,7 +582,10 @@ __global__ __launch_bounds__(64, STATIC ? ((NR <= 9 && !BURST) ? 3 : 2) : 4) voi
             h.cnt = -1;
             if (more) h = __builtin_bit_cast(THdr, ld16c(rH, (unsigned)ntrav * 16u));
             spins = 0;
+            RS_STEP(__popcll(mask));
+            RS(6);
         }
+        RS_FLUSH();
         if (bail) break;
         // the runs are over: resident rows and biases go back (nobody else touches them this epoch)
 #pragma unroll
@@ -465,28 +623,37 @@ int test_reg_extra()
     static int launches = 0;
     if (env_i("MFX_TESTING", 0) != 1) return 0;
     const int n = env_i("MFX_TEST_REG_FAIL", 0);
+    if (n == -1) return -1;                                  // the give-up path fires on a COMPLETE count: every launch must still pass
     if (n <= 0) { launches = 0; return 0; }
     return ++launches >= n ? 1 : 0;
 }
 
-struct Sel { void *fn; int kp, nr; };
-// product tile [B][2 KP + 2]; the burst variant (nr = 13) parks eight travelling rows behind it
-size_t res_lds_bytes(int kp, int nr) { return ((size_t)nr * (64 / kp) * (2 * kp + 2) + (nr == 13 ? 8 * 2 * kp : 0)) * 8; }
+struct Sel { void *fn; int kp, nr, id; };       // nr: register sets per lane; id: what select() was asked for
+// product tile [B][2 KP + 2]; the burst variant (id 13) parks eight travelling rows behind it
+size_t res_lds_bytes(int kp, int id) { return ((size_t)id * (64 / kp) * (2 * kp + 2) + (id == 13 ? 8 * 2 * kp : 0)) * 8; }
 
 // ticket: 4 register sets (4 waves per SIMD); static: 9 sets at 3 waves per SIMD (18 slots x 3 072 waves at k = 64: measured 3 %
 // faster than 26 x 2 048 and 5 % faster than 32 x 2 048 on cfg 2) or 16 sets at 2 waves per SIMD (the largest side that fits)
-template <int MODE, int NR, bool STATIC, bool BURST = false>
+template <int MODE, int NR, bool STATIC, bool BURST = false, bool DOT = false>
 Sel pick(int k)
 {
-    if (k <= 32) return {(void *)k1_res<16, NR, MODE, STATIC, BURST>, 16, NR};
-    if (k <= 64) return {(void *)k1_res<32, NR, MODE, STATIC, BURST>, 32, NR};
-    return {(void *)k1_res<64, NR, MODE, STATIC, BURST>, 64, NR};
+    const int id = NR;
+    if (k <= 32) return {(void *)k1_res<16, NR, MODE, STATIC, BURST, DOT>, 16, NR, id};
+    if (k <= 64) return {(void *)k1_res<32, NR, MODE, STATIC, BURST, DOT>, 32, NR, id};
+    return {(void *)k1_res<64, NR, MODE, STATIC, BURST, DOT>, 64, NR, id};
 }
-// nr: 4 = ticket; 9 / 16 = static; 13 = static with bursts (skewed data: 2 waves per SIMD, 26 slots x 2 048 waves at k = 64)
-Sel select(int k, int mode, int nr)
+// id: 4 = ticket; 9 / 16 = static; 13 = static with bursts (skewed data: 2 waves per SIMD, 26 slots x 2 048 waves at k = 64).
+// dot: the butterfly-dot / FMA tolerance mode (mfx_sgd_plan_set_dot) -- every binding but the burst variant, whose walk keeps the
+// ordered sum (res_dot_ok: such a plan runs its tolerance mode on the level kernels)
+template <int MODE, bool DOT>
+Sel select_m(int k, int id)
 {
-    if (mode == 0) return nr == 4 ? pick<0, 4, false>(k) : (nr == 9 ? pick<0, 9, true>(k) : (nr == 13 ? pick<0, 13, true, true>(k) : pick<0, 16, true>(k)));
-    return nr == 4 ? pick<1, 4, false>(k) : (nr == 9 ? pick<1, 9, true>(k) : (nr == 13 ? pick<1, 13, true, true>(k) : pick<1, 16, true>(k)));
+    return id == 4 ? pick<MODE, 4, false, false, DOT>(k) : (id == 9 ? pick<MODE, 9, true, false, DOT>(k) : (id == 13 ? pick<MODE, 13, true, true>(k) : pick<MODE, 16, true, false, DOT>(k)));
+}
+Sel select(int k, int mode, int id, bool dot = false)
+{
+    if (dot && id != 13) return mode == 0 ? select_m<0, true>(k, id) : select_m<1, true>(k, id);
+    return mode == 0 ? select_m<0, false>(k, id) : select_m<1, false>(k, id);
 }
 
 }  // namespace
@@ -601,7 +768,7 @@ int res_prepare(ResPlan **out, const int32_t *idx, const Rec *d_recs, int64_t nn
         ss = select(k, 0, nr);
         Bs = ss.nr * (64 / ss.kp);
         int occ = 0;
-        MFX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ss.fn, 64, res_lds_bytes(ss.kp, ss.nr)));
+        MFX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ss.fn, 64, res_lds_bytes(ss.kp, ss.id)));
         waves_s = occ * cus;
         if (headroom) {                                      // leave an eighth of the slots to whatever runs beside the launch
             const int64_t need = ceil_div((int64_t)n_res, (int64_t)Bs), spare = (int64_t)waves_s * 7 / 8;
@@ -624,7 +791,7 @@ int res_prepare(ResPlan **out, const int32_t *idx, const Rec *d_recs, int64_t nn
             const Sel sb = select(k, 0, 13);
             const int Bb = sb.nr * (64 / sb.kp);
             int occ = 0;
-            MFX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sb.fn, 64, res_lds_bytes(sb.kp, sb.nr)));
+            MFX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sb.fn, 64, res_lds_bytes(sb.kp, sb.id)));
             int wb = occ * cus;
             if (headroom && ceil_div((int64_t)n_res, (int64_t)Bb) <= (int64_t)wb * 7 / 8) wb = wb * 7 / 8;
             if (wb > 0 && (int64_t)wb * Bb >= n_res && (int64_t)n_trav * k * 8 < ((int64_t)1 << 31)) {
@@ -666,7 +833,7 @@ int res_prepare(ResPlan **out, const int32_t *idx, const Rec *d_recs, int64_t nn
     auto bail = [&](int rc) { res_destroy(rp); return rc; };
     {
         const Sel sel = kind == 1 ? st : ss;
-        rp->kp = sel.kp; rp->nr = sel.nr;
+        rp->kp = sel.kp; rp->nr = sel.id;
         if (kind == 1) {
             rp->res_item = false; rp->n_res = nu; rp->n_trav = ni; rp->B = Bt;
             rp->n_runs = (int)run_ent.size();
@@ -703,11 +870,12 @@ int res_kind(const ResPlan *rp) { return rp ? rp->kind : 0; }
 size_t res_dev_bytes(const ResPlan *rp) { return rp ? rp->dev_bytes : 0; }
 int64_t res_se_slots(const ResPlan *rp) { return rp->se_slots; }
 const double *res_se_partials(const ResPlan *rp) { return rp->d_se_run; }
-int res_describe(const ResPlan *rp, int mode, char *buf, int buflen)
+bool res_dot_ok(const ResPlan *rp) { return rp && rp->nr != 13; }
+int res_describe(const ResPlan *rp, int mode, char *buf, int buflen, bool dot)
 {
     static const char *const mode_name[] = {"linear", "logistic"};
-    snprintf(buf, (size_t)buflen, "k1_res<%d lanes/row,%d slots,%s,%s: %s rows resident,%d waves>", rp->kp, rp->B,
-             mode_name[mode & 1], rp->kind == 1 ? "ticket" : (rp->nr == 13 ? "static+bursts" : "static"), rp->res_item ? "item" : "user", rp->waves);
+    snprintf(buf, (size_t)buflen, "k1_res<%d lanes/row,%d slots,%s%s,%s: %s rows resident,%d waves>", rp->kp, rp->B,
+             mode_name[mode & 1], dot ? ",butterfly-dot+fma" : "", rp->kind == 1 ? "ticket" : (rp->nr == 13 ? "static+bursts" : "static"), rp->res_item ? "item" : "user", rp->waves);
     return MFX_OK;
 }
 
@@ -720,7 +888,7 @@ int res_begin_batch(ResPlan *rp)
 
 // enqueue ONE epoch on the library stream (capturable): counters, granules, the persistent launch, biases back
 int res_enqueue_epoch(ResPlan *rp, int mode, double *U_nk, double *V_nk, double *ib, double *ub, double lr, double Ku,
-                      double Ki, double Kb)
+                      double Ki, double Kb, bool dot)
 {
     ResParams P;
     memset(&P, 0, sizeof(P));
@@ -733,12 +901,12 @@ int res_enqueue_epoch(ResPlan *rp, int mode, double *U_nk, double *V_nk, double 
     P.n_runs = rp->n_runs; P.k = rp->k; P.res_item = rp->res_item ? 1 : 0;
     P.lr = lr; P.Kres = rp->res_item ? Ki : Ku; P.Ktrav = rp->res_item ? Ku : Ki; P.Kb = Kb;
     P.reg_extra = test_reg_extra();
-    const Sel s = select(rp->k, mode, rp->nr);
+    const Sel s = select(rp->k, mode, rp->nr, dot);
     MFX_HIP(hipMemsetAsync(rp->d_ctl, 0, sizeof(unsigned), stream()));                          // ticket
     MFX_HIP(hipMemsetAsync(rp->d_ctl + kCtlReg, 0, sizeof(unsigned), stream()));                // registration
     hipLaunchKernelGGL(k_hdr_reset, dim3(ceil_div(rp->n_trav, 256)), dim3(256), 0, stream(), rp->d_hdr, (const double *)tb, rp->n_trav);
     void *args[] = {&P};
-    MFX_HIP(hipLaunchKernel(s.fn, dim3(rp->waves), dim3(64), args, res_lds_bytes(rp->kp, rp->nr), stream()));
+    MFX_HIP(hipLaunchKernel(s.fn, dim3(rp->waves), dim3(64), args, res_lds_bytes(rp->kp, rp->nr), stream()));   // (the dot mode leaves the tile unused)
     hipLaunchKernelGGL(k_hdr_finish, dim3(ceil_div(rp->n_trav, 256)), dim3(256), 0, stream(), (const THdr *)rp->d_hdr, tb, rp->n_trav);
     MFX_HIP(hipGetLastError());
     return MFX_OK;
@@ -822,24 +990,7 @@ __global__ __launch_bounds__(64) void k2_res(Res2Params P)
     const int lane = threadIdx.x;
     // ---- registration: nothing is modified unless every wave of the grid is running ----------------
     int ok = 1;
-    if (lane == 0) {
-        if (ldc_u32(P.ctl + kCtlStatus)) ok = 0;
-        else {
-            const unsigned want = gridDim.x + (unsigned)P.reg_extra;
-            unsigned v = atomicAdd(P.ctl + kCtlReg, 1u) + 1u;
-            int spins = 0;
-            while (v != want) {
-                if (v & kRegFail) { ok = 0; break; }
-                if (++spins > kSpinReg) {
-                    const unsigned old = atomicOr(P.ctl + kCtlReg, kRegFail);
-                    if (old != want) { ok = 0; atomicOr(P.ctl + kCtlStatus, 1u); }
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(8);
-                v = ldc_u32(P.ctl + kCtlReg);
-            }
-        }
-    }
+    if (lane == 0) ok = register_wave(P.ctl, P.reg_extra);
     if (!__builtin_amdgcn_readfirstlane(ok)) return;
     if (blockIdx.x == 0 && lane == 0) atomicAdd(P.ctl + kCtlDone, 1u);           // this pass of the batch is being applied
     const Dyn2 *dyn = reinterpret_cast<const Dyn2 *>(P.dyn);
@@ -1166,24 +1317,7 @@ __global__ __launch_bounds__(64) void k2_res_box(Res2Params P)
 {
     const int lane = threadIdx.x;
     int ok = 1;
-    if (lane == 0) {
-        if (ldc_u32(P.ctl + kCtlStatus)) ok = 0;
-        else {
-            const unsigned want = gridDim.x + (unsigned)P.reg_extra;
-            unsigned v = atomicAdd(P.ctl + kCtlReg, 1u) + 1u;
-            int spins = 0;
-            while (v != want) {
-                if (v & kRegFail) { ok = 0; break; }
-                if (++spins > kSpinReg) {
-                    const unsigned old = atomicOr(P.ctl + kCtlReg, kRegFail);
-                    if (old != want) { ok = 0; atomicOr(P.ctl + kCtlStatus, 1u); }
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(8);
-                v = ldc_u32(P.ctl + kCtlReg);
-            }
-        }
-    }
+    if (lane == 0) ok = register_wave(P.ctl, P.reg_extra);
     if (!__builtin_amdgcn_readfirstlane(ok)) return;
     if (blockIdx.x == 0 && lane == 0) atomicAdd(P.ctl + kCtlDone, 1u);
     const Dyn2 *dyn = reinterpret_cast<const Dyn2 *>(P.dyn);
@@ -1656,3 +1790,10 @@ int res2_cache_to_levels(Res2Plan *rp, double *d_cache_levels)
 }
 
 }  // namespace mfx
+
+#ifdef MFX_RES_STAMPS
+extern "C" int mfx_debug_res_stamps(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(mfx::g_res_stamps), sizeof(unsigned long long) * 64 * 16) == hipSuccess ? 0 : -4;
+}
+#endif

@@ -76,3 +76,33 @@ def test_rmse_trajectory_and_predict_kernel(data):
     ref = O.rmse(O.RMSE_KMF_LINEAR, u, v, idx, r, ib, ub)
     assert abs(out.value - ref) <= 1e-5 and abs(out.value - ref) <= 1e-10
     assert out.value < rm[-1]            # the post-epoch RMSE beats the last online RMSE
+
+
+def test_butterfly_dot_mode_keeps_the_rmse_budget_at_full_size(data):
+    """north_star's tolerance: "within 1e-5 RMSE after a fixed epoch count".  Ten epochs of cfg 2 at full size in the tolerance mode
+    (butterfly dot + FMA inside the resident-side epoch, SgdPlan(dot="butterfly")) against ten epochs of the exact mode -- which is
+    the sequential loop's bits (test above; ten oracle epochs at this size would take minutes, so the exact GPU path stands in for
+    it) -- final RMSE over all ratings from the predict kernel (itself within 1e-10 of the oracle's, test above)."""
+    from mfrec_amd import _shim as S
+    from mfrec_amd.plan import SgdPlan
+    idx, r, u0, v0 = data
+    res = {}
+    for dot in ("ordered", "butterfly"):
+        u, v, ib, ub = u0.copy(), v0.copy(), np.zeros(NI), np.zeros(NU)
+        with SgdPlan(idx, r, NU, NI, K, dot=dot) as p:
+            name = p.kernel_name(0)
+            p.set_factors(u, v, ib, ub)
+            rm = p.run_kmf(0, 10, *HP)
+            p.get_factors(u, v, ib, ub)
+        out = C.c_double(0.0)
+        S.check(S.lib().mfx_predict_rmse(1, K, S.f64(u, "u", 2), S.f64(v, "v", 2), S.i32(idx, "idx", 2),
+                                         S.f64(r, "r", 1), S.f64(ib, "ib", 1), S.f64(ub, "ub", 1), 0.0,
+                                         NNZ, NU, NI, None, C.byref(out)))
+        res[dot] = (out.value, rm, name, u)
+    assert res["ordered"][2].startswith("k1_res<") and "butterfly" not in res["ordered"][2]
+    assert res["butterfly"][2].startswith("k1_res<") and "butterfly-dot" in res["butterfly"][2]
+    delta = abs(res["butterfly"][0] - res["ordered"][0])
+    assert delta <= 1e-5                                              # north_star's budget
+    assert delta <= 1e-9                                              # what is measured (~1e-13)
+    assert np.max(np.abs(res["butterfly"][1] - res["ordered"][1])) <= 1e-9      # the online RMSE of every epoch
+    assert not np.array_equal(res["butterfly"][3], res["ordered"][3])           # (it is a different summation order)

@@ -74,7 +74,7 @@ def test_ticket_user_major_vs_oracle(k, mode):
 
 
 @pytest.mark.parametrize("shape", [(900, 250), (250, 900)])     # items resident / users resident
-@pytest.mark.parametrize("k", [20, 64, 128])
+@pytest.mark.parametrize("k", [20, 40, 64, 128])
 @pytest.mark.parametrize("mode", [LINEAR, LOGISTIC])
 def test_static_any_order_vs_oracle(shape, k, mode):
     nu, ni = shape
@@ -84,6 +84,33 @@ def test_static_any_order_vs_oracle(shape, k, mode):
     u, v, ib, ub, rm, info, _, name = _run_plan(idx, r, nu, ni, k, u0, v0, E, mode, "static")
     assert info["epoch_kernel"] == "static" and ("item rows" if ni <= nu else "user rows") in name
     _check((u, v, ib, ub), _oracle(idx, r, nu, ni, k, u0, v0, E, mode), mode)
+
+
+@pytest.mark.parametrize("mode", [LINEAR, LOGISTIC])
+def test_static_on_dense_chains_and_repeated_pairs(mode):
+    """Few users and few items: long chains on both sides; runs of the SAME (user, item) pair back to back (a rating that depends on its
+    predecessor through the resident row AND the travelling row); items with one or two ratings; more slots than entities."""
+    k, E = 64, 4
+    rs = np.random.RandomState(17)
+    nu, ni = 37, 23
+    users = rs.randint(0, nu, 9000).astype(np.int32)
+    items = rs.randint(0, ni - 3, 9000).astype(np.int32)
+    # back-to-back repeats of a pair, and a user walking one item several times in a row between other users' ratings
+    for at in range(100, 8900, 400):
+        users[at:at + 5] = users[at]
+        items[at:at + 5] = items[at]
+        users[at + 10:at + 16:2] = users[at + 10]
+        items[at + 10:at + 16] = items[at + 10]
+    items[-1], items[-2], items[-3] = ni - 1, ni - 2, ni - 2   # items with one / two ratings at the very end
+    idx = np.ascontiguousarray(np.stack([users, items], axis=1))
+    r = rs.randint(1, 6, users.size).astype(np.float64)
+    u0, v0 = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
+    ib0, ub0 = rs.normal(0, 0.05, ni), rs.normal(0, 0.05, nu)
+    got = _run_plan(idx, r, nu, ni, k, u0, v0, E, mode, "static", ib0, ub0)
+    _check(got[:4], _oracle(idx, r, nu, ni, k, u0, v0, E, mode, ib0, ub0), mode)
+    # the online RMSE is a fixed-association sum per slot: the same bits run to run, whatever the timing
+    again = _run_plan(idx, r, nu, ni, k, u0, v0, E, mode, "static", ib0, ub0)
+    assert np.array_equal(again[4], got[4])
 
 
 def test_static_on_user_major_and_repeated_calls():
@@ -147,8 +174,53 @@ def test_not_eligible_is_an_argument_error():
         assert p.info()["epoch_kernel"] == "levels"
 
 
+@pytest.mark.parametrize("epoch,order", [("static", "shuffled"), ("static", "user-major"), ("ticket", "user-major")])
+@pytest.mark.parametrize("k", [24, 64, 100, 128])
+@pytest.mark.parametrize("mode", [LINEAR, LOGISTIC])
+def test_butterfly_dot_on_the_resident_side_epoch(epoch, order, k, mode):
+    """The tolerance mode (SgdPlan(dot="butterfly"): per-lane FMA partials + a wave butterfly over the lanes of a slot, FMA in the row
+    updates -- north_star's wording of the kernel) inside k1_res: no LDS product tile, no chain of k dependent adds.  Deterministic;
+    within 1e-11 of the oracle after 3 epochs (the budget is 1e-5 RMSE: tests/test_gpu_parity.py, tests/test_gpu_fullsize.py); at
+    k = 64 / 128, where the level kernels use the same lanes-per-row layout, the SAME bits as their tolerance mode -- a plan that
+    falls back to the level schedule in the middle of a run keeps its trajectory."""
+    nu, ni, nnz, E = 700, 300, 30000, 3
+    idx, r = synth.make_ratings(nu, ni, nnz, seed=6)
+    if order == "user-major":
+        idx, r = synth.user_major(idx, r)
+    u0, v0 = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
+    rs = np.random.RandomState(3)
+    ib0, ub0 = rs.normal(0, 0.05, ni), rs.normal(0, 0.05, nu)
+
+    def run(e):
+        u, v, ib, ub = u0.copy(), v0.copy(), ib0.copy(), ub0.copy()
+        with SgdPlan(idx, r, nu, ni, k, dot="butterfly", epoch=e) as p:
+            name, kern = p.kernel_name(mode), p.info()["epoch_kernel"]
+            p.set_factors(u, v, ib, ub)
+            rm = p.run_kmf(mode, E, LR, KU, KI, KB)
+            p.get_factors(u, v, ib, ub)
+        return (u, v, ib, ub, rm), name, kern
+
+    got, name, kern = run(epoch)
+    assert kern == epoch and name.startswith("k1_res<") and "butterfly-dot" in name, name
+    again, _, _ = run(epoch)
+    for a, b in zip(got, again):
+        assert np.array_equal(a, b)                                  # deterministic, whatever the timing
+    want = _oracle(idx, r, nu, ni, k, u0, v0, E, mode, ib0, ub0)
+    for a, b in zip(got[:4], want):
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-11)
+    assert not np.array_equal(got[0], want[0])                       # it is NOT the exact mode
+    lev, lname, _ = run("levels")
+    assert lname.startswith("k1_level<") and "butterfly-dot" in lname
+    if k in (64, 128) and mode == LINEAR:
+        for a, b in zip(got[:4], lev[:4]):
+            assert np.array_equal(a, b)
+    else:
+        for a, b in zip(got[:4], lev[:4]):
+            np.testing.assert_allclose(a, b, rtol=0, atol=1e-11)
+
+
 def test_gated_and_narrow_runs_take_the_level_schedule():
-    """update_users/items gates, f32 storage and the butterfly dot are served by the level kernels of the same plan."""
+    """update_users/items gates and f32 storage are served by the level kernels of the same plan."""
     nu, ni, nnz, k = 300, 500, 20000, 64
     idx, r = synth.user_major(*synth.make_ratings(nu, ni, nnz, seed=8))
     u0, v0 = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
@@ -263,3 +335,28 @@ def test_full_k_fallback_in_the_middle_of_a_batch(monkeypatch):
         _check(got[:4], want[:4], LINEAR)
         np.testing.assert_allclose(got[4], want[4], rtol=1e-12)
         assert got[6]["epoch_kernel"] == "levels", n
+
+
+def test_give_up_on_a_complete_registration_count_is_success_everywhere(monkeypatch):
+    """The registration barrier's give-up path raises its flag with a compare-and-swap that only succeeds on an INCOMPLETE count.
+    Test hook MFX_TEST_REG_FAIL=-1: wave 0 takes the give-up path at the very moment it sees the count complete (what a time-out
+    that fires together with the last arrival looks like) -- every wave must still pass, the epoch runs on the static binding and
+    gives the oracle's bits; the same for both forms of the resident-side Funk pass."""
+    from mfrec_amd.lib import gd_estimator as G
+    monkeypatch.setenv("MFX_TESTING", "1")
+    monkeypatch.setenv("MFX_TEST_REG_FAIL", "-1")
+    nu, ni, nnz, k = 900, 400, 40000, 64
+    idx, r = synth.make_ratings(nu, ni, nnz, seed=21)
+    u0, v0 = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
+    got = _run_plan(idx, r, nu, ni, k, u0, v0, 3, LINEAR, "static")
+    assert got[6]["epoch_kernel"] == "static"                       # no fall-back happened
+    _check(got[:4], _oracle(idx, r, nu, ni, k, u0, v0, 3, LINEAR), LINEAR)
+    monkeypatch.setenv("MFX_K2_RES", "1")
+    kf = 3
+    fu2, fv2 = synth.init_const(kf, ni), synth.init_const(kf, nu)
+    O.estimator_loop_without_bias(2, 2, 1e9, kf, 0.1, 0.001, 0.05, fu2, fv2, idx, r, nu, ni)
+    for box in ("2", "0"):                                          # mailbox form (2 per poll) / granule form
+        monkeypatch.setenv("MFX_K2_BOX", box)
+        fu, fv = synth.init_const(kf, ni), synth.init_const(kf, nu)
+        G.estimator_loop_without_bias(2, 2, 1e9, kf, 0.1, 0.001, 0.05, fu, fv, idx, r, nu, ni)
+        assert np.array_equal(fu, fu2) and np.array_equal(fv, fv2), box

@@ -198,3 +198,24 @@ def test_label_based_ingest_follows_the_reference_container():
     assert R._get_new_item_id() == 4 and R.items_label[4] == "item4"
     R.set_dimensionality(7)
     assert R.dimensionality == 7
+
+
+def test_bench_self_launch_without_a_gpu_fails_loudly_and_returns_the_child_code():
+    """`python bench.py --gpus 2` started plainly (no launcher, no WORLD_SIZE): bench.py starts its own two ranks.  In this
+    container there is no HIP device: the ranks fail with libmfx's "no CPU fallback" error, the launcher ends the rank still
+    waiting for the RCCL id after the grace period and returns a non-zero code -- and no JSON line is printed."""
+    import os
+    import subprocess
+    import sys
+    from mfrec_amd import _shim as S
+    if S.device_count() > 0:
+        pytest.skip("a HIP device is present: the GPU suite runs the two-rank self-launch for real")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MFX_BENCH_LAUNCH_GRACE="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--users", "2000", "--items", "1000", "--nnz", "50000"], capture_output=True, text=True,
+                         timeout=300, cwd=root, env=env)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "no CPU fallback" in out.stderr and "[bench launcher] child exit codes" in out.stderr

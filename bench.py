@@ -831,8 +831,10 @@ def main():
             def kernel_name(self, mode):
                 i = self.sb.info()
                 if i["resident_blocks"] == i["item_blocks"]:
-                    return "k1_res (static), one persistent launch per item block; RCCL all-reduce of the block's item deltas behind it"
-                return "k1_level per item block (%d of %d blocks on the static epoch); RCCL all-reduce per block" % (i["resident_blocks"], i["item_blocks"])
+                    return "k1_res (static), one persistent launch per item block; RCCL all-reduce of the block's item deltas on the " \
+                           "transfer stream, under the next block's launch"
+                return "k1_level per item block (%d of %d blocks on the static epoch); RCCL all-reduce per block on the transfer " \
+                       "stream" % (i["resident_blocks"], i["item_blocks"])
 
             def close(self):
                 self.sb.close()
@@ -894,6 +896,10 @@ def main():
     # epochs / (K * launches per epoch).  The epoch graph holds nothing else but two tiny reduction
     # kernels (and, at N > 1, the delta / all-reduce / combine step), so this is an upper bound of the
     # kernel's own duration and agrees with rocprofv3's average (profiles/).
+    # the kernel that RAN: a static epoch that lost its co-residency check sends the plan -- all blocks of a block plan, on every
+    # rank -- to the level schedule for good (and the library repeats the call), so the labels are read after the timed region
+    info = plan.info()
+    kernel_name = plan.kernel_name(LINEAR)
     mark("per-launch event pairs (profile_kmf)")
     resident = use_blocks or ((not multi) and info.get("epoch_kernel", "levels") != "levels" and a.storage == "f64")
     launches = info["launches_per_epoch"] if use_blocks else (epoch_launches(info) if resident else info["launches_per_epoch"])

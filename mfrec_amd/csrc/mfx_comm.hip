@@ -155,14 +155,24 @@ int comm_allgather_f64(double *buf, size_t count)
 // cur <- start + scale * allreduce_sum(cur - start), start <- the same value (the next epoch's start): the combine step of the
 // averaging scheme (shard_hook above) for one array on the library stream.  No communicator: nothing happens (a single shard is the
 // sequential algorithm itself).
-int comm_average_f64(double *cur, double *start, size_t n, double scale)
+int comm_average_f64(double *cur, double *start, size_t n, double scale, hipStream_t st)
 {
     if (!g_comm || !n) return MFX_OK;
-    hipStream_t s = mfx::stream();
+    hipStream_t s = st ? st : mfx::stream();
     hipLaunchKernelGGL(k_sub, dim3(grid_for(n)), dim3(256), 0, s, cur, (const double *)start, n);
     MFX_NCCL(R.AllReduce(cur, cur, n, ncclFloat64, ncclSum, g_comm, s));
     hipLaunchKernelGGL(k_combine, dim3(grid_for(n)), dim3(256), 0, s, cur, start, scale, n);
     MFX_HIP(hipGetLastError());
+    return MFX_OK;
+}
+// every rank passes its own flag and gets the maximum over the ranks (a collective: every rank must call; library stream, synchronous)
+int comm_agree_max(int *flag)
+{
+    if (!g_comm) return MFX_OK;
+    double v = (double)*flag;
+    int rc = mfx_comm_allreduce_max(&v);
+    if (rc) return rc;
+    *flag = (int)v;
     return MFX_OK;
 }
 int comm_allreduce_sum_f64(double *buf, size_t count)

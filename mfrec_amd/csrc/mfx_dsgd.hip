@@ -66,7 +66,99 @@ struct mfx_dsgd {
     std::vector<double *> avg_startU, avg_startib;   // averaging mode on the block order: the epoch's start of every item block
     bool avg_fresh = false;                          // start buffers hold the current rows
     hipStream_t xfer = nullptr;             // transfer stream
+    // recovery of a run whose static block epochs lost their co-residency check (the launch modifies nothing then, but the OTHER blocks
+    // of the run went on): the factors as they stood when the run call began, on the device
+    std::vector<double *> snapV, snapub;                 // [rank of this process]
+    std::vector<std::vector<double *>> snapU, snapib;    // [rank of this process][item block]
+    int guard = -1;                         // -1: not decided; 1: some block of the JOB runs a resident-side epoch -> snapshot per run call
 };
+
+
+// ---- recovery: a static block epoch that finds its grid not co-resident modifies nothing and marks its plan (sticky: the plan's later
+// launches of the run do nothing either) -- but the other blocks of the run go on, so the run as a whole is void.  Every run call
+// therefore starts from a device snapshot of the factors (a few hundred MB of device copies against tens of milliseconds of epochs)
+// while any block of the JOB is on a resident-side epoch; when the ranks agree that one of them lost a check, every rank restores its
+// snapshot, puts ALL its blocks on the level schedule for good, and runs the call again.  Same process, fresh launches, no re-exec.
+static bool any_resident(const mfx_dsgd *d)
+{
+    for (const DsgdRank &R : d->ranks)
+        for (mfx_sgd_plan *p : R.plans)
+            if (plan_epoch_kernel(p) != MFX_EPOCH_LEVELS) return true;
+    return false;
+}
+// `collective`: the call is one that every rank of the communicator makes together -- the block rotation over real ranks, the averaging
+// mode inside a communicator -- so the ranks can (and must) agree; a one-process object decides for itself
+// decided once (among real ranks: every rank asks in its first run call), cleared for good by a recovery
+static int dsgd_guard(mfx_dsgd *d, bool collective)
+{
+    if (d->guard >= 0) return MFX_OK;
+    int g = any_resident(d) ? 1 : 0;
+    if (collective) {
+        int rc = comm_agree_max(&g);
+        if (rc) return rc;
+    }
+    d->guard = g;
+    return MFX_OK;
+}
+static int dsgd_copy_state(mfx_dsgd *d, bool save)
+{
+    hipStream_t s = stream();
+    if (save && d->snapV.empty()) {
+        d->snapV.assign(d->ranks.size(), nullptr);
+        d->snapub.assign(d->ranks.size(), nullptr);
+        d->snapU.assign(d->ranks.size(), std::vector<double *>((size_t)d->B, nullptr));
+        d->snapib.assign(d->ranks.size(), std::vector<double *>((size_t)d->B, nullptr));
+    }
+    if (!save && d->snapV.empty()) return fail(MFX_E_STATE, "mfx_dsgd: no snapshot to restore");
+    for (size_t gi = 0; gi < d->ranks.size(); ++gi) {
+        DsgdRank &R = d->ranks[gi];
+        mfx_sgd_plan *p0 = R.plans[0];
+        const size_t nV = (size_t)plan_nu(p0) * d->k, nb = (size_t)plan_nu(p0);
+        if (save && !d->snapV[gi]) {
+            MFX_HIP(hipMalloc((void **)&d->snapV[gi], nV * sizeof(double)));
+            MFX_HIP(hipMalloc((void **)&d->snapub[gi], nb * sizeof(double)));
+        }
+        MFX_HIP(hipMemcpyAsync(save ? d->snapV[gi] : plan_V(p0), save ? plan_V(p0) : d->snapV[gi], nV * sizeof(double), hipMemcpyDeviceToDevice, s));
+        MFX_HIP(hipMemcpyAsync(save ? d->snapub[gi] : plan_ub(p0), save ? plan_ub(p0) : d->snapub[gi], nb * sizeof(double), hipMemcpyDeviceToDevice, s));
+        for (int j = 0; j < d->B; ++j) {
+            mfx_sgd_plan *p = R.plans[j];
+            const size_t nU = (size_t)plan_ni(p) * d->k, ni = (size_t)plan_ni(p);
+            if (save && !d->snapU[gi][j]) {
+                MFX_HIP(hipMalloc((void **)&d->snapU[gi][j], nU * sizeof(double)));
+                MFX_HIP(hipMalloc((void **)&d->snapib[gi][j], ni * sizeof(double)));
+            }
+            MFX_HIP(hipMemcpyAsync(save ? d->snapU[gi][j] : plan_U(p), save ? plan_U(p) : d->snapU[gi][j], nU * sizeof(double), hipMemcpyDeviceToDevice, s));
+            MFX_HIP(hipMemcpyAsync(save ? d->snapib[gi][j] : plan_ib(p), save ? plan_ib(p) : d->snapib[gi][j], ni * sizeof(double), hipMemcpyDeviceToDevice, s));
+        }
+    }
+    return MFX_OK;
+}
+// after the run's stream syncs: *redo = 1 when some rank of the job lost a co-residency check (every rank then restores and goes to
+// the level schedule); a chain-counter time-out anywhere is an error on every rank
+static int dsgd_verdict(mfx_dsgd *d, bool collective, const char *what, int *redo)
+{
+    *redo = 0;
+    int worst = 0, rc;
+    for (DsgdRank &R : d->ranks)
+        for (mfx_sgd_plan *p : R.plans) {
+            unsigned st = 0;
+            if ((rc = sgd_res_poll(p, &st))) return rc;
+            const int v = st == 0 ? 0 : (st == 1 ? 1 : 2);
+            if (v > worst) worst = v;
+        }
+    if (collective && d->guard != 0 && (rc = comm_agree_max(&worst))) return rc;
+    if (worst >= 2) return fail(MFX_E_HIP, "%s: a resident-side block epoch timed out waiting for a chain counter (on this rank or another)", what);
+    if (worst == 1) {
+        if ((rc = dsgd_copy_state(d, false))) return rc;
+        for (DsgdRank &R : d->ranks)
+            for (mfx_sgd_plan *p : R.plans) plan_force_levels(p);
+        d->guard = 0;
+        d->avg_fresh = false;
+        MFX_HIP(hipStreamSynchronize(stream()));
+        *redo = 1;
+    }
+    return MFX_OK;
+}
 
 extern "C" {
 
@@ -85,6 +177,10 @@ void mfx_dsgd_destroy(mfx_dsgd *d)
             if (r.plans[j]) mfx_sgd_plan_destroy(r.plans[j]);
     }
     if (d->xfer) (void)hipStreamDestroy(d->xfer);
+    for (double *q : d->snapV) if (q) (void)hipFree(q);
+    for (double *q : d->snapub) if (q) (void)hipFree(q);
+    for (auto &v : d->snapU) for (double *q : v) if (q) (void)hipFree(q);
+    for (auto &v : d->snapib) for (double *q : v) if (q) (void)hipFree(q);
     for (double *q : d->avg_startU) if (q) (void)hipFree(q);
     for (double *q : d->avg_startib) if (q) (void)hipFree(q);
     delete d;
@@ -262,8 +358,11 @@ mfx_dsgd *mfx_dsgd_create(const int32_t *idx, const double *r, int64_t nnz, int 
                     }
                 }
                 // (headroom: an eighth of the wave slots stays free for the transfer kernels that run beside a block -- none with world = 1)
+                // (... and none for a one-rank object outside a communicator; inside one -- a rank of the averaging mode -- the
+                //  all-reduce of block j runs on the transfer stream beside block j + 1)
+                const bool beside = world > 1 || (comm_active() && comm_world() > 1);
                 R.plans[j] = plan_create_ex(bidx[b].data(), br[b].data(), cnt[b], nul, nil, dim, MFX_SCHED_AUTO,
-                                            MFX_EPOCH_AUTO | (world > 1 ? kEpochHeadroom : 0));
+                                            MFX_EPOCH_AUTO | (beside ? kEpochHeadroom : 0));
                 if (!R.plans[j] || (j > 0 && plan_alias_users(R.plans[j], R.plans[0])) ||
                     hipEventCreateWithFlags(&R.trained[j], hipEventDisableTiming) != hipSuccess ||
                     hipEventCreateWithFlags(&R.arrived[j], hipEventDisableTiming) != hipSuccess) {
@@ -366,17 +465,9 @@ int mfx_dsgd_set_factors(mfx_dsgd *d, const double *u, const double *v, const do
     return MFX_OK;
 }
 
-// se_out (nullable): f64[nbr_epochs], the squared-error sum of each epoch over ALL ratings of the job
-// (online, as the reference accumulates it, kmf_train.pyx:257); blocks are added in step order,
-// ranks in rank order.
-int mfx_dsgd_run_kmf(mfx_dsgd *d, int mode, int nbr_epochs, double lr, double Ku, double Ki, double Kb,
-                     double *se_out)
+// one run of the block rotation (mfx_dsgd_run_kmf below wraps it in the snapshot / verdict / recovery steps)
+static int dsgd_rotation_body(mfx_dsgd *d, int mode, int nbr_epochs, double lr, double Ku, double Ki, double Kb, double *se_out)
 {
-    TraceRange trace_("mfx:dsgd_run_kmf (block rotation)");
-    if (!d) return fail(MFX_E_ARG, "mfx_dsgd_run_kmf: NULL");
-    if (!d->have_factors) return fail(MFX_E_STATE, "mfx_dsgd_run_kmf: mfx_dsgd_set_factors has not been called");
-    if (mode != MFX_MODE_LINEAR && mode != MFX_MODE_LOGISTIC) return fail(MFX_E_ARG, "mfx_dsgd_run_kmf: mode %d", mode);
-    if (nbr_epochs <= 0) return MFX_OK;
     const int G = d->world, B = d->B, stride = d->stride;
     hipStream_t s = stream(), x = d->xfer;
     int rc;
@@ -431,9 +522,6 @@ int mfx_dsgd_run_kmf(mfx_dsgd *d, int mode, int nbr_epochs, double lr, double Ku
     MFX_HIP(hipStreamSynchronize(s));
     for (DsgdRank &R : d->ranks)
         for (int j = 0; j < B; ++j) R.in_flight[j] = 0;
-    for (DsgdRank &R : d->ranks)                                  // blocks on the resident-side epoch report through a status word
-        for (mfx_sgd_plan *p : R.plans)
-            if ((rc = sgd_res_check(p))) return rc;
     if (se_out) {
         std::vector<double> se((size_t)nbr_epochs, 0.0);
         // per epoch: blocks in step order, ranks in rank order (fake world: exactly the order of the
@@ -472,25 +560,35 @@ int mfx_dsgd_run_kmf(mfx_dsgd *d, int mode, int nbr_epochs, double lr, double Ku
     return MFX_OK;
 }
 
-// north_star's averaging scheme (user shards + an RCCL all-reduce of the item deltas per epoch, mfx_sgd_run_kmf_sharded) with the
-// shard's local epoch on the BLOCK ORDER: this object was created with world = 1 over ONE rank's ratings (local user ids) and any
-// number of item blocks, so that every block runs the static resident-side epoch instead of the level schedule (a shard holds ALL
-// items: 200 K at cfg 3).  Per epoch and item block j: train the block, then U_j <- U_start_j + scale * allreduce_sum(U_j -
-// U_start_j) (items_bias alike) -- element for element the arithmetic of the whole-array all-reduce; with no communicator (one
-// rank) nothing is combined and the epoch is the sequential loop on the block order.  se_out (nullable): this rank's squared-error
-// sums per epoch.
-int mfx_dsgd_run_kmf_averaged(mfx_dsgd *d, int mode, int nbr_epochs, double lr, double Ku, double Ki, double Kb, double scale,
-                              double *se_out)
+// se_out (nullable): f64[nbr_epochs], the squared-error sum of each epoch over ALL ratings of the job
+// (online, as the reference accumulates it, kmf_train.pyx:257); blocks are added in step order,
+// ranks in rank order.
+int mfx_dsgd_run_kmf(mfx_dsgd *d, int mode, int nbr_epochs, double lr, double Ku, double Ki, double Kb,
+                     double *se_out)
 {
-    TraceRange trace_("mfx:dsgd_run_kmf_averaged (block order + RCCL all-reduce per item block)");
-    if (!d) return fail(MFX_E_ARG, "mfx_dsgd_run_kmf_averaged: NULL");
-    if (d->world != 1) return fail(MFX_E_ARG, "mfx_dsgd_run_kmf_averaged: the object must hold ONE rank's ratings (created with world = 1)");
-    if (!d->have_factors) return fail(MFX_E_STATE, "mfx_dsgd_run_kmf_averaged: mfx_dsgd_set_factors has not been called");
-    if (mode != MFX_MODE_LINEAR && mode != MFX_MODE_LOGISTIC) return fail(MFX_E_ARG, "mfx_dsgd_run_kmf_averaged: mode %d", mode);
+    TraceRange trace_("mfx:dsgd_run_kmf (block rotation)");
+    if (!d) return fail(MFX_E_ARG, "mfx_dsgd_run_kmf: NULL");
+    if (!d->have_factors) return fail(MFX_E_STATE, "mfx_dsgd_run_kmf: mfx_dsgd_set_factors has not been called");
+    if (mode != MFX_MODE_LINEAR && mode != MFX_MODE_LOGISTIC) return fail(MFX_E_ARG, "mfx_dsgd_run_kmf: mode %d", mode);
     if (nbr_epochs <= 0) return MFX_OK;
+    int rc, redo = 0;
+    const bool collective = d->rank >= 0 && d->world > 1;            // real ranks: every rank is in this call
+    if ((rc = dsgd_guard(d, collective))) return rc;
+    if (d->guard && (rc = dsgd_copy_state(d, true))) return rc;
+    if ((rc = dsgd_rotation_body(d, mode, nbr_epochs, lr, Ku, Ki, Kb, se_out))) return rc;
+    if ((rc = dsgd_verdict(d, collective, "mfx_dsgd_run_kmf", &redo))) return rc;
+    if (redo) rc = dsgd_rotation_body(d, mode, nbr_epochs, lr, Ku, Ki, Kb, se_out);     // every block on the level schedule now
+    return rc;
+}
+
+// one run of the averaging mode on the block order.  Block j's all-reduce rides the TRANSFER stream behind trained[j] while block
+// j + 1 trains on the compute stream (round 3 enqueued both on one stream: no overlap); block j's next training -- the next epoch --
+// waits for arrived[j].  The start buffers and the combine kernels of block j touch block j's rows only.
+static int dsgd_averaged_body(mfx_dsgd *d, int mode, int nbr_epochs, double lr, double Ku, double Ki, double Kb, double scale, double *se_out)
+{
     const int B = d->B;
     DsgdRank &R = d->ranks[0];
-    hipStream_t s = stream();
+    hipStream_t s = stream(), x = d->xfer;
     int rc;
     const bool comm = comm_active() && comm_world() > 1;
     if (comm) {
@@ -512,16 +610,24 @@ int mfx_dsgd_run_kmf_averaged(mfx_dsgd *d, int mode, int nbr_epochs, double lr, 
         if ((rc = sgd_reset_se(p, nbr_epochs))) return rc;
     for (int ep = 0; ep < nbr_epochs; ++ep)
         for (int j = 0; j < B; ++j) {
+            if (R.in_flight[j]) {                                 // the block's all-reduce of the epoch before
+                MFX_HIP(hipStreamWaitEvent(s, R.arrived[j], 0));
+                R.in_flight[j] = 0;
+            }
             if ((rc = sgd_enqueue_k1(R.plans[j], mode, lr, Ku, Ki, Kb))) return rc;
             if (comm) {
                 const size_t nb = (size_t)plan_ni(R.plans[j]);
-                if ((rc = comm_average_f64(plan_U(R.plans[j]), d->avg_startU[j], nb * d->k, scale))) return rc;
-                if ((rc = comm_average_f64(plan_ib(R.plans[j]), d->avg_startib[j], nb, scale))) return rc;
+                MFX_HIP(hipEventRecord(R.trained[j], s));
+                MFX_HIP(hipStreamWaitEvent(x, R.trained[j], 0));
+                if ((rc = comm_average_f64(plan_U(R.plans[j]), d->avg_startU[j], nb * d->k, scale, x))) return rc;
+                if ((rc = comm_average_f64(plan_ib(R.plans[j]), d->avg_startib[j], nb, scale, x))) return rc;
+                MFX_HIP(hipEventRecord(R.arrived[j], x));
+                R.in_flight[j] = 1;
             }
         }
+    MFX_HIP(hipStreamSynchronize(x));
     MFX_HIP(hipStreamSynchronize(s));
-    for (mfx_sgd_plan *p : R.plans)
-        if ((rc = sgd_res_check(p))) return rc;
+    for (int j = 0; j < B; ++j) R.in_flight[j] = 0;
     if (se_out) {
         std::vector<double> per((size_t)nbr_epochs);
         for (int ep = 0; ep < nbr_epochs; ++ep) se_out[ep] = 0.0;
@@ -531,6 +637,32 @@ int mfx_dsgd_run_kmf_averaged(mfx_dsgd *d, int mode, int nbr_epochs, double lr, 
         }
     }
     return MFX_OK;
+}
+
+// north_star's averaging scheme (user shards + an RCCL all-reduce of the item deltas per epoch, mfx_sgd_run_kmf_sharded) with the
+// shard's local epoch on the BLOCK ORDER: this object was created with world = 1 over ONE rank's ratings (local user ids) and any
+// number of item blocks, so that every block runs the static resident-side epoch instead of the level schedule (a shard holds ALL
+// items: 200 K at cfg 3).  Per epoch and item block j: train the block, then U_j <- U_start_j + scale * allreduce_sum(U_j -
+// U_start_j) (items_bias alike) -- element for element the arithmetic of the whole-array all-reduce; with no communicator (one
+// rank) nothing is combined and the epoch is the sequential loop on the block order.  se_out (nullable): this rank's squared-error
+// sums per epoch.
+int mfx_dsgd_run_kmf_averaged(mfx_dsgd *d, int mode, int nbr_epochs, double lr, double Ku, double Ki, double Kb, double scale,
+                              double *se_out)
+{
+    TraceRange trace_("mfx:dsgd_run_kmf_averaged (block order + RCCL all-reduce per item block)");
+    if (!d) return fail(MFX_E_ARG, "mfx_dsgd_run_kmf_averaged: NULL");
+    if (d->world != 1) return fail(MFX_E_ARG, "mfx_dsgd_run_kmf_averaged: the object must hold ONE rank's ratings (created with world = 1)");
+    if (!d->have_factors) return fail(MFX_E_STATE, "mfx_dsgd_run_kmf_averaged: mfx_dsgd_set_factors has not been called");
+    if (mode != MFX_MODE_LINEAR && mode != MFX_MODE_LOGISTIC) return fail(MFX_E_ARG, "mfx_dsgd_run_kmf_averaged: mode %d", mode);
+    if (nbr_epochs <= 0) return MFX_OK;
+    int rc, redo = 0;
+    const bool collective = comm_active() && comm_world() > 1;       // the all-reduces make this call a collective one
+    if ((rc = dsgd_guard(d, collective))) return rc;
+    if (d->guard && (rc = dsgd_copy_state(d, true))) return rc;
+    if ((rc = dsgd_averaged_body(d, mode, nbr_epochs, lr, Ku, Ki, Kb, scale, se_out))) return rc;
+    if ((rc = dsgd_verdict(d, collective, "mfx_dsgd_run_kmf_averaged", &redo))) return rc;
+    if (redo) rc = dsgd_averaged_body(d, mode, nbr_epochs, lr, Ku, Ki, Kb, scale, se_out);
+    return rc;
 }
 
 // u [k, ni] / items_bias [ni] (nullable): the full item side, gathered from the ranks that hold the

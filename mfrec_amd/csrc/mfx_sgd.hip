@@ -537,6 +537,16 @@ int sgd_res_check(mfx_sgd_plan *p)
     if (status) return fail(MFX_E_HIP, "a resident-side block epoch timed out waiting for a chain counter");
     return MFX_OK;
 }
+int sgd_res_poll(mfx_sgd_plan *p, unsigned *status)
+{
+    *status = 0;
+    if (!p->res || p->res_state != 1) return MFX_OK;
+    return res_status(p->res, status);
+}
+void plan_force_levels(mfx_sgd_plan *p)
+{
+    if (p->res && p->res_state == 1) p->res_state = -1;
+}
 int plan_epoch_kernel(const mfx_sgd_plan *p)
 {
     return res_on(p) ? res_kind(p->res) + 1 : MFX_EPOCH_LEVELS;

@@ -88,6 +88,10 @@ constexpr int kEpochHeadroom = 0x100;
 // DSGD enqueues block epochs asynchronously (sgd_enqueue_k1): the resident-side launch's status word is cleared by
 // sgd_reset_se and read by sgd_res_check after the caller's own stream sync -- non-zero: MFX_E_HIP (no fallback mid-run).
 int sgd_res_check(mfx_sgd_plan *p);
+// the same word, raw: 0 fine, 1 = a static launch of the batch found its grid not co-resident (it and every later launch of the plan
+// did nothing), 3 = a spin timed out (state undefined).  plan_force_levels: the plan runs on the level schedule from now on.
+int sgd_res_poll(mfx_sgd_plan *p, unsigned *status);
+void plan_force_levels(mfx_sgd_plan *p);
 int plan_epoch_kernel(const mfx_sgd_plan *p);      // MFX_EPOCH_LEVELS / _TICKET / _STATIC in use
 mfx_sgd_plan *plan_create_ex(const int32_t *idx, const double *r, int64_t nnz, int nu, int ni, int dim, int sched, int epoch);
 
@@ -108,7 +112,9 @@ int comm_rank();
 int comm_world();
 int comm_allgather_f64(double *buf, size_t count);          // in place: rank g's part at buf + g*count
 int comm_allreduce_sum_f64(double *buf, size_t count);      // in place, library stream
-int comm_average_f64(double *cur, double *start, size_t n, double scale);   // cur <- start + scale * allreduce(cur - start); start <- cur
+// cur <- start + scale * allreduce(cur - start); start <- cur; on stream `st` (nullptr: the library stream)
+int comm_average_f64(double *cur, double *start, size_t n, double scale, hipStream_t st = nullptr);
+int comm_agree_max(int *flag);                              // collective: the maximum of every rank's flag (synchronous)
 int comm_broadcast_f64(double *buf, size_t count, int root);
 // one fused group on stream `st` (nullptr: the library stream): send every (ptr, count) of `out` to `to`,
 // receive every (ptr, count) of `in` from `from`

@@ -118,6 +118,43 @@ def test_dsgd_blocks_on_the_static_resident_epoch(world, balanced, monkeypatch):
     np.testing.assert_allclose(np.sqrt(se / nnz), rm, rtol=1e-12)
 
 
+@pytest.mark.parametrize("fail_at", [1, 4, 9])
+def test_dsgd_recovers_when_a_static_block_loses_its_co_residency_check(fail_at, monkeypatch):
+    """Two ranks in one process, four blocks, every block on the static resident-side epoch; the `fail_at`-th static launch of the
+    process (and every later one) finds its grid "not co-resident" (test hook: what a GPU shared with another process does).  That
+    launch modifies nothing and its plan skips the rest of the run while the other blocks train on -- the run as a whole is void:
+    the library restores the factors it saved when the call began, moves every block to the level schedule and repeats the call.
+    The result is the sequential loop's on the block order, bit for bit; the next call simply continues (on the level schedule)."""
+    from mfrec_amd.sharding import DsgdKMF
+    from oracle import dsgd_sim as DS
+    from mfrec_amd.plan import SgdPlan
+    monkeypatch.setenv("MFX_K1_RES", "static")
+    monkeypatch.setenv("MFX_TESTING", "1")
+    monkeypatch.setenv("MFX_GRAPH", "0")        # eager launches: the hook counts enqueued launches
+    nu, ni, nnz, E, k = 900, 400, 40000, 3, 32
+    idx, r = synth.make_ratings(nu, ni, nnz, seed=6)
+    u0, v0 = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
+    T = DsgdKMF(idx, r, nu, ni, k, -1, 2, balanced=True)
+    assert T.info()["resident_blocks"] == 4
+    T.set_factors(u0, v0, np.zeros(ni), np.zeros(nu))
+    monkeypatch.setenv("MFX_TEST_REG_FAIL", "0")
+    with SgdPlan(idx, r, nu, ni, 18, epoch="static") as p:                       # (a static launch with the hook off resets its counter)
+        p.set_factors(synth.init_normal(18, ni, 1), synth.init_normal(18, nu, 2), np.zeros(ni), np.zeros(nu))
+        p.run_kmf(0, 1, *HP)
+    monkeypatch.setenv("MFX_TEST_REG_FAIL", str(fail_at))
+    se = T.train(0, E, *HP)
+    assert T.info()["resident_blocks"] == 0                                     # every block went to the level schedule
+    monkeypatch.setenv("MFX_TEST_REG_FAIL", "0")
+    se2 = T.train(0, 1, *HP)                                                    # ... and stays there: the next call continues
+    u, v, ib, ub = np.zeros((k, ni)), np.zeros((k, nu)), np.zeros(ni), np.zeros(nu)
+    T.get_factors(u, v, ib, ub)
+    perm = T.order()
+    T.close()
+    su, sv, sib, sub, rm = DS.simulate(0, E + 1, k, *HP, u0, v0, np.zeros(ni), np.zeros(nu), idx, r, T.user_bounds, T.item_bounds, perm=perm)
+    assert np.array_equal(u, su) and np.array_equal(v, sv) and np.array_equal(ib, sib) and np.array_equal(ub, sub)
+    np.testing.assert_allclose(np.sqrt(np.concatenate([se, se2]) / nnz), rm, rtol=1e-12)
+
+
 def test_dsgd_empty_blocks_and_real_single_rank():
     """Hand-made bounds with an empty user block and an empty item block; and the non-fake path with
     world = 1 (rank 0): one block, no rotation -- the plain sequential order."""

@@ -51,6 +51,7 @@ from mfrec_amd import sharding as SH
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 mode, out = sys.argv[1], sys.argv[2]
 NU, NI, NNZ, K, E = %(dims)s
+K = int(os.environ.get("MFX_TEST_K", K))                      # (the static resident-side epoch needs k > 16)
 HP = %(hp)s
 uid = None
 if rank != 0:
@@ -75,7 +76,7 @@ if mode.startswith("dsgd"):
     se = d.train(0, E, *HP)
     u, v, ib, ub = np.zeros((K, NI)), np.zeros((K, hi - lo)), np.zeros(NI), np.zeros(hi - lo)
     d.get_factors(u, v, ib, ub)
-    res = dict(u=u, v=v, ib=ib, ub=ub, se=np.asarray(se), lo=lo, hi=hi, order=d.order())
+    res = dict(u=u, v=v, ib=ib, ub=ub, se=np.asarray(se), lo=lo, hi=hi, order=d.order(), resident_blocks_after=d.info()["resident_blocks"])
     d.close()
 elif mode == "avg":
     s = SH.ShardedKMF(idx, r, NU, NI, K, rank, world)
@@ -86,11 +87,12 @@ elif mode == "avg":
     s.close()
 elif mode == "avgblocks":
     s = SH.ShardedKMFBlocks(idx, r, NU, NI, K, rank, world, item_blocks=3)
+    resident_before = s.info()["resident_blocks"]
     s.set_factors(u0, v0, np.zeros(NI), np.zeros(NU))
     se = s.train(0, E, *HP)
     u, v, ib, ub = s.get_local()
     res = dict(u=u, v=v[:, :s.nu_local], ib=ib, ub=ub[:s.nu_local], se=np.asarray(se), lo=s.user_lo, hi=s.user_lo + s.nu_local,
-               order=s.order())
+               order=s.order(), resident_blocks_after=s.info()["resident_blocks"], resident_blocks_before=resident_before)
     s.close()
 elif mode == "funk":
     from mfrec_amd.plan import SgdPlan
@@ -123,7 +125,8 @@ rendezvous.cleanup(rank)
 """
 
 
-def _launch(mock_lib, tmp_path, world, mode, port):
+def _launch(mock_lib, tmp_path, world, mode, port, env_extra=None):
+    """env_extra: a dict for every rank, or a list of dicts (one per rank)."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT, "dims": repr((NU, NI, NNZ, K, E)), "hp": repr(HP)})
     out = str(tmp_path / ("res_" + mode.replace(",", "_")))
@@ -131,6 +134,7 @@ def _launch(mock_lib, tmp_path, world, mode, port):
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), MFX_RCCL_LIB=mock_lib, MFX_TESTING="1", MFX_K1_RES="levels")
+        env.update((env_extra[rank] if isinstance(env_extra, (list, tuple)) else env_extra) or {})
         procs.append(subprocess.Popen([sys.executable, str(script), mode, out], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     logs = []
@@ -177,6 +181,29 @@ def test_block_rotation_over_real_processes_equals_the_fake_world(mock_lib, tmp_
     assert sorted(np.concatenate([z["order"] for z in res]).tolist()) == sorted(order.tolist())
 
 
+def test_block_rotation_with_static_blocks_recovers_when_one_rank_loses_a_co_residency_check(mock_lib, tmp_path):
+    """Block rotation over two real ranks, every block on the static resident-side epoch (k = 32, forced) with the ring's send / recv
+    kernels beside it; rank 1's 4th static launch fails its registration (test hook).  The ranks agree after the run, BOTH restore
+    their snapshots, go to the level schedule and repeat the call: the fake world's bits (= the sequential loop's on the block order)."""
+    from mfrec_amd import sharding as SH
+    idx, r = synth.make_ratings(NU, NI, NNZ, seed=41)
+    u0, v0 = synth.init_normal(32, NI, 1), synth.init_normal(32, NU, 2)
+    base = {"MFX_K1_RES": "static", "MFX_TEST_K": "32", "MFX_GRAPH": "0"}
+    res = _launch(mock_lib, tmp_path, 2, "dsgd,balanced", 29715, [base, dict(base, MFX_TEST_REG_FAIL="4")])
+    d = SH.DsgdKMF(idx, r, NU, NI, 32, -1, 2, balanced=True)
+    d.set_factors(u0, v0, np.zeros(NI), np.zeros(NU))
+    se = d.train(0, E, *HP)
+    u, v, ib, ub = np.zeros((32, NI)), np.zeros((32, NU)), np.zeros(NI), np.zeros(NU)
+    d.get_factors(u, v, ib, ub)
+    d.close()
+    for z in res:
+        lo, hi = int(z["lo"]), int(z["hi"])
+        assert np.array_equal(z["u"], u) and np.array_equal(z["ib"], ib)
+        assert np.array_equal(z["v"], v[:, lo:hi]) and np.array_equal(z["ub"], ub[lo:hi])
+        assert np.allclose(z["se"], np.asarray(se), rtol=1e-12, atol=0)
+        assert int(z["resident_blocks_after"]) == 0
+
+
 def test_averaging_mode_over_real_processes_equals_the_fake_world(mock_lib, tmp_path):
     from mfrec_amd import sharding as SH
     idx, r, u0, v0 = _problem()
@@ -192,15 +219,14 @@ def test_averaging_mode_over_real_processes_equals_the_fake_world(mock_lib, tmp_
         assert np.array_equal(z["v"], v[:, lo:hi]) and np.array_equal(z["ub"], ub[lo:hi])
 
 
-def test_averaging_mode_on_the_block_order_over_real_processes_equals_its_simulation(mock_lib, tmp_path):
-    """ShardedKMFBlocks (mfx_dsgd_run_kmf_averaged): the averaging scheme with every shard's local epoch on ITS block order and one
-    all-reduce per item block, two real ranks -- against the CPU simulation of the same scheme: per epoch every shard runs the
-    oracle's epoch (kmf_train.pyx:243-270) on its ratings in the order the rank reports, from the common item state; the deltas
-    are added in rank order and combined with scale 1/2 (sharding.combine)."""
+def _check_avgblocks(res, k):
+    """The CPU simulation of the averaging scheme on the ranks' block orders: per epoch every shard runs the oracle's epoch
+    (kmf_train.pyx:243-270) on its ratings in the order the rank reports, from the common item state; the deltas are added in rank
+    order and combined with scale 1/2 (sharding.combine)."""
     from mfrec_amd import sharding as SH
     from oracle import oracle as O
-    idx, r, u0, v0 = _problem()
-    res = _launch(mock_lib, tmp_path, 2, "avgblocks", 29761)
+    idx, r = synth.make_ratings(NU, NI, NNZ, seed=41)
+    u0, v0 = synth.init_normal(k, NI, 1), synth.init_normal(k, NU, 2)
     bounds = SH.user_blocks(idx, NU, 2)
     shards = [SH.shard(idx, r, bounds, g) for g in range(2)]
     u, ib, v, ub = u0.copy(), np.zeros(NI), v0.copy(), np.zeros(NU)
@@ -211,7 +237,7 @@ def test_averaging_mode_on_the_block_order_over_real_processes_equals_its_simula
             assert sorted(perm.tolist()) == list(range(sr.shape[0]))
             ug, ibg = u.copy(), ib.copy()
             vg, ubg = np.ascontiguousarray(v[:, lo:lo + n]), np.ascontiguousarray(ub[lo:lo + n])
-            O.train_linear_kernel(1, K, 0.1, HP[0], 0, 0, HP[1], HP[2], HP[3], 0.0, ug, vg, np.ascontiguousarray(sidx[perm]),
+            O.train_linear_kernel(1, k, 0.1, HP[0], 0, 0, HP[1], HP[2], HP[3], 0.0, ug, vg, np.ascontiguousarray(sidx[perm]),
                                   np.ascontiguousarray(sr[perm]), ibg, ubg)
             v[:, lo:lo + n] = vg; ub[lo:lo + n] = ubg
             du += ug - u
@@ -221,6 +247,34 @@ def test_averaging_mode_on_the_block_order_over_real_processes_equals_its_simula
         lo, hi = int(z["lo"]), int(z["hi"])
         assert np.array_equal(z["u"], u) and np.array_equal(z["ib"], ib)
         assert np.array_equal(z["v"], v[:, lo:hi]) and np.array_equal(z["ub"], ub[lo:hi])
+
+
+def test_averaging_mode_on_the_block_order_over_real_processes_equals_its_simulation(mock_lib, tmp_path):
+    """ShardedKMFBlocks (mfx_dsgd_run_kmf_averaged): the averaging scheme with every shard's local epoch on ITS block order and one
+    all-reduce per item block -- on the TRANSFER stream, under the next block's training (round 4) --, two real ranks, against the
+    CPU simulation of the same scheme.  The stand-in delivers late: a missing event between the two streams reads stale rows."""
+    res = _launch(mock_lib, tmp_path, 2, "avgblocks", 29761)
+    _check_avgblocks(res, K)
+
+
+def test_averaging_mode_with_static_blocks_and_a_rank_that_loses_a_co_residency_check(mock_lib, tmp_path):
+    """The same with every block on the STATIC resident-side epoch (k = 32, forced), the all-reduce kernels of block j running beside
+    block j + 1's persistent launch.  Rank 0's 5th static launch fails its registration (test hook: what a GPU shared with another
+    process does): that block epoch and the plan's later ones modify nothing while the other blocks go on -- the ranks agree on the
+    failure after the run, restore the snapshot taken when the call began, move every block to the level schedule and run the call
+    again.  Same bits as the simulation; and without a failure (rank hooks off) the static blocks give them too."""
+    for port, extra in ((29762, {"MFX_K1_RES": "static", "MFX_TEST_K": "32"}),
+                        (29763, [{"MFX_K1_RES": "static", "MFX_TEST_K": "32", "MFX_GRAPH": "0", "MFX_TEST_REG_FAIL": "5"},
+                                 {"MFX_K1_RES": "static", "MFX_TEST_K": "32", "MFX_GRAPH": "0"}])):
+        res = _launch(mock_lib, tmp_path, 2, "avgblocks", port, extra)
+        _check_avgblocks(res, 32)
+        if isinstance(extra, list):
+            assert int(res[0]["resident_blocks_after"]) == 0 and int(res[1]["resident_blocks_after"]) == 0   # BOTH ranks went to levels
+        else:
+            # (two processes share the card here: a REAL lost check can happen -- it did, once, in round 4 -- and is recovered the
+            #  same way; all blocks or none)
+            assert int(res[0]["resident_blocks_before"]) == 3 and int(res[0]["resident_blocks_after"]) in (0, 3)
+            assert int(res[0]["resident_blocks_after"]) == int(res[1]["resident_blocks_after"])
 
 
 def test_sharded_funk_pass_over_real_processes_equals_its_simulation(mock_lib, tmp_path):
@@ -296,3 +350,24 @@ def test_bench_two_ranks_prints_one_line_with_both_modes(mock_lib, tmp_path):
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert "users sharded over 2 GPUs" in d["config"]["workload"]
     assert d["also"]["dsgd_exact"]["value"] > 0 and "error" not in d["also"]["dsgd_exact"]
+
+
+def test_bench_plain_invocation_launches_its_own_ranks(mock_lib):
+    """`python bench.py --gpus 2 ...` with NO launcher (no WORLD_SIZE in the environment -- the shape of the driver's N = 1 command):
+    bench.py starts its own two ranks before anything touches the GPU, rank 0 prints the one JSON line, the exit code is the worst
+    child's.  Both ranks on device 0 through the stand-in; the static resident-side epoch is left ON (two grids share the GPU: a lost
+    co-residency check is recovered inside the library, never an error)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MFX_RCCL_LIB=mock_lib, MFX_TESTING="1", MFX_BENCH_DEVICE="0", MFX_BENCH_DSGD_TIMEOUT="200")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--users", "60000", "--items", "20000", "--nnz", "3000000"], env=env, capture_output=True, text=True,
+                         timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert "users sharded over 2 GPUs" in d["config"]["workload"]
+    assert d["also"]["dsgd_exact"]["value"] > 0 and "error" not in d["also"]["dsgd_exact"]
+    # the kernel named in the roofline is the one the epoch ran on
+    assert ("k1_res" in d["roofline"]["kernel"]) == (d["config"]["epoch_kernel"].startswith("static"))

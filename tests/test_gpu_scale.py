@@ -168,6 +168,36 @@ def test_cfg4_full_size_als_epoch_residuals(cfg3_data):
     assert dev_s < 1.0                      # 0.14 s measured; a regression guard, not a benchmark
 
 
+def test_cfg4_shaped_row_slices_vs_oracle(cfg3_data):
+    """cfg 4's shapes against the ORACLE itself (als_implicit.pyx:211-352 restated), where it is affordable: the user pass over
+    the first 2 000 users with the FULL 200 K-item factor table (degree ~100 rows, Gramian over 200 K columns, k = 128), the item
+    pass over the first 300 items with the FULL 1 M-user table (degree ~500 rows: the long rows of the item half-pass) -- the
+    run-length views simply end there (rows beyond the last listed row stay untouched, als_implicit.pyx:269-270).  About a minute
+    of CPU.  1e-9 relative, the ALS tolerance of tests/test_gpu_als.py (Cholesky solve against the reference's explicit inverse)."""
+    import scipy.sparse as sp
+    from mfrec_amd.lib.als_implicit import als_wrmf
+    from mfrec_amd.lib.datasets import create_bool_sparse_col, create_bool_sparse_row
+    from oracle import oracle as O
+    nu, ni, nnz, idx, _ = cfg3_data
+    k, c_pos, lam, n_users, n_items = 128, 1, 0.015, 2000, 300
+    M = sp.csr_matrix((np.ones(nnz, dtype=np.int8), (idx[:, 0], idx[:, 1])), shape=(nu, ni))
+    M.sum_duplicates()
+    urow, ucol = create_bool_sparse_row(M[:n_users])
+    irow, icol = create_bool_sparse_col(M[:, :n_items])
+    del M
+    assert len(urow) == n_users + 1 and len(irow) == n_items + 1 and 150000 < len(ucol) < 250000 and 100000 < len(icol) < 200000
+    rs = np.random.RandomState(1)
+    u0, v0 = rs.normal(0, 0.1, (k, ni)), rs.normal(0, 0.1, (k, nu))
+    u, v = u0.copy(), v0.copy()
+    als_wrmf(1, k, u, v, None, None, urow, ucol, irow, icol, nu, ni, c_pos, lam)
+    u2, v2 = u0.copy(), v0.copy()
+    O.als_wrmf(1, k, u2, v2, None, None, urow, ucol, irow, icol, nu, ni, c_pos, lam)
+    assert np.array_equal(v[:, n_users:], v0[:, n_users:]) and np.array_equal(u[:, n_items:], u0[:, n_items:])   # untouched rows
+    assert not np.array_equal(v[:, :n_users], v0[:, :n_users])
+    np.testing.assert_allclose(v[:, :n_users], v2[:, :n_users], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(u[:, :n_items], u2[:, :n_items], rtol=1e-9, atol=1e-12)
+
+
 def test_cfg5_shard_shape_properties():
     from mfrec_amd import _shim as S
     from mfrec_amd.plan import SgdPlan
@@ -236,8 +266,33 @@ def test_cfg5_whole_one_gpu_properties():
     d.close()
     assert dinfo["item_blocks"] == 24 and dinfo["resident_blocks"] == 72, dinfo
     assert perm.shape[0] == nnz and int(perm.sum()) == nnz * (nnz - 1) // 2
-    del perm
     assert np.all(np.isfinite(se)) and np.all(np.diff(se) < 0), se
+    # ORACLE check of that path on a prefix of the epoch: the first block of the reported order -- block (user block 0, item block 0),
+    # ~14 M ratings against the full 10 M x 1 M row tables -- as a trainer of its own on the SAME bounds (every other block empty),
+    # one epoch, bit for bit against the sequential loop (kmf_train.pyx:243-270) on those ratings in the order it reports
+    from oracle import oracle as O
+    ub_, ib_ = d.user_bounds.copy(), d.item_bounds.copy()
+    n0 = int(np.count_nonzero((idx[:, 0] < ub_[1]) & (idx[:, 1] < ib_[1])))
+    sub = np.sort(perm[:n0])                                   # the block's ratings, in the GIVEN order
+    del perm
+    sidx, sr = np.ascontiguousarray(idx[sub]), np.ascontiguousarray(r[sub])
+    assert int(sidx[:, 0].max()) < ub_[1] and int(sidx[:, 1].max()) < ib_[1] and 10000000 < n0 < 18000000
+    del sub
+    pu, pv = synth.init_normal(k, ni, 7), synth.init_normal(k, nu, 8)
+    pib, pub = np.zeros(ni), np.zeros(nu)
+    d2 = sharding.DsgdKMF(sidx, sr, nu, ni, k, -1, 3, user_bounds=ub_, item_bounds=ib_, item_blocks_1gpu=24)
+    assert d2.info()["resident_blocks"] == 1                          # (the 71 other blocks are empty)
+    d2.set_factors(pu, pv, pib, pub)
+    d2.train(0, 1, *HP)
+    d2.get_factors(pu, pv, pib, pub)
+    porder = d2.order()
+    d2.close()
+    assert np.array_equal(porder, np.arange(n0))                      # (one block, given order inside it: the identity)
+    ou, ov, oib, oub = synth.init_normal(k, ni, 7), synth.init_normal(k, nu, 8), np.zeros(ni), np.zeros(nu)
+    O.train_linear_kernel(1, k, 0.1, HP[0], 0, 0, HP[1], HP[2], HP[3], 0.0, ou, ov, np.ascontiguousarray(sidx[porder]),
+                          np.ascontiguousarray(sr[porder]), oib, oub)
+    assert np.array_equal(pu, ou) and np.array_equal(pv, ov) and np.array_equal(pib, oib) and np.array_equal(pub, oub)
+    del pu, pv, ou, ov, sidx, sr
     # host and device builders on the first 100 M ratings of the same tables: same level structure
     n = 100000000
     pidx, pr = np.ascontiguousarray(idx[:n]), np.ascontiguousarray(r[:n])

@@ -25,8 +25,9 @@ agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for f in glob.glob(O + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         kn = r["Kernel_Name"]
-        if kn.startswith("k2_") or "k2_" in kn[:40]:
-            a = agg[kn.split("(")[0]][r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
+        if "::k2_" in kn:
+            short = kn[kn.index("::k2_") + 2:].split("(")[0]          # e.g. k2_res_box<2>
+            a = agg[short][r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
 out = {k: {c: {"dispatches": v[0], "avg": v[1] / v[0]} for c, v in cs.items()} for k, cs in agg.items()}
 json.dump(out, open(O + "/summary.json", "w"), indent=1)
 for k in sorted(out):

@@ -340,32 +340,47 @@ def train_rmse(u, v, ib, ub, idx, r, nu, ni, k):
     return out.value
 
 
-def also_k1_tolerance(idx, r, nu, ni, k, u0, v0, steps, warmup, order, epochs=10):
-    """North-star's own kernel wording (wave-shuffle reduction of the k-dim dot, FMA): timed, and its final
-    train RMSE after `epochs` epochs compared with the exact mode's (= the oracle's, bit for bit) from the
-    same initial factors on the same order."""
+def also_k1_tolerance(idx, r, nu, ni, k, u0, v0, steps, warmup, order, epochs=10, variant="butterfly"):
+    """The two tolerance modes of the full-k epoch, each timed, with its final train RMSE after `epochs` epochs against the exact
+    mode's (= the oracle's, bit for bit) from the same initial factors on the same order.
+    variant "butterfly": north_star's own kernel wording (wave-shuffle reduction of the k-dim dot, FMA), f64 rows;
+    variant "f32": f32 row storage, f64 arithmetic, ordered dot (half the travelling bytes)."""
     from mfrec_amd.plan import SgdPlan, LINEAR
     if order == "balanced":
         from mfrec_amd.lib.datasets import balanced_order_gpu
         perm, _ = balanced_order_gpu(idx, nu, ni)
         idx, r = np.ascontiguousarray(idx[perm]), np.ascontiguousarray(r[perm])
     res = {}
-    for dot in ("ordered", "butterfly"):
+    kw = {"dot": "butterfly"} if variant == "butterfly" else {"storage": "f32"}
+    for name, kwargs in (("exact", {}), (variant, kw)):
         u, v, ib, ub = u0.copy(), v0.copy(), np.zeros(ni), np.zeros(nu)
-        with SgdPlan(idx, r, nu, ni, k, dot=dot) as p:
+        with SgdPlan(idx, r, nu, ni, k, **kwargs) as p:
             p.set_factors(u, v, ib, ub)
             p.run_kmf(LINEAR, epochs, LR, KU, KI, KB, want_rmse=False)
             p.get_factors(u, v, ib, ub)
-            res[dot] = train_rmse(u, v, ib, ub, idx, r, nu, ni, k)
-            if dot == "butterfly":
+            res[name] = train_rmse(u, v, ib, ub, idx, r, nu, ni, k)
+            if name == variant:
                 m = k1_measure(p, idx.shape[0], nu, k, steps, warmup,
                                lambda n: p.run_kmf(LINEAR, n, LR, KU, KI, KB, want_rmse=False))
     m["unit"] = "rating-updates/s"
-    m["workload"] = "cfg2 shape, %s order, full-k SGD in TOLERANCE mode: butterfly k-dot (DPP + cross-row swaps, fixed " \
-                    "association) + FMA -- deterministic f64, not bit-identical to the reference" % order
-    m["final_train_rmse_exact_mode"] = res["ordered"]
-    m["final_train_rmse"] = res["butterfly"]
-    m["rmse_delta_vs_exact_after_%d_epochs" % epochs] = abs(res["butterfly"] - res["ordered"])
+    if variant == "butterfly":
+        m["dtype"] = "f64 (butterfly dot + FMA: a different summation order than the reference's)"
+        m["workload"] = "cfg2 shape, %s order, full-k SGD in TOLERANCE mode: butterfly k-dot (DPP + cross-row swaps, fixed " \
+                        "association) + FMA -- deterministic f64, not bit-identical to the reference" % order
+    else:
+        m["dtype"] = "f64 arithmetic on f32-stored rows (NOT the reference precision)"
+        m["workload"] = "cfg2 shape, %s order, full-k SGD on f32-STORED rows (widened on load, rounded once per update), f64 " \
+                        "arithmetic, ordered dot -- half the travelling bytes; not the reference's precision" % order
+        # the byte model at s = 4 (SURVEY 8(d)): 16-B record + k*4 + 8 (f64 bias) + amortised user row
+        b_read = 16 + k * 4 + 8 + (k * 4 + 8) / (idx.shape[0] / float(nu))
+        ro = m["roofline"]
+        ro["bytes_per_update_read"] = b_read
+        ro["achieved"] = m["value"] * b_read / 1e9
+        ro["frac"] = m["value"] * b_read / HBM_PEAK
+        ro["algorithmic_bytes_per_launch"] = b_read * idx.shape[0] / ro["launches_per_epoch"]
+    m["final_train_rmse_exact_mode"] = res["exact"]
+    m["final_train_rmse"] = res[variant]
+    m["rmse_delta_vs_exact_after_%d_epochs" % epochs] = abs(res[variant] - res["exact"])
     m["rmse_budget"] = 1e-5
     return m
 
@@ -1058,6 +1073,8 @@ def main():
         leg("k1_balanced", lambda: also_k1_order(idx, r, nu, ni, k, u0, v0n, a.steps, a.warmup, "balanced"))
         leg("k1_tolerance_mode", lambda: also_k1_tolerance(idx, r, nu, ni, k, u0, v0n, a.steps, a.warmup, "shuffled"))
         leg("k1_tolerance_mode_balanced", lambda: also_k1_tolerance(idx, r, nu, ni, k, u0, v0n, a.steps, a.warmup, "balanced"))
+        leg("k1_f32_rows", lambda: also_k1_tolerance(idx, r, nu, ni, k, u0, v0n, a.steps, a.warmup, "shuffled", variant="f32"))
+        leg("k1_f32_rows_balanced", lambda: also_k1_tolerance(idx, r, nu, ni, k, u0, v0n, a.steps, a.warmup, "balanced", variant="f32"))
         leg("k1_zipf08", lambda: also_k1_skew(nu, ni, nnz, k, u0, v0n, 0.8))
         leg("k2_funk", lambda: also_funk(idx, r, nu, ni, k, "shuffled"))
         leg("k2_funk_balanced", lambda: also_funk(idx, r, nu, ni, k, "balanced"))

@@ -398,16 +398,22 @@ K1Params k1_params(mfx_sgd_plan *p, double lr, double Ku, double Ki, double Kb, 
 // run `epochs` full-k epochs; hook (nullable) is called after each epoch's launches have
 // been enqueued (sharded mode enqueues its all-reduce there).
 // one resident-side epoch + its squared-error reduction (mfx_sgd_res.hip)
+// 0: f64 rows + ordered dot; 1: butterfly dot (f64 rows); 2: f32 rows (ordered dot); -1: not served there (bf16 rows)
+int res_variant(const mfx_sgd_plan *p) { return p->f32 == 2 ? -1 : (p->f32 == 1 ? (p->dot ? -1 : 2) : (p->dot ? 1 : 0)); }
 int enqueue_res_epoch(mfx_sgd_plan *p, int mode, const K1Params &P)
 {
-    int rc = res_enqueue_epoch(p->res, mode, (double *)P.U, (double *)P.V, P.ib, P.ub, P.lr, P.Ku, P.Ki, P.Kb, p->dot != 0);
+    int rc = res_enqueue_epoch(p->res, mode, (double *)P.U, (double *)P.V, P.ib, P.ub, P.lr, P.Ku, P.Ki, P.Kb, res_variant(p));
     if (rc) return rc;
     return enqueue_reduce(p, res_se_slots(p->res), res_se_partials(p->res));
 }
 
 // the resident-side epoch serves the plain linear / logistic run: f64 rows, both sides trained; the ordered dot, or -- round 4 --
 // the butterfly-dot tolerance mode (every binding but the burst variant)
-bool res_on(const mfx_sgd_plan *p) { return p->res && p->res_state == 1 && !p->f32 && (!p->dot || res_dot_ok(p->res)); }
+bool res_on(const mfx_sgd_plan *p)
+{
+    const int v = res_variant(p);
+    return p->res && p->res_state == 1 && v >= 0 && (v == 0 || res_variants_ok(p->res));
+}
 bool res_applies(const mfx_sgd_plan *p, int mode, const K1Params &P)
 {
     return res_on(p) && (mode == K1_LINEAR || mode == K1_LOGISTIC) && P.upd_u && P.upd_i;
@@ -887,7 +893,7 @@ int mfx_sgd_plan_kernel_name(const mfx_sgd_plan *p, int mode, char *buf, int buf
         else snprintf(buf, (size_t)buflen, "k2_level<%d threads>%s", kK2Block, p->k2x_state == 0 ? " (undecided: no Funk run yet)" : "");
         return MFX_OK;
     }
-    if (mode < 2 && res_on(p)) return res_describe(p->res, mode, buf, buflen, p->dot != 0);
+    if (mode < 2 && res_on(p)) return res_describe(p->res, mode, buf, buflen, res_variant(p));
     static const char *const mode_name[] = {"linear", "logistic", "learned"};
     snprintf(buf, (size_t)buflen, "k1_level<%s,%s%s>", k1_select<false>(p->k, mode, p->batch, p->f32, p->dot).tag,
              mode_name[mode], p->f32 == 1 ? ",f32" : "");

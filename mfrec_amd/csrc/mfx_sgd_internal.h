@@ -75,11 +75,12 @@ int res_kind(const ResPlan *rp);                 // 0 none, 1 ticket (users resi
 size_t res_dev_bytes(const ResPlan *rp);
 int64_t res_se_slots(const ResPlan *rp);
 const double *res_se_partials(const ResPlan *rp);
-int res_describe(const ResPlan *rp, int mode, char *buf, int buflen, bool dot = false);
-bool res_dot_ok(const ResPlan *rp);            // the butterfly-dot tolerance mode is served by this plan's resident-side kernel
+// variant: 0 = f64 rows, ordered dot (exact); 1 = butterfly dot + FMA (tolerance mode, f64 rows); 2 = f32 row storage (ordered dot)
+int res_describe(const ResPlan *rp, int mode, char *buf, int buflen, int variant = 0);
+bool res_variants_ok(const ResPlan *rp);       // variants 1 and 2 are served by this plan's resident-side kernel (all but the burst one)
 int res_begin_batch(ResPlan *rp);
 int res_enqueue_epoch(ResPlan *rp, int mode, double *U_nk, double *V_nk, double *ib, double *ub, double lr, double Ku,
-                      double Ki, double Kb, bool dot = false);
+                      double Ki, double Kb, int variant = 0);
 int res_status(ResPlan *rp, unsigned *status, unsigned *applied = nullptr);
 // plan creation with the epoch kernel chosen (MFX_EPOCH_*); the Funk / learned-bias / dense-cache drop-ins pass
 // MFX_EPOCH_LEVELS: they never run a plain full-k epoch.  | kEpochHeadroom (DSGD sub-plans): a static grid leaves an eighth

@@ -68,6 +68,42 @@ constexpr int kSpinReg = 1 << 15;        // registration: tens of milliseconds
 // 16-byte agent-scope (sc1) accesses the compiler can see and count
 __device__ __forceinline__ v4u ld16c(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16); }
 __device__ __forceinline__ void st16c(v4u v, __amdgpu_buffer_rsrc_t r, unsigned off) { __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 16); }
+// one lane's feature pair of a row in the plan's storage type TS: f64 rows move 16 bytes per lane (exact mode), f32 rows 8 bytes
+// ("f32 storage, f64 arithmetic": widened on load, rounded once on store -- the level kernels' narrow-storage option,
+// mfx_sgd_plan_set_storage(32); NOT the reference's precision)
+template <typename TS> struct RowIO;
+template <> struct RowIO<double> {
+    static constexpr unsigned lane_bytes = 16u;
+    static __device__ __forceinline__ d2 ld(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_bit_cast(d2, ld16c(r, off)); }
+    static __device__ __forceinline__ void st(d2 v, __amdgpu_buffer_rsrc_t r, unsigned off) { st16c(__builtin_bit_cast(v4u, v), r, off); }
+    static __device__ __forceinline__ d2 round(d2 v) { return v; }
+    static __device__ __forceinline__ d2 ldp(const double *rows, size_t e) { return *reinterpret_cast<const d2 *>(rows + e); }
+    static __device__ __forceinline__ void stp(double *rows, size_t e, d2 v) { *reinterpret_cast<d2 *>(rows + e) = v; }
+};
+template <> struct RowIO<float> {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    static constexpr unsigned lane_bytes = 8u;
+    static __device__ __forceinline__ d2 ld(__amdgpu_buffer_rsrc_t r, unsigned off)
+    {
+        const f2 w = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 16));
+        return d2{(double)w.x, (double)w.y};
+    }
+    static __device__ __forceinline__ void st(d2 v, __amdgpu_buffer_rsrc_t r, unsigned off)
+    {
+        const f2 w = f2{(float)v.x, (float)v.y};
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, w), r, off, 0, 16);
+    }
+    static __device__ __forceinline__ d2 round(d2 v) { return d2{(double)(float)v.x, (double)(float)v.y}; }   // what the next load would return
+    static __device__ __forceinline__ d2 ldp(const double *rows, size_t e)
+    {
+        const f2 w = *reinterpret_cast<const f2 *>(reinterpret_cast<const float *>(rows) + e);
+        return d2{(double)w.x, (double)w.y};
+    }
+    static __device__ __forceinline__ void stp(double *rows, size_t e, d2 v)
+    {
+        *reinterpret_cast<f2 *>(reinterpret_cast<float *>(rows) + e) = f2{(float)v.x, (float)v.y};
+    }
+};
 // a slot's next record.  Plain (cached) load: a lane walks its run 16 bytes at a time and eight records share a 128-byte line.
 // (Measured against non-temporal loads: FETCH_SIZE and the epoch time are the same within the box-to-box spread.)
 #ifndef MFX_RES_REC_NT
@@ -229,7 +265,7 @@ __device__ __forceinline__ double group_sum_r(double x, int lane)
 
 // One step of a wave: the slots in `mask` apply their head rating.  FULL: every slot (no branches around
 // memory operations: one basic block of loads, one of stores).  Lane s < B owns slot s's scalar state.
-template <int KP, int NR, int MODE, bool FULL, bool DOT>
+template <int KP, int NR, int MODE, bool FULL, bool DOT, typename TS>
 __device__ __forceinline__ void res_step(const ResParams &P, unsigned long long mask, bool ready, const URec &rec, double tbv,
                                          double &rbv, double &se, d2 (&vv)[NR], double *prod, __amdgpu_buffer_rsrc_t rT,
                                          int lane, int g, int q, double &tbn RS_PARAM)
@@ -240,7 +276,7 @@ __device__ __forceinline__ void res_step(const ResParams &P, unsigned long long 
     const bool fl = 2 * q < k;                               // this lane holds a feature pair
     bool rdy[NR];
     d2 uu[NR];
-    const unsigned qoff = (unsigned)q * 16u, rowb = (unsigned)(k * 8);
+    const unsigned qoff = (unsigned)q * RowIO<TS>::lane_bytes, rowb = (unsigned)(k * (int)sizeof(TS));
     constexpr unsigned SETM = (1u << SPW) - 1u;
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
@@ -251,7 +287,7 @@ __device__ __forceinline__ void res_step(const ResParams &P, unsigned long long 
         // address, no memory instruction for it.  (The cross-lane reads are v_readlane: they do not depend on EXEC.)
         if (FULL || ((unsigned)(mask >> (j * SPW)) & SETM)) {
             const unsigned o = (unsigned)set_bcast_i<SPW>(rec.trav, j * SPW, g) * rowb + qoff;
-            if (rdy[j]) uu[j] = __builtin_bit_cast(d2, ld16c(rT, o));
+            if (rdy[j]) uu[j] = RowIO<TS>::ld(rT, o);
         }
     }
     wait_vm0();
@@ -328,8 +364,8 @@ __device__ __forceinline__ void res_step(const ResParams &P, unsigned long long 
                 vn.x = cf.x + P.lr * (gr * mf.x - P.Kres * cf.x);
                 vn.y = cf.y + P.lr * (gr * mf.y - P.Kres * cf.y);
             }
-            st16c(__builtin_bit_cast(v4u, un), rT, o);
-            vv[j] = vn;
+            RowIO<TS>::st(un, rT, o);
+            vv[j] = RowIO<TS>::round(vn);
         }
     }
 }
@@ -472,10 +508,11 @@ __device__ __forceinline__ int res_burst(const ResParams &P, int s, int &pos, in
 }
 
 // KP lanes per row (16 bytes = one feature pair per lane: k <= 2 KP), NR register sets per lane, B = NR * 64/KP slots
-template <int KP, int NR, int MODE, bool STATIC, bool BURST = false, bool DOT = false>
+template <int KP, int NR, int MODE, bool STATIC, bool BURST = false, bool DOT = false, typename TS = double>
 __global__ __launch_bounds__(64, STATIC ? ((NR <= 9 && !BURST) ? 3 : 2) : 4) void k1_res(ResParams P)
 {
     static_assert(!(BURST && DOT), "the burst walk keeps the ordered sum");
+    static_assert(!(BURST || DOT) || std::is_same<TS, double>::value, "narrow rows: ordered sum, no bursts");
     constexpr int SPW = 64 / KP, B = NR * SPW;
     extern __shared__ __attribute__((aligned(16))) double prod[];       // [B][stride]
     const int lane = threadIdx.x, g = lane / KP, q = lane % KP;
@@ -525,7 +562,7 @@ __global__ __launch_bounds__(64, STATIC ? ((NR <= 9 && !BURST) ? 3 : 2) : 4) voi
             const int ent = __shfl(my_ent, j * SPW + g, 64);
             const int hv = __shfl((int)have, j * SPW + g, 64);
             vv[j] = d2{0.0, 0.0};
-            if (hv && fl) vv[j] = *reinterpret_cast<const d2 *>(P.Rm + (size_t)ent * k + 2 * q);
+            if (hv && fl) vv[j] = RowIO<TS>::ldp(P.Rm, (size_t)ent * k + 2 * q);
         }
         double se = 0.0;
         int spins = 0;
@@ -564,8 +601,8 @@ __global__ __launch_bounds__(64, STATIC ? ((NR <= 9 && !BURST) ? 3 : 2) : 4) voi
                 }
             }
             double tbn = 0.0;
-            if (!STATIC && mask == ALL) res_step<KP, NR, MODE, true, DOT>(P, mask, ready, rec, h.bias, rbv, se, vv, prod, rT, lane, g, q, tbn RS_ARG);
-            else res_step<KP, NR, MODE, false, DOT>(P, mask, ready, rec, h.bias, rbv, se, vv, prod, rT, lane, g, q, tbn RS_ARG);
+            if (!STATIC && mask == ALL) res_step<KP, NR, MODE, true, DOT, TS>(P, mask, ready, rec, h.bias, rbv, se, vv, prod, rT, lane, g, q, tbn RS_ARG);
+            else res_step<KP, NR, MODE, false, DOT, TS>(P, mask, ready, rec, h.bias, rbv, se, vv, prod, rT, lane, g, q, tbn RS_ARG);
             RS(3);                                                        // 2 + 3: loads, products, sums, updates, stores issued (res_step stamps 2)
             // publish: every row store of this wave has been acknowledged, then bias + chain counter in one granule
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -592,7 +629,7 @@ __global__ __launch_bounds__(64, STATIC ? ((NR <= 9 && !BURST) ? 3 : 2) : 4) voi
         for (int j = 0; j < NR; ++j) {
             const int ent = __shfl(my_ent, j * SPW + g, 64);
             const int hv = __shfl((int)have, j * SPW + g, 64);
-            if (hv && fl) *reinterpret_cast<d2 *>(P.Rm + (size_t)ent * k + 2 * q) = vv[j];
+            if (hv && fl) RowIO<TS>::stp(P.Rm, (size_t)ent * k + 2 * q, vv[j]);
         }
         if (have) { P.rb[my_ent] = rbv; P.se_run[run] = se; }
     }
@@ -634,26 +671,29 @@ size_t res_lds_bytes(int kp, int id) { return ((size_t)id * (64 / kp) * (2 * kp 
 
 // ticket: 4 register sets (4 waves per SIMD); static: 9 sets at 3 waves per SIMD (18 slots x 3 072 waves at k = 64: measured 3 %
 // faster than 26 x 2 048 and 5 % faster than 32 x 2 048 on cfg 2) or 16 sets at 2 waves per SIMD (the largest side that fits)
-template <int MODE, int NR, bool STATIC, bool BURST = false, bool DOT = false>
+template <int MODE, int NR, bool STATIC, bool BURST = false, bool DOT = false, typename TS = double>
 Sel pick(int k)
 {
     const int id = NR;
-    if (k <= 32) return {(void *)k1_res<16, NR, MODE, STATIC, BURST, DOT>, 16, NR, id};
-    if (k <= 64) return {(void *)k1_res<32, NR, MODE, STATIC, BURST, DOT>, 32, NR, id};
-    return {(void *)k1_res<64, NR, MODE, STATIC, BURST, DOT>, 64, NR, id};
+    if (k <= 32) return {(void *)k1_res<16, NR, MODE, STATIC, BURST, DOT, TS>, 16, NR, id};
+    if (k <= 64) return {(void *)k1_res<32, NR, MODE, STATIC, BURST, DOT, TS>, 32, NR, id};
+    return {(void *)k1_res<64, NR, MODE, STATIC, BURST, DOT, TS>, 64, NR, id};
 }
 // id: 4 = ticket; 9 / 16 = static; 13 = static with bursts (skewed data: 2 waves per SIMD, 26 slots x 2 048 waves at k = 64).
-// dot: the butterfly-dot / FMA tolerance mode (mfx_sgd_plan_set_dot) -- every binding but the burst variant, whose walk keeps the
-// ordered sum (res_dot_ok: such a plan runs its tolerance mode on the level kernels)
-template <int MODE, bool DOT>
+// variant 0: f64 rows, ordered dot (exact); 1: the butterfly-dot / FMA tolerance mode (mfx_sgd_plan_set_dot); 2: f32 row storage
+// (mfx_sgd_plan_set_storage(32)) -- both on every binding but the burst variant, whose walk keeps f64 rows and the ordered sum
+// (res_variants_ok: such a plan serves its tolerance modes on the level kernels)
+template <int MODE, bool DOT, typename TS>
 Sel select_m(int k, int id)
 {
-    return id == 4 ? pick<MODE, 4, false, false, DOT>(k) : (id == 9 ? pick<MODE, 9, true, false, DOT>(k) : (id == 13 ? pick<MODE, 13, true, true>(k) : pick<MODE, 16, true, false, DOT>(k)));
+    return id == 4 ? pick<MODE, 4, false, false, DOT, TS>(k) : (id == 9 ? pick<MODE, 9, true, false, DOT, TS>(k) : pick<MODE, 16, true, false, DOT, TS>(k));
 }
-Sel select(int k, int mode, int id, bool dot = false)
+Sel select(int k, int mode, int id, int variant = 0)
 {
-    if (dot && id != 13) return mode == 0 ? select_m<0, true>(k, id) : select_m<1, true>(k, id);
-    return mode == 0 ? select_m<0, false>(k, id) : select_m<1, false>(k, id);
+    if (id == 13) return mode == 0 ? pick<0, 13, true, true>(k) : pick<1, 13, true, true>(k);
+    if (variant == 1) return mode == 0 ? select_m<0, true, double>(k, id) : select_m<1, true, double>(k, id);
+    if (variant == 2) return mode == 0 ? select_m<0, false, float>(k, id) : select_m<1, false, float>(k, id);
+    return mode == 0 ? select_m<0, false, double>(k, id) : select_m<1, false, double>(k, id);
 }
 
 }  // namespace
@@ -870,12 +910,12 @@ int res_kind(const ResPlan *rp) { return rp ? rp->kind : 0; }
 size_t res_dev_bytes(const ResPlan *rp) { return rp ? rp->dev_bytes : 0; }
 int64_t res_se_slots(const ResPlan *rp) { return rp->se_slots; }
 const double *res_se_partials(const ResPlan *rp) { return rp->d_se_run; }
-bool res_dot_ok(const ResPlan *rp) { return rp && rp->nr != 13; }
-int res_describe(const ResPlan *rp, int mode, char *buf, int buflen, bool dot)
+bool res_variants_ok(const ResPlan *rp) { return rp && rp->nr != 13; }
+int res_describe(const ResPlan *rp, int mode, char *buf, int buflen, int variant)
 {
     static const char *const mode_name[] = {"linear", "logistic"};
     snprintf(buf, (size_t)buflen, "k1_res<%d lanes/row,%d slots,%s%s,%s: %s rows resident,%d waves>", rp->kp, rp->B,
-             mode_name[mode & 1], dot ? ",butterfly-dot+fma" : "", rp->kind == 1 ? "ticket" : (rp->nr == 13 ? "static+bursts" : "static"), rp->res_item ? "item" : "user", rp->waves);
+             mode_name[mode & 1], variant == 1 ? ",butterfly-dot+fma" : (variant == 2 ? ",f32 rows" : ""), rp->kind == 1 ? "ticket" : (rp->nr == 13 ? "static+bursts" : "static"), rp->res_item ? "item" : "user", rp->waves);
     return MFX_OK;
 }
 
@@ -888,7 +928,7 @@ int res_begin_batch(ResPlan *rp)
 
 // enqueue ONE epoch on the library stream (capturable): counters, granules, the persistent launch, biases back
 int res_enqueue_epoch(ResPlan *rp, int mode, double *U_nk, double *V_nk, double *ib, double *ub, double lr, double Ku,
-                      double Ki, double Kb, bool dot)
+                      double Ki, double Kb, int variant)
 {
     ResParams P;
     memset(&P, 0, sizeof(P));
@@ -901,7 +941,7 @@ int res_enqueue_epoch(ResPlan *rp, int mode, double *U_nk, double *V_nk, double 
     P.n_runs = rp->n_runs; P.k = rp->k; P.res_item = rp->res_item ? 1 : 0;
     P.lr = lr; P.Kres = rp->res_item ? Ki : Ku; P.Ktrav = rp->res_item ? Ku : Ki; P.Kb = Kb;
     P.reg_extra = test_reg_extra();
-    const Sel s = select(rp->k, mode, rp->nr, dot);
+    const Sel s = select(rp->k, mode, rp->nr, variant);
     MFX_HIP(hipMemsetAsync(rp->d_ctl, 0, sizeof(unsigned), stream()));                          // ticket
     MFX_HIP(hipMemsetAsync(rp->d_ctl + kCtlReg, 0, sizeof(unsigned), stream()));                // registration
     hipLaunchKernelGGL(k_hdr_reset, dim3(ceil_div(rp->n_trav, 256)), dim3(256), 0, stream(), rp->d_hdr, (const double *)tb, rp->n_trav);

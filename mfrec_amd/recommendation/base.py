@@ -244,12 +244,18 @@ class BaseRecommender(object):
         The factor arrays themselves are read WITHOUT pickle."""
         import scipy.io
         z = np.load(filename + "_svd.npz", allow_pickle=False)
-        self.svd_u, self.svd_v = z["svd_u"], z["svd_v"]          # plain f64 arrays: no pickle involved
-        try:
-            s = z["svd_s"]
-        except ValueError:                                       # an object array (None for the SGD / ALS families)
-            s = np.load(filename + "_svd.npz", allow_pickle=True)["svd_s"]
-        self.svd_s = s.item() if (s.dtype == object and s.shape == ()) else s
+
+        def member(key):
+            # trained factors are plain f64 arrays: no pickle involved.  A member that np.savez stored as an object array -- svd_s
+            # of the SGD / ALS families, and svd_u / svd_v of a recommender saved BEFORE training (None) -- is re-read with
+            # allow_pickle for THAT member only, as the reference's own np.load does, and a 0-d object array comes back as its item
+            try:
+                a = z[key]
+            except ValueError:
+                a = np.load(filename + "_svd.npz", allow_pickle=True)[key]
+            return a.item() if (a.dtype == object and a.shape == ()) else a
+
+        self.svd_u, self.svd_v, self.svd_s = member("svd_u"), member("svd_v"), member("svd_s")
         self.relationship_matrix = lil_matrix(scipy.io.mmread(filename + "_relations.mtx"))
         self._nbr_users, self._nbr_items = self.relationship_matrix.shape
         for suffix, attr in self._STATE_DICTS:

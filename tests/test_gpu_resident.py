@@ -219,8 +219,49 @@ def test_butterfly_dot_on_the_resident_side_epoch(epoch, order, k, mode):
             np.testing.assert_allclose(a, b, rtol=0, atol=1e-11)
 
 
+@pytest.mark.parametrize("epoch,order", [("static", "shuffled"), ("ticket", "user-major")])
+@pytest.mark.parametrize("k", [24, 64, 100, 128])
+@pytest.mark.parametrize("mode", [LINEAR, LOGISTIC])
+def test_f32_row_storage_on_the_resident_side_epoch(epoch, order, k, mode):
+    """SgdPlan(storage="f32") -- "f32 storage, f64 arithmetic": rows widened on load, rounded once per update -- inside k1_res: the
+    travelling rows move 8 bytes per lane instead of 16, the resident row in registers is rounded to f32 after every update (what a
+    reload would return).  The ordered sum and every other operation are the exact mode's, so the result is the level kernels' f32
+    mode bit for bit (linear), whatever their lane layout; NOT the reference's precision (its RMSE budget: tests/test_gpu_parity.py)."""
+    nu, ni, nnz, E = 700, 300, 30000, 3
+    idx, r = synth.make_ratings(nu, ni, nnz, seed=6)
+    if order == "user-major":
+        idx, r = synth.user_major(idx, r)
+    u0, v0 = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
+    rs = np.random.RandomState(3)
+    ib0, ub0 = rs.normal(0, 0.05, ni), rs.normal(0, 0.05, nu)
+
+    def run(e):
+        u, v, ib, ub = u0.copy(), v0.copy(), ib0.copy(), ub0.copy()
+        with SgdPlan(idx, r, nu, ni, k, storage="f32", epoch=e) as p:
+            name, kern = p.kernel_name(mode), p.info()["epoch_kernel"]
+            p.set_factors(u, v, ib, ub)
+            rm = p.run_kmf(mode, E, LR, KU, KI, KB)
+            p.get_factors(u, v, ib, ub)
+        return (u, v, ib, ub, rm), name, kern
+
+    got, name, kern = run(epoch)
+    assert kern == epoch and name.startswith("k1_res<") and "f32 rows" in name, name
+    lev, lname, _ = run("levels")
+    assert lname.startswith("k1_level<") and "f32" in lname
+    if mode == LINEAR:
+        for a, b in zip(got[:4], lev[:4]):
+            assert np.array_equal(a, b)
+        np.testing.assert_allclose(got[4], lev[4], rtol=1e-12)
+    else:
+        for a, b in zip(got[:4], lev[:4]):
+            np.testing.assert_allclose(a, b, rtol=0, atol=1e-6)      # (f32 rounding amplifies the 1-ulp difference of the device exp)
+    want = _oracle(idx, r, nu, ni, k, u0, v0, E, mode, ib0, ub0)
+    assert not np.array_equal(got[0], want[0])                       # it is NOT the exact mode ...
+    np.testing.assert_allclose(got[0], want[0], rtol=0, atol=1e-5)   # ... but close to it
+
+
 def test_gated_and_narrow_runs_take_the_level_schedule():
-    """update_users/items gates and f32 storage are served by the level kernels of the same plan."""
+    """update_users/items gates (and bf16 storage) are served by the level kernels of the same plan."""
     nu, ni, nnz, k = 300, 500, 20000, 64
     idx, r = synth.user_major(*synth.make_ratings(nu, ni, nnz, seed=8))
     u0, v0 = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)

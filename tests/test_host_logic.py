@@ -128,6 +128,22 @@ def test_save_state_load_state_file_set(tmp_path):
     assert Q.svd_s.tolist() == [2.0, 1.0] and Q.users_label == ["ann"]
 
 
+def test_save_then_load_state_of_an_untrained_recommender(tmp_path):
+    """A state saved BEFORE training holds svd_u = svd_v = None, which np.savez stores as 0-d object arrays; the reference's
+    np.load round-trips them (base.py:578-596) and so must load_state."""
+    from mfrec_amd.recommendation.base import BaseRecommender
+    R = BaseRecommender(4, 3)
+    R.set_ratings(np.array([[0, 1], [3, 2]]), [2.0, 4.0])
+    assert R.svd_u is None and R.svd_v is None
+    base = str(tmp_path / "untrained")
+    R.save_state(base)
+    Q = BaseRecommender(1, 1)
+    Q.svd_u = Q.svd_v = np.zeros((2, 2))
+    Q.load_state(base)
+    assert Q.svd_u is None and Q.svd_v is None and Q.svd_s is None and (Q.nbr_users, Q.nbr_items) == (4, 3)
+    assert (Q.relationship_matrix != R.relationship_matrix).nnz == 0
+
+
 def test_balanced_order_falls_back_when_a_builder_refuses(monkeypatch):
     """get_ratings('balanced') promises GPU builder -> host builder -> plain shuffle; a builder's refusal
     arrives as MfxError (MFX_E_STATE) or MemoryError (MFX_E_NOMEM) after _shim.check()."""

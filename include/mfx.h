@@ -86,8 +86,9 @@ int mfx_schedule_pack(const int32_t *ratings_index, const double *ratings, const
 
 /* An input ORDER with close to the minimum number of dependency levels (first-fit edge colouring
  * over a seeded random visiting order; round-major).  The reference shuffles the ratings with an
- * unseeded RNG before every train() (base.py:1127-1129), so any permutation is a legitimate order;
- * this one roughly halves the level count of an i.i.d. shuffle.  perm_out[j] = index of the j-th
+ * unseeded RNG before every train() (base.py:1127-1129), i.e. leaves the order open; this structured one
+ * roughly halves the level count of an i.i.d. shuffle, and the result is exact ON it.  (Model quality on such
+ * orders against uniform draws: measured in profiles/r04_block_order_quality.json, not assumed.)  perm_out[j] = index of the j-th
  * rating of the new order.  Host code. */
 int mfx_schedule_balanced_order(const int32_t *ratings_index, int64_t nnz, int nu, int ni,
                                 uint64_t seed, int64_t *perm_out, int64_t *n_rounds_out);
@@ -360,7 +361,8 @@ int mfx_als_wrmf_sharded(int nbr_epochs, int dim, double *u, double *v,
  * MFX_DSGD_BALANCED the block's own minimum-level order (first-fit recolouring, as
  * mfx_schedule_balanced_order_gpu); mfx_dsgd_get_order returns the whole order.  The reference's only
  * multi-machine precedent is the averaging prototype gradient_descent.py:124-211; its rating order is an
- * unseeded shuffle (base.py:1127-1129), so any order is a legitimate one.
+ * unseeded shuffle (base.py:1127-1129): the order is open, and the result is exact ON the order this object reports
+ * (its training quality against uniform shuffles: profiles/r04_block_order_quality.json).
  * ratings_index holds GLOBAL ids; a rank keeps the ratings of its own user block (so passing all ratings
  * or only the rank's own is the same).  rank = -1: all `world` ranks live in this process on this GPU
  * (hand-off = device copy), for tests and rehearsals.  mfx_comm_init first when world > 1 and rank >= 0.

@@ -13,8 +13,9 @@
 // reference's sequential loop (kmf_train.pyx:243-270) run on the rating order
 //     for h in 0..B-1: for g in 0..G-1: ratings of block (g, (stride * g + h) mod B), in block order
 // where "block order" is the given order, or (MFX_DSGD_BALANCED) the block's first-fit recolouring with
-// the fewest dependency levels -- as legitimate an order as the reference's unseeded shuffle
-// (base.py:1127-1129).  mfx_dsgd_get_order returns that order for the tests to feed the oracle with.
+// the fewest dependency levels -- the reference draws its order from an unseeded RNG (base.py:1127-1129), i.e. leaves it open;
+// how this structured order trains against uniform draws is measured in profiles/r04_block_order_quality.json.
+// mfx_dsgd_get_order returns that order for the tests to feed the oracle with.
 //
 // One DSGD rank = B sub-plans (one per item block) that share the rank's user rows.  rank = -1 keeps
 // all G ranks in this process on this GPU ("fake world": the hand-off is a device copy on the second

@@ -434,9 +434,13 @@ def main():
          out_b_y=ya, out_b_rmse_hist=hist_b[:nb])
 
     # ---------------- G12: top-N ranking (mf.py:144-193, gradient_descent.py:768-800) ----------------
-    # PARITY UNPINNED for this fixture: the reference's Python-2 harness cannot be imported, so
-    # the expected lists come from the cited restatement in oracle/oracle.py, not from the reference itself.
+    # The reference's Python-2 harness cannot be imported as a package, so the expected lists are written from the
+    # cited restatement in oracle/oracle.py -- and then PINNED (round 4): oracle/pin_topn.py cuts the reference's own definitions
+    # of these functions out of its files, translates them with lib2to3, executes them on the fixture's inputs and refuses any
+    # difference (record: tests/golden/g12_topn_pin.json, bound to the golden file by its SHA-256).
     topn_fixture(save)
+    import pin_topn
+    pin_topn.main()
 
     for name, size in written:
         print("%-18s %8d B" % (name, size))

@@ -1,7 +1,8 @@
 """GPU: batched top-N (mfx_topn_batch, mfx_topn_plan_query) against tests/golden/g12_topn.npz -- the lists the cited
 restatement of the reference's ranking rules gives (oracle/oracle.py: find_recommended_items, mf.py:144-193 /
-gradient_descent.py:768-800).  PARITY UNPINNED for this half: the reference's Python-2 harness cannot be run, the
-fixture comes from the restatement (oracle/make_golden.py topn_fixture).
+gradient_descent.py:768-800).  The fixture is written from the restatement (oracle/make_golden.py topn_fixture) and, since round 4,
+PINNED: oracle/pin_topn.py executes the reference's own definitions of these functions (cut from its files, translated by lib2to3)
+on the fixture's inputs and refuses any difference (tests/golden/g12_topn_pin.json; tests/test_oracle_golden.py checks the record).
 
 Items must match exactly (the fixture keeps neighbouring scores either exactly tied or 1e-9 apart); scores to 1e-12
 relative (the reference sums the dot with np.dot, whose association is BLAS's; the kernel sums left to right)."""

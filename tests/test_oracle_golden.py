@@ -176,7 +176,7 @@ def test_g11_implicit_feedback(golden):
 
 def test_topn_restatement_rules_and_fixture(golden):
     """The ranking rules of mf.py:144-193 restated in oracle/oracle.py: a hand-checkable case, then the committed
-    fixture (generated from this restatement; parity unpinned -- the Python-2 harness cannot be run here)."""
+    fixture (written from this restatement and PINNED against the reference's own source: next test)."""
     from oracle import oracle as O
     u = np.array([[1.0, 2.0, 2.0, 0.0, 5.0, np.nan, 3.0]])           # k = 1, 7 items
     v = np.array([[1.0, 1.0]])
@@ -199,3 +199,22 @@ def test_topn_restatement_rules_and_fixture(golden):
                     it, sc = O.find_recommended_items(kind, um, vm, int(usr), rated, int(n_cand), int(N), ib, ub, float(g["p_%s_mu" % tag]))
                     assert it == [int(x) for x in want_i[j] if x >= 0]
                     assert np.array_equal(np.array(sc), want_s[j, :len(sc)])
+
+
+def test_topn_golden_is_pinned_by_the_reference_source():
+    """tests/golden/g12_topn.npz was compared -- in the build container, by oracle/pin_topn.py -- with the reference's OWN definitions
+    of find_recommended_items / find_user_top_match / the five predict functions / precision_recall (cut from its files, translated by
+    lib2to3, executed): the record names the definitions and is bound to the committed golden file by its SHA-256, so a regenerated
+    fixture that was not pinned again fails here."""
+    import hashlib
+    import json
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    rec = json.load(open(os.path.join(gold, "g12_topn_pin.json")))
+    assert rec["golden_sha256"] == hashlib.sha256(open(os.path.join(gold, "g12_topn.npz"), "rb").read()).hexdigest()
+    assert rec["queries_compared"] == 2 * 5 * 3 * 9 and rec["precision_recall_runs_compared"] == 2
+    defs = {(d["file"].split("/")[-1], d["definition"]) for d in rec["definitions"]}
+    for want in (("mf.py", "def find_recommended_items"), ("gradient_descent.py", "def find_user_top_match"),
+                 ("metrics.py", "def precision_recall"), ("kmf.py", "def predict_logistic"), ("wrmf.py", "def predict")):
+        assert want in defs
+    assert "lib2to3" in rec["pinned_by"]

@@ -441,6 +441,7 @@ def main():
     topn_fixture(save)
     import pin_topn
     pin_topn.main()
+    pin_topn.pin_snapshots()
 
     for name, size in written:
         print("%-18s %8d B" % (name, size))

@@ -144,6 +144,40 @@ def test_save_then_load_state_of_an_untrained_recommender(tmp_path):
     assert (Q.relationship_matrix != R.relationship_matrix).nnz == 0
 
 
+def test_files_written_by_the_reference_own_statements_load(tmp_path):
+    """tests/golden/refwritten_* were written, in the build container, by the reference's OWN statements (base.py:805-806
+    save_model_snapshot; base.py:559-560, the mmwrite + np.savez statements of save_state), cut from the file and executed by
+    oracle/pin_topn.py (record: tests/golden/snapshot_pin.json).  mfrec_amd must read them: keys, shapes, values, the None that
+    np.savez stores for svd_s.  (The five label / index pickles of a state are Python-2 text pickles the reference code cannot write
+    under Python 3: hand-made here in that format.)"""
+    import json
+    import os
+    import pickle
+    import shutil
+    from mfrec_amd.recommendation.base import BaseRecommender
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    rec = json.load(open(os.path.join(gold, "snapshot_pin.json")))
+    assert "refwritten_model_snapshot.npz" in rec["fixtures_written_by_the_reference_statements"]
+    rs = np.random.RandomState(5)
+    u, v = rs.normal(0, 0.1, (3, 6)), rs.normal(0, 0.1, (3, 4))
+    Q = BaseRecommender(1, 1)
+    Q.load_model_snapshot(os.path.join(gold, "refwritten"))
+    assert np.array_equal(Q.svd_u, u) and np.array_equal(Q.svd_v, v)
+    base = str(tmp_path / "s")
+    shutil.copy(os.path.join(gold, "refwritten_state_relations.mtx"), base + "_relations.mtx")
+    shutil.copy(os.path.join(gold, "refwritten_state_svd.npz"), base + "_svd.npz")
+    for suffix, obj in (("_userslabel.dat", ["u0", "u1", "u2", "u3"]), ("_usersindex.dat", {"u0": 0}), ("_itemslabel.dat", []),
+                        ("_itemsindex.dat", {}), ("_itemsindexmap.dat", {})):
+        with open(base + suffix, "w") as f:
+            f.write(pickle.dumps(obj, protocol=0).decode("latin1"))
+    P = BaseRecommender(1, 1)
+    P.load_state(base)
+    assert (P.nbr_users, P.nbr_items) == (4, 6) and P.svd_s is None
+    assert np.array_equal(P.svd_u, u) and np.array_equal(P.svd_v, v)
+    assert P.relationship_matrix[3, 5] == 5.0 and P.relationship_matrix[2, 0] == 4.0 and P.relationship_matrix.nnz == 4
+    assert P.users_label == ["u0", "u1", "u2", "u3"]
+
+
 def test_balanced_order_falls_back_when_a_builder_refuses(monkeypatch):
     """get_ratings('balanced') promises GPU builder -> host builder -> plain shuffle; a builder's refusal
     arrives as MfxError (MFX_E_STATE) or MemoryError (MFX_E_NOMEM) after _shim.check()."""

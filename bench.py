@@ -410,7 +410,7 @@ def also_funk(idx, r, nu, ni, k, order, epochs_per_feature=2):
     persistent = kname.startswith("k2_xcd_pass") or kname.startswith("k2_res")
     launches = 1 if persistent else info["funk_launches_per_epoch"]
     ms_pass = tm.ms / n
-    how = ("one persistent launch per pass, lane = item, V[f,user] travels through per-rating mailboxes" if kname.startswith("k2_res_box")
+    how = ("one persistent launch per pass, lane = item, V[f,user] travels through per-rating mailboxes" if (kname.startswith("k2_res") and "mailbox" in kname)
            else "one persistent launch per pass, lane = item, V[f,user] travels inside 16-byte granules" if kname.startswith("k2_res")
            else "one persistent single-XCD launch per pass" if kname.startswith("k2_xcd_pass") else "one launch per dependency level")
     # algorithmic bytes: 24 B per scalar update (16-B record + 8-B cache word)

@@ -254,22 +254,25 @@ void mfx_sgd_plan_destroy(mfx_sgd_plan *p);
  * [4]=ratings per wave batch, [5]=device bytes held, [6]=schedule build microseconds,
  * [7]=launches per epoch (Funk) */
 int mfx_sgd_plan_info(const mfx_sgd_plan *p, int64_t info[8]);
-/* Name of the k1_level instantiation this plan launches for `mode` (0 linear, 1 logistic, 2 learned
- * bias): "k1_level<lanes per rating,features per lane,ratings per wave,access form,mode>"; mode 3: the
- * kernel of the Funk pass ("k2_xcd_pass<...>", the single-XCD persistent pass chosen for large levels,
- * or "k2_level<...>", one launch per level). */
+/* Name of the kernel this plan launches for `mode` (0 linear, 1 logistic, 2 learned bias): the resident-side epoch
+ * "k1_res<lanes per row,slots per wave,mode[,butterfly-dot+fma | ,f32 rows],binding: resident side,waves>" or
+ * "k1_level<lanes per rating,features per lane,ratings per wave,access form,mode>"; mode 3: the kernel of the Funk pass
+ * ("k2_res<...>": the persistent lane-per-item pass, mailbox or granule form; "k2_xcd_pass<...>": the single-XCD persistent
+ * pass; "k2_level<...>": one launch per level). */
 int mfx_sgd_plan_kernel_name(const mfx_sgd_plan *p, int mode, char *buf, int buflen);
 /* Storage type of the factor rows inside the plan: 64 (default; exact), 32 or 16 (bf16) -- "narrow
  * storage, f64 arithmetic" modes of the full-k kernels: rows are widened on load and rounded once on
  * store.  NOT bit-exact (measured RMSE deltas: DESIGN.md -- f32 stays within the 1e-5 budget, bf16 does
- * not); single-GPU; call before set_factors.  bf16: k a multiple of 8, k >= 16, linear / logistic. */
+ * not); single-GPU; call before set_factors.  bf16: k a multiple of 8, k >= 16, linear / logistic.
+ * f32 rows are served by the resident-side epoch too (same bits as on the level kernels), bf16 by the level kernels. */
 int mfx_sgd_plan_set_storage(mfx_sgd_plan *p, int bits);
 /* How the full-k kernels (linear / logistic) form the k-term dot product ib + ub + sum_f U[f,i] V[f,u]:
  * MFX_DOT_ORDERED (default): summed strictly left to right by one lane, no FMA -- the reference's
  * operation order (kmf_train.pyx:75-97), bit-identical results.  MFX_DOT_BUTTERFLY: per-lane partial
  * products and a wave butterfly (DPP + cross-row swaps) with a FIXED association, FMA in dot and row
  * update -- deterministic, f64, but NOT bit-identical to the reference (tolerance mode: final RMSE
- * within 1e-5, measured in DESIGN.md).  f64 rows, even k > 4. */
+ * within 1e-5, measured in DESIGN.md).  f64 rows, even k > 4.  Served by the resident-side epoch and by the level kernels
+ * with the SAME association: the same bits whichever kernel runs the plan. */
 enum { MFX_DOT_ORDERED = 0, MFX_DOT_BUTTERFLY = 1 };
 int mfx_sgd_plan_set_dot(mfx_sgd_plan *p, int dot);
 int mfx_sgd_set_factors(mfx_sgd_plan *p, const double *u, const double *v,

@@ -871,7 +871,7 @@ int mfx_sgd_plan_info(const mfx_sgd_plan *p, int64_t info[8])
 int mfx_sgd_plan_res_info(const mfx_sgd_plan *p, int64_t info[4])
 {
     if (!p || !info) return MFX_E_ARG;
-    const bool on = res_on(p);                                             // (narrow storage: level kernels)
+    const bool on = res_on(p);                                             // (bf16 rows: level kernels)
     info[0] = on ? res_kind(p->res) + 1 : MFX_EPOCH_LEVELS;          // (kind 1 = ticket, 2 = static)
     info[1] = p->res ? res_kind(p->res) + 1 : MFX_EPOCH_LEVELS;      // prepared (switched off by a failed registration?)
     info[2] = p->res ? (int64_t)res_dev_bytes(p->res) : 0;

@@ -240,27 +240,27 @@ __device__ __forceinline__ double readlane64(double x, int l)          // l wave
     return __hiloint2double(hi, lo);
 }
 
-// ---- tolerance mode (DOT): the k-term dot as north_star words it -- per-lane partial products (FMA), then a wave butterfly over
-// the KP lanes of a slot (quad swaps, half-row and row mirrors on DPP, then the cross-row swaps) -- and FMA in the row updates.
-// The SAME association and the same operations as the level kernels' DOT mode (mfx_sgd_kernels.h group_sum / k1_body<DOT = 1>), so a
-// plan gives the same bits whichever kernel serves it; NOT the reference's left-to-right sum (kmf_train.pyx:75-97).
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64r(double x)
-{
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
+// ---- tolerance mode (DOT): the k-term dot as north_star words it -- per-lane partial products (FMA), reduced over the KP lanes of a
+// slot with the association of the level kernels' wave butterfly (mfx_sgd_kernels.h group_sum / k1_body<DOT = 1>), and FMA in the row
+// updates: a plan gives the same bits whichever kernel serves it; NOT the reference's left-to-right sum (kmf_train.pyx:75-97).
+// Tolerance mode: the KP per-lane partials of one rating, from its row of the LDS tile, added as the BALANCED pairwise tree in index
+// order -- ((p0 + p1) + (p2 + p3)) + ... -- by ONE lane.  Floating-point addition is commutative, so this tree gives the very bits of
+// the wave butterfly of the level kernels' tolerance mode (group_sum: quad swaps, half-row / row mirrors, cross-row swaps -- every
+// stage adds a lane's value and its partner's), at a fraction of its cost here: the butterflies of a step's register sets run one
+// after the other behind the uniform skips (0.76 us per step, tools/res_stamps.py), this tree sums all slots of the wave at once.
 template <int KP>
-__device__ __forceinline__ double group_sum_r(double x, int lane)
+__device__ __forceinline__ double tree_sum(const double *row)
 {
-    if constexpr (KP >= 2) x = x + dpp_f64r<0xB1>(x);     // quad_perm [1,0,3,2]
-    if constexpr (KP >= 4) x = x + dpp_f64r<0x4E>(x);     // quad_perm [2,3,0,1]
-    if constexpr (KP >= 8) x = x + dpp_f64r<0x141>(x);    // row_half_mirror
-    if constexpr (KP >= 16) x = x + dpp_f64r<0x140>(x);   // row_mirror
-    if constexpr (KP >= 32) x = x + shfl64(x, lane ^ 16);
-    if constexpr (KP >= 64) x = x + shfl64(x, lane ^ 32);
-    return x;
+    double c[KP / 8];
+#pragma unroll
+    for (int i = 0; i < KP / 8; ++i) {
+        const d2 a = *reinterpret_cast<const d2 *>(row + 8 * i), b = *reinterpret_cast<const d2 *>(row + 8 * i + 2);
+        const d2 e = *reinterpret_cast<const d2 *>(row + 8 * i + 4), f = *reinterpret_cast<const d2 *>(row + 8 * i + 6);
+        c[i] = ((a.x + a.y) + (b.x + b.y)) + ((e.x + e.y) + (f.x + f.y));
+    }
+    if constexpr (KP == 16) return c[0] + c[1];
+    else if constexpr (KP == 32) return (c[0] + c[1]) + (c[2] + c[3]);
+    else return ((c[0] + c[1]) + (c[2] + c[3])) + ((c[4] + c[5]) + (c[6] + c[7]));
 }
 
 // One step of a wave: the slots in `mask` apply their head rating.  FULL: every slot (no branches around
@@ -304,27 +304,18 @@ __device__ __forceinline__ void res_apply(const ResParams &P, unsigned long long
     bool rdy[NR];
 #pragma unroll
     for (int j = LO; j < HI; ++j) rdy[j] = fl && (FULL || ((mask >> (j * SPW + g)) & 1ull));
-    double dotv = 0.0;
     if constexpr (DOT) {
-        // per-lane partials (features ascending, FMA) + butterfly over the slot's lanes; lane n (< B) owns slot n = j * SPW + g':
-        // its dot sits in every lane of half-group g' of register set j (lanes that hold no row to apply contribute 0).
-        // Set by set behind the uniform skips: a step moves ~4 of 18 slots.  (Measured against a stage-major form over ALL sets, whose
-        // independent adds cover each other's latency: 3.23 against 3.66 G/s on cfg 2 shuffled -- nine butterflies cost more issue
-        // slots than the three or four a step needs cost latency; profiles/r04_k1_res_stamps.txt.)
+        // per-lane partials (features ascending, FMA) of every moving slot into the first KP entries of its tile row (a lane that holds
+        // no feature pair of the row writes its 0), then ONE lane per slot adds them as the balanced pairwise tree (tree_sum)
 #pragma unroll
         for (int j = LO; j < HI; ++j) {
             if (!(FULL || ((unsigned)(mask >> (j * SPW)) & SETM))) continue;                 // uniform
-            double a = __builtin_fma(uu[j].x, vv[j].x, 0.0);
-            a = __builtin_fma(uu[j].y, vv[j].y, a);
-            a = group_sum_r<KP>(rdy[j] ? a : 0.0, lane);
-            double t = readlane64(a, 0);
-#pragma unroll
-            for (int x = 1; x < SPW; ++x) {
-                const double tx = readlane64(a, x * KP);
-                t = (lane % SPW) == x ? tx : t;
-            }
-            if (lane / SPW == j) dotv = t;
+            const double a = __builtin_fma(uu[j].y, vv[j].y, __builtin_fma(uu[j].x, vv[j].x, 0.0));
+            if (FULL || ((mask >> (j * SPW + g)) & 1ull)) prod[(j * SPW + g) * stride + q] = a;
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         RS(7);
     } else {
 #pragma unroll
@@ -339,7 +330,7 @@ __device__ __forceinline__ void res_apply(const ResParams &P, unsigned long long
     if (FULL ? (lane < B) : ready) {
         // kmf_train.pyx:92: 0 + item bias + user bias, then the products left to right
         double sum = P.res_item ? (0.0 + rbv + tbv) : (0.0 + tbv + rbv);
-        if constexpr (DOT) sum += dotv;
+        if constexpr (DOT) sum += tree_sum<KP>(prod + lane * stride);
         else sum = ordered_sum(sum, prod + lane * stride, k);
         double err;
         if constexpr (MODE == 0) {
@@ -355,7 +346,7 @@ __device__ __forceinline__ void res_apply(const ResParams &P, unsigned long long
         rbv = rbv + P.lr * (grad - P.Kb * rbv);              // :259-260 (both gates on in this path)
         tbn = tbv + P.lr * (grad - P.Kb * tbv);
     }
-    if constexpr (!DOT) __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_wave_barrier();
     RS(8);                                                   // 8: ordered sums, errors, bias updates
 #pragma unroll
     for (int j = LO; j < HI; ++j) {

@@ -91,7 +91,7 @@ if st:
                 "# 1 = after the s_waitcnt fix, with the look-ahead variant (since archived); 2 = + readlane broadcasts and the pipelined ordered sum;\n"
                 "# 3 = finer stamps inside the compute phase; 4 = + uniform set skips and s_setprio (dropped); 5 = exact vs butterfly-dot, set-major;\n"
                 "# 6 = butterfly-dot stage-major over all sets (dropped); 7 = the final kernel on the balanced (stream-bound: 6.3 us steps, 8.8 ratings each) and the\n"
-                "# user-major order (chain-bound: 1 266 steps of 3.5 us)).  With the stamps an epoch takes ~2.9-3.0 ms instead of 2.7.\n")
+                "# user-major order (chain-bound: 1 266 steps of 3.5 us); 8 = the tolerance mode with the LDS tree sum (kept)).  With the stamps an epoch takes ~2.9-3.0 ms instead of 2.7.\n")
         for f in st:
             o.write("\n## %s\n" % os.path.basename(f)); o.write(open(f).read())
     print("   r04_k1_res_stamps.txt (%d runs)" % len(st))

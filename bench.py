@@ -634,10 +634,29 @@ def self_launch(n):
     env0 = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                 TORCHELASTIC_RUN_ID="selflaunch%d" % os.getpid(), TORCHELASTIC_RESTART_COUNT="0")
     kids = []
+
+    def die_with_parent():
+        # (child side, before exec'ing python: if the launcher is killed -- a driver's timeout --, the ranks get SIGTERM instead of
+        #  living on as orphans that hold the GPUs)
+        try:
+            import ctypes
+            import signal
+            ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGTERM)        # PR_SET_PDEATHSIG
+        except Exception:
+            pass
+
     for rk in range(n):
         env = dict(env0, RANK=str(rk), LOCAL_RANK=str(rk))
         kids.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                     stdout=None if rk == 0 else sys.stderr))
+                                     stdout=None if rk == 0 else sys.stderr, preexec_fn=die_with_parent))
+
+    def forward(signum, frame):                      # SIGTERM / SIGINT to the launcher ends the ranks too
+        for p in kids:
+            if p.poll() is None:
+                p.terminate()
+    import signal
+    signal.signal(signal.SIGTERM, forward)
+    signal.signal(signal.SIGINT, forward)
     grace = float(os.environ.get("MFX_BENCH_LAUNCH_GRACE", "60"))
     failed_at = None
     while True:

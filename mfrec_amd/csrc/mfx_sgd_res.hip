@@ -265,50 +265,41 @@ __device__ __forceinline__ double tree_sum(const double *row)
 
 // One step of a wave: the slots in `mask` apply their head rating.  FULL: every slot (no branches around
 // memory operations: one basic block of loads, one of stores).  Lane s < B owns slot s's scalar state.
-// ... in two halves over the register sets [LO, HI): res_load requests the travelling rows of the slots in `mask`, res_apply --
-// once they have returned -- does everything else.  (k1_res calls them back to back over all sets; a pipelined epoch that requested
-// one half of the sets' rows while it applied the other half was measured and dropped: profiles/experiments/r04_k1_res_pipe.hip.txt.)
-template <int KP, int NR, bool FULL, typename TS, int LO, int HI>
-__device__ __forceinline__ void res_load(const ResParams &P, unsigned long long mask, const URec &rec, d2 (&uu)[NR],
-                                         __amdgpu_buffer_rsrc_t rT, int g, int q)
+// (Round 4 also split this step into a load half and an apply half for a pipelined epoch that took turns over two groups of
+//  register sets -- measured slower on every order and dropped: profiles/experiments/r04_k1_res_pipe.hip.txt; the split itself cost
+//  1.5 % through register allocation, so the step is one function again.)
+template <int KP, int NR, int MODE, bool FULL, bool DOT, typename TS>
+__device__ __forceinline__ void res_step(const ResParams &P, unsigned long long mask, bool ready, const URec &rec, double tbv,
+                                         double &rbv, double &se, d2 (&vv)[NR], double *prod, __amdgpu_buffer_rsrc_t rT,
+                                         int lane, int g, int q, double &tbn RS_PARAM)
 {
-    constexpr int SPW = 64 / KP;
+    constexpr int SPW = 64 / KP, B = NR * SPW;
+    constexpr int stride = 2 * KP + 2;                       // rows 16-B aligned, stride / 2 odd (k1_stride at k = 2 KP)
     const int k = P.k;
     const bool fl = 2 * q < k;                               // this lane holds a feature pair
+    bool rdy[NR];
+    d2 uu[NR];
     const unsigned qoff = (unsigned)q * RowIO<TS>::lane_bytes, rowb = (unsigned)(k * (int)sizeof(TS));
     constexpr unsigned SETM = (1u << SPW) - 1u;
 #pragma unroll
-    for (int j = LO; j < HI; ++j) {
+    for (int j = 0; j < NR; ++j) {
         const int src = j * SPW + g;
-        const bool rdyj = fl && (FULL || ((mask >> src) & 1ull));
+        rdy[j] = fl && (FULL || ((mask >> src) & 1ull));
         uu[j] = d2{0.0, 0.0};
         // a set none of whose slots moves is skipped as a whole -- a UNIFORM branch (the ballot is a scalar): no broadcast, no
         // address, no memory instruction for it.  (The cross-lane reads are v_readlane: they do not depend on EXEC.)
         if (FULL || ((unsigned)(mask >> (j * SPW)) & SETM)) {
             const unsigned o = (unsigned)set_bcast_i<SPW>(rec.trav, j * SPW, g) * rowb + qoff;
-            if (rdyj) uu[j] = RowIO<TS>::ld(rT, o);
+            if (rdy[j]) uu[j] = RowIO<TS>::ld(rT, o);
         }
     }
-}
-template <int KP, int NR, int MODE, bool FULL, bool DOT, typename TS, int LO, int HI>
-__device__ __forceinline__ void res_apply(const ResParams &P, unsigned long long mask, bool ready, const URec &rec, double tbv,
-                                          double &rbv, double &se, d2 (&vv)[NR], d2 (&uu)[NR], double *prod,
-                                          __amdgpu_buffer_rsrc_t rT, int lane, int g, int q, double &tbn RS_PARAM)
-{
-    constexpr int SPW = 64 / KP, B = NR * SPW;
-    constexpr int stride = 2 * KP + 2;                       // rows 16-B aligned, stride / 2 odd (k1_stride at k = 2 KP)
-    const int k = P.k;
-    const bool fl = 2 * q < k;
-    const unsigned qoff = (unsigned)q * RowIO<TS>::lane_bytes, rowb = (unsigned)(k * (int)sizeof(TS));
-    constexpr unsigned SETM = (1u << SPW) - 1u;
-    bool rdy[NR];
-#pragma unroll
-    for (int j = LO; j < HI; ++j) rdy[j] = fl && (FULL || ((mask >> (j * SPW + g)) & 1ull));
+    wait_vm0();
+    RS(2);
     if constexpr (DOT) {
         // per-lane partials (features ascending, FMA) of every moving slot into the first KP entries of its tile row (a lane that holds
         // no feature pair of the row writes its 0), then ONE lane per slot adds them as the balanced pairwise tree (tree_sum)
 #pragma unroll
-        for (int j = LO; j < HI; ++j) {
+        for (int j = 0; j < NR; ++j) {
             if (!(FULL || ((unsigned)(mask >> (j * SPW)) & SETM))) continue;                 // uniform
             const double a = __builtin_fma(uu[j].y, vv[j].y, __builtin_fma(uu[j].x, vv[j].x, 0.0));
             if (FULL || ((mask >> (j * SPW + g)) & 1ull)) prod[(j * SPW + g) * stride + q] = a;
@@ -319,7 +310,7 @@ __device__ __forceinline__ void res_apply(const ResParams &P, unsigned long long
         RS(7);
     } else {
 #pragma unroll
-        for (int j = LO; j < HI; ++j)
+        for (int j = 0; j < NR; ++j)
             if (rdy[j]) *reinterpret_cast<d2 *>(prod + (j * SPW + g) * stride + 2 * q) = d2{uu[j].x * vv[j].x, uu[j].y * vv[j].y};
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -349,7 +340,7 @@ __device__ __forceinline__ void res_apply(const ResParams &P, unsigned long long
     __builtin_amdgcn_wave_barrier();
     RS(8);                                                   // 8: ordered sums, errors, bias updates
 #pragma unroll
-    for (int j = LO; j < HI; ++j) {
+    for (int j = 0; j < NR; ++j) {
         if (!(FULL || ((unsigned)(mask >> (j * SPW)) & SETM))) continue;                     // uniform
         const double gr = set_bcast_d<SPW>(grad, j * SPW, g);
         const unsigned o = (unsigned)set_bcast_i<SPW>(rec.trav, j * SPW, g) * rowb + qoff;   // formed again rather than kept: a register per slot pair less
@@ -371,17 +362,6 @@ __device__ __forceinline__ void res_apply(const ResParams &P, unsigned long long
             vv[j] = RowIO<TS>::round(vn);
         }
     }
-}
-template <int KP, int NR, int MODE, bool FULL, bool DOT, typename TS>
-__device__ __forceinline__ void res_step(const ResParams &P, unsigned long long mask, bool ready, const URec &rec, double tbv,
-                                         double &rbv, double &se, d2 (&vv)[NR], double *prod, __amdgpu_buffer_rsrc_t rT,
-                                         int lane, int g, int q, double &tbn RS_PARAM)
-{
-    d2 uu[NR];
-    res_load<KP, NR, FULL, TS, 0, NR>(P, mask, rec, uu, rT, g, q);
-    wait_vm0();
-    RS(2);
-    res_apply<KP, NR, MODE, FULL, DOT, TS, 0, NR>(P, mask, ready, rec, tbv, rbv, se, vv, uu, prod, rT, lane, g, q, tbn RS_ARG);
 }
 
 // BURST (static binding, skewed data): a resident entity with a long run ahead -- the hot item of a power-law catalogue:

@@ -45,37 +45,33 @@ def cfg3_data():
     return nu, ni, nnz, idx, r
 
 
-def test_cfg3_whole_one_epoch_bitexact_vs_oracle(cfg3_data):
+@pytest.fixture(scope="module")
+def cfg3_runs(cfg3_data):
+    """cfg 3 whole, ONE epoch, on the three schedules the library has for it -- the given (shuffled) order on the level schedule, the
+    user-major order on the ticket epoch, the one-GPU block order on the static epoch -- each on the GPU, and the oracle's sequential
+    loop (kmf_train.pyx:243-270) on each of the three orders.  The three oracle runs (about a minute each at this size) run side by
+    side on three host threads (the C restatement releases the GIL), which is what keeps this file's wall time down; the tests below
+    only compare."""
+    import threading
+    from mfrec_amd import sharding
     from mfrec_amd.plan import SgdPlan
     from oracle import oracle as O
     nu, ni, nnz, idx, r = cfg3_data
     k = 64
     u0, v0 = synth.init_normal(k, ni, 7), synth.init_normal(k, nu, 8)
+    out = {}
+    # -- given order, level schedule
     u, v, ib, ub = u0.copy(), v0.copy(), np.zeros(ni), np.zeros(nu)
     with SgdPlan(idx, r, nu, ni, k) as p:
         info = p.info()
         p.set_factors(u, v, ib, ub)
         rm = p.run_kmf(0, 1, *HP)
         p.get_factors(u, v, ib, ub)
-    rm2 = np.zeros(1)
-    ib2, ub2 = np.zeros(ni), np.zeros(nu)
-    O.train_linear_kernel(1, k, 0.1, HP[0], 0, 0, HP[1], HP[2], HP[3], 0.0, u0, v0, idx, r, ib2, ub2, 1, 1, 0, rm2)
-    assert np.array_equal(u, u0) and np.array_equal(v, v0)          # u0 / v0 now hold the oracle's result
-    assert np.array_equal(ib, ib2) and np.array_equal(ub, ub2)
-    assert abs(rm[0] - rm2[0]) <= 1e-12 * rm2[0]
-    assert info["schedule_builder"] == "device" and 900 < info["n_levels"] < 1500
-
-
-def test_cfg3_whole_user_major_resident_epoch_bitexact_vs_oracle(cfg3_data):
-    from mfrec_amd.plan import SgdPlan
-    from oracle import oracle as O
-    nu, ni, nnz, idx, r = cfg3_data
-    k = 64
-    # user-major, ascending items, generation order among duplicates: one stable sort of a combined key
+    out["given"] = dict(gpu=(u, v, ib, ub), rm=rm, info=info, order=(idx, r))
+    # -- user-major, ascending items, generation order among duplicates: one stable sort of a combined key
     order = np.argsort((idx[:, 0].astype(np.int64) << 32) | idx[:, 1].astype(np.int64), kind="stable")
     iu, ru = np.ascontiguousarray(idx[order]), np.ascontiguousarray(r[order])
     del order
-    u0, v0 = synth.init_normal(k, ni, 7), synth.init_normal(k, nu, 8)
     u, v, ib, ub = u0.copy(), v0.copy(), np.zeros(ni), np.zeros(nu)
     with SgdPlan(iu, ru, nu, ni, k) as p:
         info = p.info()
@@ -85,15 +81,48 @@ def test_cfg3_whole_user_major_resident_epoch_bitexact_vs_oracle(cfg3_data):
         rm = p.run_kmf(0, 1, *HP)
         dt = time.time() - t0
         p.get_factors(u, v, ib, ub)
-        assert p.info()["epoch_kernel"] == "ticket"            # no fallback happened
-    assert info["epoch_kernel"] == "ticket" and "user rows resident" in name, (info, name)
-    rm2 = np.zeros(1)
-    ib2, ub2 = np.zeros(ni), np.zeros(nu)
-    O.train_linear_kernel(1, k, 0.1, HP[0], 0, 0, HP[1], HP[2], HP[3], 0.0, u0, v0, iu, ru, ib2, ub2, 1, 1, 0, rm2)
-    assert np.array_equal(u, u0) and np.array_equal(v, v0)          # u0 / v0 now hold the oracle's result
-    assert np.array_equal(ib, ib2) and np.array_equal(ub, ub2)
-    assert abs(rm[0] - rm2[0]) <= 1e-12 * rm2[0]
-    assert dt < 1.0                         # ~30 ms on the device + the first launch; a regression guard
+        after = p.info()["epoch_kernel"]
+    out["user_major"] = dict(gpu=(u, v, ib, ub), rm=rm, info=info, name=name, dt=dt, after=after, order=(iu, ru))
+    # -- the one-GPU block order (sharding.kmf_train_block_order: four item blocks, every block in its own minimum-level order)
+    u, v, ib, ub = u0.copy(), v0.copy(), np.zeros(ni), np.zeros(nu)
+    perm = sharding.kmf_train_block_order(0, 1, k, HP[0], HP[1], HP[2], HP[3], u, v, idx, r, ib, ub)
+    pidx, pr = np.ascontiguousarray(idx[perm]), np.ascontiguousarray(r[perm])
+    out["blocks"] = dict(gpu=(u, v, ib, ub), perm_ok=(perm.shape[0] == nnz and int(perm.sum()) == nnz * (nnz - 1) // 2), order=(pidx, pr))
+    del perm
+
+    def oracle(tag):
+        oi, orr = out[tag]["order"]
+        ou, ov, oib, oub, orm = u0.copy(), v0.copy(), np.zeros(ni), np.zeros(nu), np.zeros(1)
+        O.train_linear_kernel(1, k, 0.1, HP[0], 0, 0, HP[1], HP[2], HP[3], 0.0, ou, ov, oi, orr, oib, oub, 1, 1, 0, orm)
+        out[tag]["oracle"] = (ou, ov, oib, oub)
+        out[tag]["oracle_rm"] = orm
+
+    th = [threading.Thread(target=oracle, args=(tag,)) for tag in ("given", "user_major", "blocks")]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    return out
+
+
+def _same(a, b):
+    return all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_cfg3_whole_one_epoch_bitexact_vs_oracle(cfg3_runs):
+    g = cfg3_runs["given"]
+    assert _same(g["gpu"], g["oracle"])
+    assert abs(g["rm"][0] - g["oracle_rm"][0]) <= 1e-12 * g["oracle_rm"][0]
+    assert g["info"]["schedule_builder"] == "device" and 900 < g["info"]["n_levels"] < 1500
+
+
+def test_cfg3_whole_user_major_resident_epoch_bitexact_vs_oracle(cfg3_runs):
+    g = cfg3_runs["user_major"]
+    assert g["info"]["epoch_kernel"] == "ticket" and "user rows resident" in g["name"], (g["info"], g["name"])
+    assert g["after"] == "ticket"                                  # no fallback happened
+    assert _same(g["gpu"], g["oracle"])
+    assert abs(g["rm"][0] - g["oracle_rm"][0]) <= 1e-12 * g["oracle_rm"][0]
+    assert g["dt"] < 1.0                    # ~30 ms on the device + the first launch; a regression guard
 
 
 def _sampled_residuals(Y, X, off, col, rows, c_pos, lam):
@@ -115,28 +144,21 @@ def _sampled_residuals(Y, X, off, col, rows, c_pos, lam):
     return worst
 
 
-def test_cfg3_whole_block_order_bitexact_vs_oracle(cfg3_data):
+def test_cfg3_whole_block_order_bitexact_vs_oracle(cfg3_data, cfg3_runs):
     """cfg 3 whole on the ONE-GPU block order (sharding.kmf_train_block_order: 200 K items do not fit the static resident-side epoch
     at once, four item blocks do; every block in its own minimum-level order): one epoch, bit for bit against the oracle's
     sequential loop (kmf_train.pyx:243-270) ON THE ORDER THE TRAINER REPORTS."""
     from mfrec_amd import sharding
-    from oracle import oracle as O
     nu, ni, nnz, idx, r = cfg3_data
-    k = 64
-    assert sharding.one_gpu_block_counts(nu, ni, k) == (1, 4)
-    u0, v0 = synth.init_normal(k, ni, 7), synth.init_normal(k, nu, 8)
-    u, v, ib, ub = u0.copy(), v0.copy(), np.zeros(ni), np.zeros(nu)
-    perm = sharding.kmf_train_block_order(0, 1, k, HP[0], HP[1], HP[2], HP[3], u, v, idx, r, ib, ub)
-    assert perm.shape[0] == nnz and int(perm.sum()) == nnz * (nnz - 1) // 2
-    pidx, pr = np.ascontiguousarray(idx[perm]), np.ascontiguousarray(r[perm])
+    assert sharding.one_gpu_block_counts(nu, ni, 64) == (1, 4)
+    g = cfg3_runs["blocks"]
+    assert g["perm_ok"]
+    pidx = g["order"][0]
     # the order groups the ratings by item block: block ids never decrease along it
     bounds = sharding.item_blocks(idx, ni, 4)
     jb = np.searchsorted(bounds, pidx[:, 1], side="right") - 1
     assert jb[0] == 0 and jb[-1] == 3 and np.all(np.diff(jb) >= 0)
-    ib2, ub2 = np.zeros(ni), np.zeros(nu)
-    O.train_linear_kernel(1, k, 0.1, HP[0], 0, 0, HP[1], HP[2], HP[3], 0.0, u0, v0, pidx, pr, ib2, ub2)
-    assert np.array_equal(u, u0) and np.array_equal(v, v0)          # u0 / v0 now hold the oracle's result
-    assert np.array_equal(ib, ib2) and np.array_equal(ub, ub2)
+    assert _same(g["gpu"], g["oracle"])
 
 
 def test_cfg4_full_size_als_epoch_residuals(cfg3_data):
@@ -240,7 +262,8 @@ def test_cfg5_whole_one_gpu_properties():
     from mfrec_amd.plan import SgdPlan
     nu, ni, nnz, k = 10000000, 1000000, 1000000000, 64
     idx, r = synth.make_ratings(nu, ni, nnz)
-    u0, v0 = synth.init_normal(k, ni, 7), synth.init_normal(k, nu, 8)
+    U0, V0 = synth.init_normal(k, ni, 7), synth.init_normal(k, nu, 8)         # (640 M normals: drawn once, copied where needed)
+    u0, v0 = U0.copy(), V0.copy()
     with SgdPlan(idx, r, nu, ni, k) as p:
         info = p.info()
         p.set_factors(u0, v0, np.zeros(ni), np.zeros(nu))
@@ -260,7 +283,7 @@ def test_cfg5_whole_one_gpu_properties():
     assert sharding.one_gpu_block_counts(nu, ni, k) == (3, 24)
     d = sharding.DsgdKMF(idx, r, nu, ni, k, -1, 3, item_blocks_1gpu=24)
     dinfo = d.info()
-    d.set_factors(synth.init_normal(k, ni, 7), synth.init_normal(k, nu, 8), np.zeros(ni), np.zeros(nu))
+    d.set_factors(U0, V0, np.zeros(ni), np.zeros(nu))
     se = np.concatenate([d.train(0, 2, *HP), d.train(0, 1, *HP)])
     perm = d.order()
     d.close()
@@ -278,8 +301,19 @@ def test_cfg5_whole_one_gpu_properties():
     sidx, sr = np.ascontiguousarray(idx[sub]), np.ascontiguousarray(r[sub])
     assert int(sidx[:, 0].max()) < ub_[1] and int(sidx[:, 1].max()) < ib_[1] and 10000000 < n0 < 18000000
     del sub
-    pu, pv = synth.init_normal(k, ni, 7), synth.init_normal(k, nu, 8)
+    pu, pv = U0.copy(), V0.copy()
     pib, pub = np.zeros(ni), np.zeros(nu)
+    # (the oracle's run of the same block starts now, on a host thread beside the GPU's: the C restatement releases the GIL)
+    import threading
+    ou, ov, oib, oub = U0, V0, np.zeros(ni), np.zeros(nu)                     # U0 / V0 are not needed unchanged any more
+    oracle_in = {}
+
+    def run_oracle():
+        oi, orr = oracle_in["idx"], oracle_in["r"]
+        O.train_linear_kernel(1, k, 0.1, HP[0], 0, 0, HP[1], HP[2], HP[3], 0.0, ou, ov, oi, orr, oib, oub)
+    oracle_in["idx"], oracle_in["r"] = sidx, sr                      # (one block, given order inside it: the object's order is the identity -- asserted below)
+    th = threading.Thread(target=run_oracle)
+    th.start()
     d2 = sharding.DsgdKMF(sidx, sr, nu, ni, k, -1, 3, user_bounds=ub_, item_bounds=ib_, item_blocks_1gpu=24)
     assert d2.info()["resident_blocks"] == 1                          # (the 71 other blocks are empty)
     d2.set_factors(pu, pv, pib, pub)
@@ -288,11 +322,9 @@ def test_cfg5_whole_one_gpu_properties():
     porder = d2.order()
     d2.close()
     assert np.array_equal(porder, np.arange(n0))                      # (one block, given order inside it: the identity)
-    ou, ov, oib, oub = synth.init_normal(k, ni, 7), synth.init_normal(k, nu, 8), np.zeros(ni), np.zeros(nu)
-    O.train_linear_kernel(1, k, 0.1, HP[0], 0, 0, HP[1], HP[2], HP[3], 0.0, ou, ov, np.ascontiguousarray(sidx[porder]),
-                          np.ascontiguousarray(sr[porder]), oib, oub)
+    th.join()
     assert np.array_equal(pu, ou) and np.array_equal(pv, ov) and np.array_equal(pib, oib) and np.array_equal(pub, oub)
-    del pu, pv, ou, ov, sidx, sr
+    del pu, pv, ou, ov, U0, V0, sidx, sr
     # host and device builders on the first 100 M ratings of the same tables: same level structure
     n = 100000000
     pidx, pr = np.ascontiguousarray(idx[:n]), np.ascontiguousarray(r[:n])

@@ -36,6 +36,9 @@ LR, KU, KI, KB = 0.01, 0.1, 0.1, 0.007        # kmf.py:51-56 defaults
 FUNK_LR, FUNK_K, FUNK_INIT = 0.001, 0.05, 0.1  # gradient_descent.py:80-84 defaults
 CFG2 = (100000, 50000, 10000000, 64)
 CFG3 = (1000000, 200000, 100000000, 64)
+# one producer-store -> consumer-poll hop through the coherent path, other CU (tools/hop_latency.hip); overridden by the
+# newest profiles/rNN_hop_latency.json
+HOP_US_DEFAULT = 0.6
 
 
 def algorithmic_bytes(k, nnz, nu, s=8, rec=16):
@@ -329,6 +332,45 @@ def also_k1_skew(nu, ni, nnz, k, u0, v0, a):
     return m
 
 
+def ml10m_shape(nnz=10000000, seed=1):
+    """The SHAPE of the reference's only published workload (gradient_descent.py:41-45: MovieLens-10M, 69 878 users x 10 677
+    items, 10 M ratings): a synthetic with power-law degrees on both sides (the real file is not available offline), shuffled."""
+    nu, ni = 69878, 10677
+    rs = np.random.RandomState(seed)
+    pu, pi = 1.0 / np.arange(1, nu + 1) ** 0.4, 1.0 / np.arange(1, ni + 1) ** 0.47
+    idx = np.ascontiguousarray(np.stack([rs.choice(nu, nnz, p=pu / pu.sum()), rs.choice(ni, nnz, p=pi / pi.sum())], 1).astype(np.int32))
+    r = rs.randint(1, 6, nnz).astype(np.float64)
+    return nu, ni, idx, r
+
+
+# the dependent f64 arithmetic of ONE rating in exact mode (64 ordered adds + the error / bias chain, profiles/r04_k1_res_stamps.txt):
+# what a rating of the hottest entity costs at the very least, its rows being forwarded in registers
+DEP_US_PER_RATING = 0.65
+
+
+def also_k1_ml10m(k):
+    """K1 (full-k SGD, exact) on the MovieLens-10M SHAPE: the epoch is at least as long as the hottest item's chain --
+    max degree x the dependent arithmetic of one rating -- which is the floor printed beside the byte roofline."""
+    from mfrec_amd import synth
+    from mfrec_amd.plan import SgdPlan, LINEAR
+    nu, ni, idx, r = ml10m_shape()
+    nnz = idx.shape[0]
+    with SgdPlan(idx, r, nu, ni, k) as p:
+        p.set_factors(synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2), np.zeros(ni), np.zeros(nu))
+        m = k1_measure(p, nnz, nu, k, 3, 1, lambda n: p.run_kmf(LINEAR, n, LR, KU, KI, KB, want_rmse=False))
+    m["unit"] = "rating-updates/s"
+    m["max_item_degree"] = int(np.bincount(idx[:, 1]).max())
+    m["max_user_degree"] = int(np.bincount(idx[:, 0]).max())
+    floor_ms = m["max_item_degree"] * DEP_US_PER_RATING * 1e-3
+    m["roofline"]["chain_floor_ms"] = floor_ms
+    m["roofline"]["chain_floor"] = "hottest item's degree x %.2f us of dependent f64 arithmetic per rating (exact mode)" % DEP_US_PER_RATING
+    m["roofline"]["frac_of_chain_floor"] = floor_ms / m["device_ms_per_step"]
+    m["north_star_floor_updates_per_s"] = 200e6
+    m["workload"] = "MovieLens-10M SHAPE (synthetic, power-law degrees on both sides): 69 878 x 10 677, 10 M ratings, shuffled, k=%d, " \
+                    "full-k SGD (train_linear_kernel), exact; epoch kernel: %s" % (k, m["epoch_kernel"])
+    return m
+
+
 def train_rmse(u, v, ib, ub, idx, r, nu, ni, k):
     """sqrt(mean((r - predict(item, user))^2)) over the training ratings, f64, batched predict kernel
     (metrics.py:69-73 with kmf.py:88-94's predict)."""
@@ -378,6 +420,10 @@ def also_k1_tolerance(idx, r, nu, ni, k, u0, v0, steps, warmup, order, epochs=10
         ro["achieved"] = m["value"] * b_read / 1e9
         ro["frac"] = m["value"] * b_read / HBM_PEAK
         ro["algorithmic_bytes_per_launch"] = b_read * idx.shape[0] / ro["launches_per_epoch"]
+        # ... and the write side at s = 4: item row + f64 item bias every rating, user row + bias once per run
+        b_total = b_read + k * 4 + 8 + (k * 4 + 8) / (idx.shape[0] / float(nu))
+        ro["bytes_per_update_total"] = b_total
+        ro["frac_total_bytes"] = m["value"] * b_total / HBM_PEAK
     m["final_train_rmse_exact_mode"] = res["exact"]
     m["final_train_rmse"] = res[variant]
     m["rmse_delta_vs_exact_after_%d_epochs" % epochs] = abs(res[variant] - res["exact"])
@@ -418,8 +464,10 @@ def also_funk(idx, r, nu, ni, k, order, epochs_per_feature=2):
             "frac": rate * 24 / HBM_PEAK, "bytes_per_scalar_update": 24, "kernel": kname,
             "avg_launch_us": ms_pass * 1e3 / max(launches, 1), "launches_per_pass": launches, "traffic": None}
     if persistent:
-        # the pass is a chain of `levels` dependent hand-offs inside one launch: what one hop of the chain costs
+        # the pass is a chain of `levels` dependent hand-offs inside one launch: what one hop of the chain costs, and the floor
+        # the minimum hop of this part sets under it
         roof["us_per_chain_level"] = ms_pass * 1e3 / max(info["n_levels"], 1)
+        roof.update(chain_floor(info["n_levels"], ms_pass))
     else:
         roof["us_per_level"] = ms_pass * 1e3 / max(info["n_levels"], 1)
     tr = k2_traffic(kname) if order == "shuffled" and (nu, ni, nnz, k) == CFG2 else None
@@ -460,11 +508,8 @@ def also_funk_ml10m(with_cpu):
     and the hottest users (~7 K ratings) own a whole wave each (DESIGN.md section 4, K2 hot-wave roles)."""
     from mfrec_amd import synth
     from mfrec_amd.plan import SgdPlan, Timer
-    nu, ni, nnz, k = 69878, 10677, 10000000, 40
-    rs = np.random.RandomState(1)
-    pu, pi = 1.0 / np.arange(1, nu + 1) ** 0.4, 1.0 / np.arange(1, ni + 1) ** 0.47
-    idx = np.ascontiguousarray(np.stack([rs.choice(nu, nnz, p=pu / pu.sum()), rs.choice(ni, nnz, p=pi / pi.sum())], 1).astype(np.int32))
-    r = rs.randint(1, 6, nnz).astype(np.float64)
+    nnz, k = 10000000, 40
+    nu, ni, idx, r = ml10m_shape(nnz)
     with SgdPlan(idx, r, nu, ni, k) as p:
         p.set_factors(synth.init_const(k, ni, FUNK_INIT), synth.init_const(k, nu, FUNK_INIT))
         p.run_funk(1, 1e9, FUNK_INIT, FUNK_LR, FUNK_K, epoch_cap=1)
@@ -690,7 +735,7 @@ def self_launch(n):
     return worst
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -718,57 +763,76 @@ def main():
                     help="f32 = NOT the reference's precision: rows stored as f32 (measured option only)")
     ap.add_argument("--cpu-replica", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--start-at", type=float, default=0.0, help=argparse.SUPPRESS)
-    a = ap.parse_args()
-    if a.cpu_replica:
-        a.users = a.users or CFG2[0]; a.items = a.items or CFG2[1]
-        return cpu_replica_main(a)
+    return ap.parse_args()
 
-    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # plain `python bench.py --gpus N`: this process is only the launcher (nothing above has touched the GPU or loaded
-        # the library) -- N fresh child ranks, rank 0's JSON line relayed, worst child exit code returned
-        return self_launch(a.gpus)
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        a.gpus = world
-    if world > 1:
+class Job(object):
+    """What the stages of one bench run hand to each other (one process = one rank)."""
+
+    def mark(self, what):      # MFX_BENCH_TRACE=1: one stderr line per stage (which stage a traced run died in)
+        self.where[0] = what
+        if os.environ.get("MFX_BENCH_TRACE") == "1":
+            sys.stderr.write("[bench] stage: %s\n" % what); sys.stderr.flush()
+
+    def barrier(self):
+        self.S.sync()                                      # hipStreamSynchronize on the library stream
+        if self.multi:
+            self.S.check(self.S.lib().mfx_comm_barrier())  # RCCL all-reduce + sync = cross-rank barrier
+
+    def max_over_ranks(self, x):
+        if not self.multi:
+            return x
+        import ctypes as C
+        w = C.c_double(x)
+        self.S.check(self.S.lib().mfx_comm_allreduce_max(C.byref(w)))
+        return w.value
+
+
+def init_ranks(a):
+    """Rank / world from the launcher's environment, the run's watchdog, the workload (cfg 2 at N = 1, cfg 3 at N > 1)."""
+    J = Job()
+    J.a = a
+    J.rank = int(os.environ.get("RANK", "0"))
+    J.world = int(os.environ.get("WORLD_SIZE", "1"))
+    J.local = int(os.environ.get("LOCAL_RANK", "0"))
+    if J.world != a.gpus:
+        a.gpus = J.world
+    if J.world > 1:
         os.environ.setdefault("NCCL_DEBUG", "WARN")
     # MFX_BENCH_FORCE_MULTI=1 (rehearsal on a one-GPU box; the driver never sets it): run the N > 1 code path
     # -- cfg 3, sharded plan, real RCCL all-reduce on a forced 1-rank communicator, the DSGD leg -- with world 1
-    multi = world > 1 or os.environ.get("MFX_BENCH_FORCE_MULTI") == "1"
-    if multi and world == 1:
+    J.multi = J.world > 1 or os.environ.get("MFX_BENCH_FORCE_MULTI") == "1"
+    if J.multi and J.world == 1:
         os.environ["MFX_FORCE_COMM"] = "1"
-
-    if world > 1:
+    J.where = ["start"]
+    if J.world > 1:
         # a rank that never comes back from a collective (a peer died, a link is down) would sit there until the
         # driver's own limit: say which rank and where, then end the process with an error
         import threading
-        where = ["start"]
 
         def stuck():
-            fail_line(rank, world, "watchdog", "no progress after %s s, last stage: %s"
-                      % (os.environ.get("MFX_BENCH_TIMEOUT", "1500"), where[0]))
+            fail_line(J.rank, J.world, "watchdog", "no progress after %s s, last stage: %s"
+                      % (os.environ.get("MFX_BENCH_TIMEOUT", "1500"), J.where[0]))
             os._exit(3)
 
         main_dog = threading.Timer(float(os.environ.get("MFX_BENCH_TIMEOUT", "1500")), stuck)
         main_dog.daemon = True
         main_dog.start()
-    else:
-        where = ["start"]
+    cfg = CFG2 if (a.workload == "cfg2" or (a.workload == "auto" and not J.multi)) else CFG3
+    J.nu, J.ni, J.nnz = a.users or cfg[0], a.items or cfg[1], a.nnz or cfg[2]
+    J.k = a.k
+    J.cfg_name = {CFG2: "cfg2", CFG3: "cfg3"}.get((J.nu, J.ni, J.nnz, J.k), "custom")
+    return J
 
-    cfg = CFG2 if (a.workload == "cfg2" or (a.workload == "auto" and not multi)) else CFG3
-    nu, ni, nnz = a.users or cfg[0], a.items or cfg[1], a.nnz or cfg[2]
-    k = a.k
-    cfg_name = {CFG2: "cfg2", CFG3: "cfg3"}.get((nu, ni, nnz, k), "custom")
 
+def init_device_and_comm(J):
+    """Build (a no-op when libmfx.so is current), HIP device = LOCAL_RANK, and at N > 1 the RCCL communicator."""
     from mfrec_amd import _shim as S
     from mfrec_amd import build as B
-    from mfrec_amd import synth
-    from mfrec_amd.plan import SgdPlan, LINEAR
+    J.S = S
+    rank, world, local = J.rank, J.world, J.local
     uid = None
-    if multi:
+    if J.multi:
         # torch.distributed.run is only the launcher: no torch import in the ranks (see
         # mfrec_amd/rendezvous.py); the RCCL unique id travels through a file.  Rank 0 builds (a
         # no-op when libmfx.so is current) before it publishes the id, the other ranks wait for the
@@ -778,7 +842,7 @@ def main():
         if rank != 0:
             uid = rendezvous.exchange_unique_id(rank, world, None)
     B.build(verbose=False)
-    where[0] = "device / RCCL communicator init"
+    J.where[0] = "device / RCCL communicator init"
     try:
         # MFX_BENCH_DEVICE: rehearsal hook (several ranks on one GPU); the driver never sets it
         # one process per GPU: device = LOCAL_RANK; a launcher that narrows every rank's view to its own GPU
@@ -787,7 +851,7 @@ def main():
         if not (ndev == 1 or local < ndev):
             raise SystemExit("LOCAL_RANK %d but only %d visible devices: two ranks would share a GPU" % (local, ndev))
         S.init(int(os.environ.get("MFX_BENCH_DEVICE", local if local < ndev else 0)))
-        if multi:
+        if J.multi:
             def make_id():
                 idbuf = C.create_string_buffer(S.UNIQUE_ID_BYTES)
                 S.check(S.lib().mfx_comm_unique_id(idbuf))
@@ -800,14 +864,16 @@ def main():
         fail_line(rank, world, "device / RCCL communicator init", e)
         raise
 
-    def mark(what):            # MFX_BENCH_TRACE=1: one stderr line per stage (which stage a traced run died in)
-        where[0] = what
-        if os.environ.get("MFX_BENCH_TRACE") == "1":
-            sys.stderr.write("[bench] stage: %s\n" % what); sys.stderr.flush()
 
-    mark("synthetic data + plan (schedule build, upload)")
-    # ---- data: the whole job's ratings are a pure function of the counter, so every rank generates them
-    # and keeps its own users (strong scaling: same 100M ratings at every N) -------------------------
+def build_plan(J):
+    """Synthetic ratings of the whole job (a pure function of the counter: every rank generates them and keeps its own
+    users -- strong scaling: the same ratings at every N), this rank's shard, initial factors, the plan (schedule build and
+    upload: everything resident in HBM before the timed region)."""
+    from mfrec_amd import synth
+    from mfrec_amd.plan import SgdPlan, LINEAR
+    a, rank, world, multi = J.a, J.rank, J.world, J.multi
+    nu, ni, nnz, k = J.nu, J.ni, J.nnz, J.k
+    J.mark("synthetic data + plan (schedule build, upload)")
     if world > 1 and a.scaling == "weak":
         idx, r = synth.make_ratings(nu, ni, nnz, t0=rank * nnz, user_base=0)
         my_idx, my_r, nu_local, job_nnz = idx, r, nu, world * nnz
@@ -837,13 +903,15 @@ def main():
         v0 = synth.init_normal(k, nu, synth.SEED_INIT + 1 + rank)
     else:
         v0 = v0_full
-    my_nnz = my_r.shape[0]
+    J.idx, J.r, J.job_nnz, J.bounds = idx, r, job_nnz, bounds
+    J.my_idx, J.my_r, J.nu_local, J.my_nnz = my_idx, my_r, nu_local, my_r.shape[0]
+    J.u0, J.v0, J.v0_full = u0, v0, v0_full
     # (N > 1: the user-sharded averaging mode.  A shard holds ALL items -- too many for the static resident-side epoch at cfg 3 --, so
     #  its local epoch runs on the item-block order (sharding.ShardedKMFBlocks: every block on the static epoch, one all-reduce of the
     #  item deltas per block), or, --avg-epoch levels, the given order on the level schedule with one all-reduce per epoch)
-    use_blocks = multi and a.avg_epoch == "blocks" and a.storage == "f64" and a.order == "shuffled" and ni > 42000
-    sb = None
-    if use_blocks:
+    J.use_blocks = multi and a.avg_epoch == "blocks" and a.storage == "f64" and a.order == "shuffled" and ni > 42000
+    J.sb = None
+    if J.use_blocks:
         from mfrec_amd.sharding import ShardedKMFBlocks
 
         class BlocksPlan(object):                       # what the code below asks of a plan
@@ -873,75 +941,75 @@ def main():
             def close(self):
                 self.sb.close()
 
-        plan = BlocksPlan()
-        sb = plan.sb
+        J.plan = BlocksPlan()
+        J.sb = J.plan.sb
     else:
-        plan = SgdPlan(my_idx, my_r, max(nu_local, 1), ni, k, storage=a.storage, epoch=a.epoch if not multi else "levels")
-    plan.set_factors(u0, v0, np.zeros(ni), np.zeros(max(nu_local, 1)))
-    info = plan.info()
-    kernel_name = plan.kernel_name(LINEAR)          # the instantiation the library launches, from the library
-    last_rmse = {}
+        J.plan = SgdPlan(my_idx, my_r, max(nu_local, 1), ni, k, storage=a.storage, epoch=a.epoch if not multi else "levels")
+    J.plan.set_factors(u0, v0, np.zeros(ni), np.zeros(max(nu_local, 1)))
+    J.last_rmse = {}
+    J.LINEAR = LINEAR
 
-    def run(n):
-        if n <= 0:
-            return
-        if use_blocks:
-            se = sb.train(LINEAR, n, LR, KU, KI, KB, 1.0 / world)
-            last_rmse["se_local"] = float(se[-1])
-        elif multi:
-            rm, se = plan.run_kmf_sharded(LINEAR, n, LR, KU, KI, KB, 1.0 / world)
-            last_rmse["se_local"] = float(se[-1])
-        else:
-            plan.run_kmf(LINEAR, n, LR, KU, KI, KB, want_rmse=False)
 
-    def barrier():
-        S.sync()                                      # hipStreamSynchronize on the library stream
-        if multi:
-            S.check(S.lib().mfx_comm_barrier())       # RCCL all-reduce + sync = cross-rank barrier
+def run_epochs(J, n):
+    """n epochs of the headline mode on this rank's plan (the hot path; nothing else)."""
+    if n <= 0:
+        return
+    a, plan, world = J.a, J.plan, J.world
+    if J.use_blocks:
+        se = J.sb.train(J.LINEAR, n, LR, KU, KI, KB, 1.0 / world)
+        J.last_rmse["se_local"] = float(se[-1])
+    elif J.multi:
+        rm, se = plan.run_kmf_sharded(J.LINEAR, n, LR, KU, KI, KB, 1.0 / world)
+        J.last_rmse["se_local"] = float(se[-1])
+    else:
+        plan.run_kmf(J.LINEAR, n, LR, KU, KI, KB, want_rmse=False)
 
-    def max_over_ranks(x):
-        if not multi:
-            return x
-        import ctypes as C
-        w = C.c_double(x)
-        S.check(S.lib().mfx_comm_allreduce_max(C.byref(w)))
-        return w.value
 
-    mark("warmup / timed region")
+def timed_region(J):
+    """W untimed warm-up epochs, then EXACTLY K epochs between a barrier + stream synchronisation on both sides; the MAX
+    over the ranks of the wall time; HIP events on the library's stream around the same K epochs."""
+    a, S = J.a, J.S
+    J.mark("warmup / timed region")
     try:
-        run(max(a.warmup, 0))
-        barrier()
+        run_epochs(J, max(a.warmup, 0))
+        J.barrier()
         S.check(S.lib().mfx_timer_start())
         t0 = time.perf_counter()
-        run(a.steps)
-        barrier()
+        run_epochs(J, a.steps)
+        J.barrier()
         wall = time.perf_counter() - t0
         import ctypes as C
         ms = C.c_double(0.0)
         S.check(S.lib().mfx_timer_stop(C.byref(ms)))
-        dev_ms = ms.value
-        wall = max_over_ranks(wall)
+        J.dev_ms = ms.value
+        J.wall = J.max_over_ranks(wall)
     except Exception as e:
-        fail_line(rank, world, "timed region", e)
+        fail_line(J.rank, J.world, "timed region", e)
         raise
 
-    # Dominant kernel = k1_level (one launch per dependency level).  Its average launch duration is taken
-    # from the HIP events that bracket the timed region on the library's stream: device time of the K
-    # epochs / (K * launches per epoch).  The epoch graph holds nothing else but two tiny reduction
-    # kernels (and, at N > 1, the delta / all-reduce / combine step), so this is an upper bound of the
+
+def headline_line(J):
+    """The JSON line of rank 0 (without `also` and `cpu_baseline`): value, config, roofline of the dominant kernel."""
+    a, plan, multi, world, use_blocks = J.a, J.plan, J.multi, J.world, J.use_blocks
+    nu, ni, nnz, k, my_nnz, job_nnz = J.nu, J.ni, J.nnz, J.k, J.my_nnz, J.job_nnz
+    dev_ms, wall = J.dev_ms, J.wall
+    # Dominant kernel = k1_res (ONE persistent launch per epoch) or k1_level (one launch per dependency level).  Its
+    # average launch duration is taken from the HIP events that bracket the timed region on the library's stream:
+    # device time of the K epochs / (K * launches per epoch).  The epoch holds nothing else but the tiny granule /
+    # reduction kernels (and, at N > 1, the delta / all-reduce / combine step), so this is an upper bound of the
     # kernel's own duration and agrees with rocprofv3's average (profiles/).
     # the kernel that RAN: a static epoch that lost its co-residency check sends the plan -- all blocks of a block plan, on every
     # rank -- to the level schedule for good (and the library repeats the call), so the labels are read after the timed region
     info = plan.info()
-    kernel_name = plan.kernel_name(LINEAR)
-    mark("per-launch event pairs (profile_kmf)")
+    kernel_name = plan.kernel_name(J.LINEAR)
+    J.mark("per-launch event pairs (profile_kmf)")
     resident = use_blocks or ((not multi) and info.get("epoch_kernel", "levels") != "levels" and a.storage == "f64")
     launches = info["launches_per_epoch"] if use_blocks else (epoch_launches(info) if resident else info["launches_per_epoch"])
     b_read, b_total = algorithmic_bytes(k, nnz, nu)
     avg_launch_s = dev_ms * 1e-3 / (a.steps * launches)
     achieved = (b_read * my_nnz / launches) / avg_launch_s
     # cross-check on the level schedule: an event pair around every launch (the resident-side epoch IS one launch)
-    kern_ms = plan.profile_kmf(LINEAR, LR, KU, KI, KB)[0] if not resident else dev_ms / a.steps
+    kern_ms = plan.profile_kmf(J.LINEAR, LR, KU, KI, KB)[0] if not resident else dev_ms / a.steps
 
     # HBM traffic per launch: from the committed rocprofv3 PMC summary of this same command
     # (profiles/rNN_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes)
@@ -958,60 +1026,329 @@ def main():
     except Exception:
         traffic = None
 
-    also = {}
-    line = None
-    if rank == 0:
-        value = job_nnz * a.steps / wall
-        line = {
-            "metric": "rating-updates/s per epoch at k=%d" % k, "value": value,
-            "unit": "rating-updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": wall * 1e3 / a.steps, "higher_is_better": True,
-            "scaling": "weak" if (not multi or a.scaling == "weak") else "strong",
-            "vs_baseline": None,
-            "dtype": "f64" if a.storage == "f64" else "f64 arithmetic on %s-stored rows (NOT the reference precision)" % a.storage,
-            "data": "synthetic",
-            "config": {"workload": "%s: synthetic %dK users x %dK items, %dM ratings%s, k=%d, full-k SGD "
-                                   "(train_linear_kernel), %s order, exact (bit-identical to the sequential loop), epoch kernel: %s%s" % (
-                                       cfg_name, nu // 1000, ni // 1000, nnz // 1000000,
-                                       " per GPU" if (world > 1 and a.scaling == "weak") else "", k, a.order,
-                                       info.get("epoch_kernel", "levels") if (not multi or use_blocks) else "levels",
-                                       "" if not multi else
-                                       ", users sharded over %d GPUs, item factors replicated, RCCL all-reduce of the "
-                                       "item deltas every epoch (parameter averaging, scale 1/%d)" % (world, world)),
-                       "users": nu, "items": ni, "ratings": job_nnz, "ratings_this_gpu": my_nnz, "k": k,
-                       "levels": info["n_levels"], "launches_per_epoch": launches,
-                       "epoch_kernel": info.get("epoch_kernel", "levels") if (not multi or use_blocks) else "levels",
-                       "sharding": ("users x%d, item-delta all-reduce (RCCL)%s" % (world, " per item block; a shard's local order: "
-                                    "its item-block order" if use_blocks else "")) if multi else "none"},
-            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": b_read * my_nnz / launches,
-                         "kernel": kernel_name,
-                         "bytes_per_update_read": b_read, "bytes_per_update_total": b_total,
-                         "avg_launch_us": avg_launch_s * 1e6, "launches_per_epoch": launches,
-                         "event_pair_avg_launch_us": kern_ms * 1e3 / launches,
-                         "frac_total_bytes": (b_total * my_nnz / launches) / avg_launch_s / HBM_PEAK},
-            "device_ms_per_step": dev_ms / a.steps,
-            "schedule_build_ms": info["schedule_us"] / 1e3,
-        }
-        if traffic is not None:
-            line["roofline"]["traffic_unit"] = "bytes per launch (PMC, %s)" % traffic_src
-        if multi and "se_local" in last_rmse:
-            line["rmse_online_last_rank0_shard"] = float(np.sqrt(last_rmse["se_local"] / max(my_nnz, 1)))
-        if multi:
-            # `value` is the AVERAGING mode (north_star's user shards + item-delta all-reduce): a different trajectory than
-            # the sequential loop.  Its final-RMSE gap is measured here on a bounded CPU simulation of the same algorithm
-            # (test infrastructure: oracle/sharded_sim.py) at cfg 3 / 100; the mode that keeps the reference's RMSE is DSGD.
-            try:
-                line["rmse_gap_vs_sequential"] = averaging_gap(world, min(a.steps, 5), k)
-            except Exception as e:
-                line["rmse_gap_vs_sequential"] = {"error": repr(e)}
-            line["parity_mode"] = "also.dsgd_exact: block rotation, bit-identical to the sequential loop on its block order " \
-                                  "(RMSE gap 0); `value` is parameter averaging and misses north_star's 1e-5 by the gap above"
+    if J.rank != 0:
+        return None
+    value = job_nnz * a.steps / wall
+    epoch_kernel = info.get("epoch_kernel", "levels") if (not multi or use_blocks) else "levels"
+    if not multi:
+        how = "exact (bit-identical to the sequential loop)"
+        shard = ""
+    else:
+        # north_star's scheme: a DIFFERENT trajectory than the sequential loop (rmse_gap_vs_sequential below says by how much);
+        # the mode that keeps the sequential loop's bits is also.dsgd_exact
+        how = "parameter AVERAGING (not the sequential loop's trajectory: see rmse_gap_vs_sequential)"
+        shard = ", users sharded over %d GPUs, item factors replicated, RCCL all-reduce of the item deltas every epoch " \
+                "(scale 1/%d)" % (world, world)
+    line = {
+        "metric": "rating-updates/s per epoch at k=%d" % k, "value": value,
+        "unit": "rating-updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": wall * 1e3 / a.steps, "higher_is_better": True,
+        "scaling": "n/a" if not multi else ("weak" if a.scaling == "weak" else "strong"),
+        "vs_baseline": None,
+        "dtype": "f64" if a.storage == "f64" else "f64 arithmetic on %s-stored rows (NOT the reference precision)" % a.storage,
+        "data": "synthetic",
+        "config": {"workload": "%s: synthetic %dK users x %dK items, %dM ratings%s, k=%d, full-k SGD "
+                               "(train_linear_kernel), %s order, %s, epoch kernel: %s%s" % (
+                                   J.cfg_name, nu // 1000, ni // 1000, nnz // 1000000,
+                                   " per GPU" if (world > 1 and a.scaling == "weak") else "", k, a.order, how, epoch_kernel, shard),
+                   "users": nu, "items": ni, "ratings": job_nnz, "ratings_this_gpu": my_nnz, "k": k,
+                   "levels": info["n_levels"], "launches_per_epoch": launches,
+                   "epoch_kernel": epoch_kernel,
+                   "sharding": ("users x%d, item-delta all-reduce (RCCL)%s" % (world, " per item block; a shard's local order: "
+                                "its item-block order" if use_blocks else "")) if multi else "none"},
+        "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": b_read * my_nnz / launches,
+                     "kernel": kernel_name,
+                     "bytes_per_update_read": b_read, "bytes_per_update_total": b_total,
+                     "avg_launch_us": avg_launch_s * 1e6, "launches_per_epoch": launches,
+                     "event_pair_avg_launch_us": kern_ms * 1e3 / launches,
+                     "frac_total_bytes": (b_total * my_nnz / launches) / avg_launch_s / HBM_PEAK},
+        "device_ms_per_step": dev_ms / a.steps,
+        "schedule_build_ms": info["schedule_us"] / 1e3,
+    }
+    if traffic is not None:
+        line["roofline"]["traffic_unit"] = "bytes per launch (PMC, %s)" % traffic_src
+    if not multi and resident:
+        # the epoch is a chain of dependent hand-offs, not a stream: the floor that chain sets
+        line["roofline"].update(chain_floor(info["n_levels"], avg_launch_s * 1e3))
+    if multi and "se_local" in J.last_rmse:
+        line["rmse_online_last_rank0_shard"] = float(np.sqrt(J.last_rmse["se_local"] / max(my_nnz, 1)))
+    if multi:
+        # `value` is the AVERAGING mode (north_star's user shards + item-delta all-reduce): a different trajectory than
+        # the sequential loop.  Its final-RMSE gap is measured here on a bounded CPU simulation of the same algorithm
+        # (test infrastructure: oracle/sharded_sim.py) at cfg 3 / 100; the mode that keeps the reference's RMSE is DSGD.
+        try:
+            line["rmse_gap_vs_sequential"] = averaging_gap(world, min(a.steps, 5), k)
+        except Exception as e:
+            line["rmse_gap_vs_sequential"] = {"error": repr(e)}
+        line["parity_mode"] = "also.dsgd_exact: block rotation, bit-identical to the sequential loop on its block order " \
+                              "(RMSE gap 0); `value` is parameter averaging and misses north_star's 1e-5 by the gap above"
+    return line
 
-    # ---- N > 1: the exact block-rotation mode on the same ratings, timed the same way.  The main line exists
-    # already: a watchdog prints it (without this leg) and ends the process if the leg -- whose send/recv ring no
-    # one-GPU box can rehearse -- does not come back, so the averaging-mode `value` survives a hang here. -------
+
+def chain_floor(levels, launch_ms):
+    """The epoch / pass as a chain: `levels` dependent hand-offs, each at least one producer-store -> consumer-poll hop through
+    the coherent path.  The hop is the MINIMUM measured on this part in isolation (tools/hop_latency.hip, committed under
+    profiles/): nothing of the kernel's own work is in it, so launch time / floor says how much of the launch is chain."""
+    hop_us, src = HOP_US_DEFAULT, "default"
+    try:
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hop_latency.json")))
+        if cands:
+            hj = json.load(open(cands[-1]))
+            hop_us, src = float(hj["min_hop_us"]), os.path.basename(cands[-1])
+    except Exception:
+        pass
+    floor_ms = levels * hop_us * 1e-3
+    return {"chain_levels": levels, "min_hop_us": hop_us, "min_hop_source": src, "chain_floor_ms": floor_ms,
+            "frac_of_chain_floor": floor_ms / launch_ms if launch_ms > 0 else None}
+
+
+def one_gpu_same_workload(J):
+    """N > 1, rank 0 only, AFTER the timed region (no collective inside: the other ranks wait at their next barrier):
+    the SAME job -- every rating of it, the same k -- on this rank's ONE GPU, so that the line carries its own
+    denominator: the one-GPU block order (sharding.DsgdKMF, world = 1: item blocks on the static resident-side epoch,
+    exact on that order), the local epoch every user shard of the sharded run uses."""
+    from mfrec_amd import synth
+    from mfrec_amd.plan import Timer
+    from mfrec_amd.sharding import DsgdKMF, one_gpu_block_counts
+    a, nu, ni, nnz, k = J.a, J.nu, J.ni, J.nnz, J.k
+    steps = max(1, min(a.steps, 3))
+    nb = one_gpu_block_counts(nu, ni, k)[1]
+    t0 = time.perf_counter()
+    dk = DsgdKMF(J.idx, J.r, nu, ni, k, -1, 1, balanced=True, item_blocks_1gpu=nb)
+    build_s = time.perf_counter() - t0
+    try:
+        dk.set_factors(J.u0, J.v0_full if J.v0_full is not None else synth.init_normal(k, nu, synth.SEED_INIT + 1),
+                       np.zeros(ni), np.zeros(nu))
+        dk.train(J.LINEAR, 1, LR, KU, KI, KB)
+        J.S.sync()
+        t0 = time.perf_counter()
+        with Timer() as tm:
+            dk.train(J.LINEAR, steps, LR, KU, KI, KB)
+        J.S.sync()
+        wall = time.perf_counter() - t0
+        info = dk.info()
+    finally:
+        dk.close()
+    return {"value": nnz * steps / wall, "unit": "rating-updates/s", "ms_per_step": wall * 1e3 / steps,
+            "device_ms_per_step": tm.ms / steps, "steps": steps, "warmup": 1, "item_blocks": nb,
+            "blocks_on_the_resident_epoch": info.get("resident_blocks"), "plan_build_s": round(build_s, 1),
+            "workload": "the same %d ratings, k=%d, on rank 0's ONE GPU: one-GPU block order (%d item blocks, each in its "
+                        "minimum-level order, static resident-side epoch), exact on that order; wall time between stream "
+                        "synchronisations" % (nnz, k, nb)}
+
+
+def dsgd_leg(J, line, also, emit):
+    """N > 1: the exact block-rotation mode on the same ratings, timed the same way.  The main line exists
+    already: a watchdog prints it (without this leg) and ends the process if the leg -- whose send/recv ring no
+    one-GPU box can rehearse -- does not come back, so the averaging-mode `value` survives a hang here."""
+    import threading
+    a, rank, world = J.a, J.rank, J.world
+    limit_s = float(os.environ.get("MFX_BENCH_DSGD_TIMEOUT", "240"))
+
+    def give_up():
+        also["dsgd_exact"] = {"error": "no result after %.0f s (watchdog): leg abandoned" % limit_s}
+        fail_line(rank, world, "dsgd leg", "watchdog after %.0f s" % limit_s)
+        emit()
+        os._exit(4)          # a hang in a GPU collective is a failure of the run, whatever was printed
+
+    J.where[0] = "dsgd leg (block rotation: ncclSend/Recv ring)"
+    dog = threading.Timer(limit_s, give_up)
+    dog.daemon = True
+    dog.start()
+    try:
+        from mfrec_amd import sharding as SH
+        J.plan.close()
+        J.plan = None
+        nu, ni, k = J.nu, J.ni, J.k
+        # item blocks per GPU: as many as it takes for a block's items to fit the static resident-side epoch (cfg 3: 3 at
+        # N = 2, 2 at N = 4, 1 at N = 8; a block rests m - 1 steps in transit)
+        m_blocks = max(1, -(-(ni // world) // 42000))
+        d = SH.DsgdKMF(J.idx, J.r, nu, ni, k, rank, world, user_bounds=J.bounds, balanced=True,
+                       item_blocks_1gpu=(world * m_blocks if m_blocks > 1 else None))
+        d.set_factors(J.u0, J.v0, np.zeros(ni), np.zeros(max(J.nu_local, 1)))
+        d.train(J.LINEAR, max(a.warmup, 1), LR, KU, KI, KB)
+        J.barrier()
+        t0 = time.perf_counter()
+        se = d.train(J.LINEAR, a.steps, LR, KU, KI, KB)
+        J.barrier()
+        w2 = J.max_over_ranks(time.perf_counter() - t0)
+        di = d.info()
+        also["dsgd_exact"] = {"value": J.job_nnz * a.steps / w2, "unit": "rating-updates/s",
+                              "ms_per_step": w2 * 1e3 / a.steps, "rmse_online_last": float(np.sqrt(se[-1] / J.job_nnz)),
+                              "launches_per_epoch_per_gpu": di["launches_per_epoch"],
+                              "workload": "%s: the same ratings, %d x %d user/item blocks, every block in its own "
+                                          "minimum-level (balanced) order, block rotation over a ncclSend/Recv ring; "
+                                          "bit-identical to the sequential loop on that order "
+                                          "(tests/test_gpu_fakeworld.py)" % (J.cfg_name, world, world * m_blocks),
+                              "blocks_on_the_resident_epoch": di.get("resident_blocks")}
+        one = line.get("one_gpu_same_workload") if line else None
+        if one and "value" in one:
+            also["dsgd_exact"]["speedup_vs_one_gpu"] = also["dsgd_exact"]["value"] / one["value"]
+        d.close()
+    except Exception as e:
+        fail_line(rank, world, "dsgd leg", e)
+        also["dsgd_exact"] = {"error": repr(e)}
+    dog.cancel()
+
+
+def also_legs(J, also):
+    """N = 1: the other kernels of the path (secondary, clearly labelled; never `value`)."""
+    from mfrec_amd import synth
+    from mfrec_amd.plan import SgdPlan
+    a, idx, r, nu, ni, nnz, k, u0 = J.a, J.idx, J.r, J.nu, J.ni, J.nnz, J.k, J.u0
+    LINEAR = J.LINEAR
+    v0n = J.v0
+    only = set(x for x in a.also_only.split(",") if x)
+
+    def leg(name, fn):
+        if only and name not in only:
+            return
+        if os.environ.get("MFX_BENCH_TRACE") == "1":
+            sys.stderr.write("[bench] leg %s\n" % name); sys.stderr.flush()
+        t = time.perf_counter()
+        try:
+            also[name] = fn()
+            also[name]["leg_wall_s"] = round(time.perf_counter() - t, 1)
+        except Exception as e:                      # never let a secondary leg break the bench line
+            also[name] = {"error": repr(e)}
+
+    J.plan.close()
+    J.plan = None
+    leg("k1_levels", lambda: also_k1_order(idx, r, nu, ni, k, u0, v0n, a.steps, a.warmup, "shuffled", epoch="levels"))
+    leg("k1_user_major", lambda: also_k1_order(idx, r, nu, ni, k, u0, v0n, a.steps, a.warmup, "user-major"))
+    leg("k1_balanced", lambda: also_k1_order(idx, r, nu, ni, k, u0, v0n, a.steps, a.warmup, "balanced"))
+    leg("k1_tolerance_mode", lambda: also_k1_tolerance(idx, r, nu, ni, k, u0, v0n, a.steps, a.warmup, "shuffled"))
+    leg("k1_tolerance_mode_balanced", lambda: also_k1_tolerance(idx, r, nu, ni, k, u0, v0n, a.steps, a.warmup, "balanced"))
+    leg("k1_f32_rows", lambda: also_k1_tolerance(idx, r, nu, ni, k, u0, v0n, a.steps, a.warmup, "shuffled", variant="f32"))
+    leg("k1_f32_rows_balanced", lambda: also_k1_tolerance(idx, r, nu, ni, k, u0, v0n, a.steps, a.warmup, "balanced", variant="f32"))
+    leg("k1_zipf08", lambda: also_k1_skew(nu, ni, nnz, k, u0, v0n, 0.8))
+    leg("k1_ml10m_shape", lambda: also_k1_ml10m(k))
+    leg("k2_funk", lambda: also_funk(idx, r, nu, ni, k, "shuffled"))
+    leg("k2_funk_balanced", lambda: also_funk(idx, r, nu, ni, k, "balanced"))
+    if not a.no_cpu and "k2_funk" in also and "error" not in also["k2_funk"]:
+        try:
+            also["k2_funk"]["cpu_baseline"] = cpu_baseline_funk(idx, r, nu, ni)
+        except Exception as e:
+            also["k2_funk"]["cpu_baseline"] = {"error": repr(e)}
+
+    leg("k2_funk_ml10m_shape", lambda: also_funk_ml10m(not a.no_cpu))
+    leg("topn_batch", lambda: also_topn(idx, r, nu, ni, k, not a.no_cpu))
+
+    def cfg3_and_als():
+        nu3, ni3, nnz3, k3 = CFG3
+        idx3, r3 = synth.make_ratings(nu3, ni3, nnz3)
+        out = {}
+        with SgdPlan(idx3, r3, nu3, ni3, k3) as p3:
+            p3.set_factors(synth.init_normal(k3, ni3, synth.SEED_INIT), synth.init_normal(k3, nu3, synth.SEED_INIT + 1),
+                           np.zeros(ni3), np.zeros(nu3))
+            m = k1_measure(p3, nnz3, nu3, k3, a.steps, a.warmup,
+                           lambda n: p3.run_kmf(LINEAR, n, LR, KU, KI, KB, want_rmse=False))
+        m["unit"] = "rating-updates/s"
+        m["workload"] = "cfg3 whole on ONE GPU (1M x 200K, 100M ratings, k=64), given (shuffled) order"
+        out["k1_cfg3_whole_1gpu"] = m
+        # the same 100 M ratings in get_ratings(randomize_order=False)'s order (base.py:1115-1126): user rows
+        # resident, one persistent launch per epoch (MFX_EPOCH_TICKET by the cost model)
+        try:
+            i3u, r3u = synth.user_major(idx3, r3)
+            with SgdPlan(i3u, r3u, nu3, ni3, k3) as p3:
+                p3.set_factors(synth.init_normal(k3, ni3, synth.SEED_INIT), synth.init_normal(k3, nu3, synth.SEED_INIT + 1),
+                               np.zeros(ni3), np.zeros(nu3))
+                m2 = k1_measure(p3, nnz3, nu3, k3, a.steps, a.warmup,
+                                lambda n: p3.run_kmf(LINEAR, n, LR, KU, KI, KB, want_rmse=False))
+            m2["unit"] = "rating-updates/s"
+            m2["workload"] = "cfg3 whole on ONE GPU, user-major order (get_ratings(randomize_order=False)): user rows " \
+                             "resident in registers, item rows travel behind chain counters; epoch kernel: %s" % m2["epoch_kernel"]
+            out["k1_user_resident_cfg3"] = m2
+            del i3u, r3u
+        except Exception as e:
+            out["k1_user_resident_cfg3"] = {"error": repr(e)}
+        # the same 100 M ratings on the item-block order (sharding.DsgdKMF, world = 1): 200 K items do not fit the register file
+        # at once, four blocks of 50 K do -- every block on the static resident-side epoch; exact on that order.  Twice: the
+        # given order inside the blocks, and every block in its own minimum-level (balanced) order (`value`)
+        try:
+            from mfrec_amd.sharding import DsgdKMF
+            from mfrec_amd.plan import Timer
+            from mfrec_amd.sharding import one_gpu_block_counts
+            nb = one_gpu_block_counts(nu3, ni3, k3)[1]
+            res_b = {}
+            for bal in (False, True):
+                t0 = time.perf_counter()
+                dk = DsgdKMF(idx3, r3, nu3, ni3, k3, -1, 1, balanced=bal, item_blocks_1gpu=nb)
+                build_s = time.perf_counter() - t0
+                dk.set_factors(synth.init_normal(k3, ni3, synth.SEED_INIT), synth.init_normal(k3, nu3, synth.SEED_INIT + 1),
+                               np.zeros(ni3), np.zeros(nu3))
+                dk.train(LINEAR, max(a.warmup, 1), LR, KU, KI, KB)
+                with Timer() as tmb:
+                    se_b = dk.train(LINEAR, a.steps, LR, KU, KI, KB)
+                info_b = dk.info()
+                dk.close()
+                res_b[bal] = (nnz3 * a.steps / (tmb.ms * 1e-3), tmb.ms / a.steps, info_b, build_s, float(np.sqrt(se_b[-1] / nnz3)))
+            rate_b, ms_b, info_b, build_s, rm_b = res_b[True]
+            br3 = algorithmic_bytes(k3, nnz3, nu3)[0]
+            out["k1_cfg3_item_blocks_1gpu"] = {
+                "value": rate_b, "unit": "rating-updates/s", "device_ms_per_step": ms_b, "item_blocks": nb,
+                "blocks_on_the_resident_epoch": info_b["resident_blocks"], "levels_total": info_b["levels_total"],
+                "plan_build_s": round(build_s, 1), "rmse_online_last": rm_b,
+                "given_order_inside_the_blocks": {"value": res_b[False][0], "device_ms_per_step": res_b[False][1],
+                                                  "levels_total": res_b[False][2]["levels_total"], "plan_build_s": round(res_b[False][3], 1)},
+                "roofline": {"bound": "hbm", "achieved": rate_b * br3 / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                             "frac": rate_b * br3 / HBM_PEAK, "traffic": None,
+                             "kernel": "k1_res (static), one persistent launch per item block and epoch",
+                             "note": "measured ceiling of the access pattern: 5.5 G ratings/s (tools/rmw_ceiling.hip)"},
+                "workload": "cfg3 whole on ONE GPU, ITEM-BLOCK order: the given (shuffled) ratings grouped by %d item blocks (stable), "
+                            "every block in its own minimum-level order; exact on that order (bit-identical to the sequential loop: "
+                            "tests/test_gpu_fakeworld.py, tests/test_gpu_scale.py).  The N = 1 point of the curve `--gpus N` continues "
+                            "(the N > 1 line times this same job again as `one_gpu_same_workload`): at N > 1 every user shard runs this "
+                            "very local epoch (item blocks on the static resident-side epoch)" % nb}
+        except Exception as e:
+            out["k1_cfg3_item_blocks_1gpu"] = {"error": repr(e)}
+        del r3
+        t = time.perf_counter()
+        try:
+            out["k3_als_cfg4"] = also_als(idx3, nu3, ni3, 128)
+            out["k3_als_cfg4"]["leg_wall_s"] = round(time.perf_counter() - t, 1)
+        except Exception as e:
+            out["k3_als_cfg4"] = {"error": repr(e)}
+        return out
+
+    if not only or (only & {"k1_cfg3_whole_1gpu", "k1_user_resident_cfg3", "k1_cfg3_item_blocks_1gpu", "k3_als_cfg4"}):
+        if os.environ.get("MFX_BENCH_TRACE") == "1":
+            sys.stderr.write("[bench] leg cfg3 + als\n"); sys.stderr.flush()
+        try:
+            also.update(cfg3_and_als())
+        except Exception as e:
+            also["k1_cfg3_whole_1gpu"] = {"error": repr(e)}
+    if not a.no_cpu and "k3_als_cfg4" in also and "error" not in also["k3_als_cfg4"]:
+        try:
+            cb = cpu_baseline_als(128)
+            # scaled to cfg 4 by the FLOP model: seconds per epoch the CPU path would need
+            cb["cfg4_epoch_s_extrapolated"] = also["k3_als_cfg4"]["model_tflop_per_epoch"] * 1e3 / cb["model_gflops"]
+            also["k3_als_cfg4"]["cpu_baseline"] = cb
+        except Exception as e:
+            also["k3_als_cfg4"]["cpu_baseline"] = {"error": repr(e)}
+
+
+def main():
+    a = parse_args()
+    if a.cpu_replica:
+        a.users = a.users or CFG2[0]; a.items = a.items or CFG2[1]
+        return cpu_replica_main(a)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process is only the launcher (nothing above has touched the GPU or loaded
+        # the library) -- N fresh child ranks, rank 0's JSON line relayed, worst child exit code returned
+        return self_launch(a.gpus)
+
+    J = init_ranks(a)
+    init_device_and_comm(J)
+    build_plan(J)
+    timed_region(J)
+    line = headline_line(J)
+    rank, multi = J.rank, J.multi
+
+    also = {}
     printed = []
 
     def emit():
@@ -1021,193 +1358,34 @@ def main():
                 line["also"] = also
             print(json.dumps(line), flush=True)
 
-    if multi and a.scaling == "strong" and not a.no_also:
-        import threading
-        limit_s = float(os.environ.get("MFX_BENCH_DSGD_TIMEOUT", "240"))
-
-        def give_up():
-            also["dsgd_exact"] = {"error": "no result after %.0f s (watchdog): leg abandoned" % limit_s}
-            fail_line(rank, world, "dsgd leg", "watchdog after %.0f s" % limit_s)
-            emit()
-            os._exit(4)          # a hang in a GPU collective is a failure of the run, whatever was printed
-
-        where[0] = "dsgd leg (block rotation: ncclSend/Recv ring)"
-        dog = threading.Timer(limit_s, give_up)
-        dog.daemon = True
-        dog.start()
+    if multi and a.scaling == "strong" and rank == 0 and os.environ.get("MFX_BENCH_NO_ONE_GPU") != "1":
+        # the line's own denominator: the same job on ONE GPU (rank 0's), timed here -- after `value` is safe, before the DSGD leg
+        J.mark("one-GPU run of the same workload (rank 0 only; the other ranks wait at their next barrier)")
         try:
-            from mfrec_amd import sharding as SH
-            plan.close()
-            plan = None
-            # item blocks per GPU: as many as it takes for a block's items to fit the static resident-side epoch (cfg 3: 3 at
-            # N = 2, 2 at N = 4, 1 at N = 8; a block rests m - 1 steps in transit)
-            m_blocks = max(1, -(-(ni // world) // 42000))
-            d = SH.DsgdKMF(idx, r, nu, ni, k, rank, world, user_bounds=bounds, balanced=True,
-                           item_blocks_1gpu=(world * m_blocks if m_blocks > 1 else None))
-            d.set_factors(u0, v0, np.zeros(ni), np.zeros(max(nu_local, 1)))
-            d.train(LINEAR, max(a.warmup, 1), LR, KU, KI, KB)
-            barrier()
-            t0 = time.perf_counter()
-            se = d.train(LINEAR, a.steps, LR, KU, KI, KB)
-            barrier()
-            w2 = max_over_ranks(time.perf_counter() - t0)
-            di = d.info()
-            also["dsgd_exact"] = {"value": job_nnz * a.steps / w2, "unit": "rating-updates/s",
-                                  "ms_per_step": w2 * 1e3 / a.steps, "rmse_online_last": float(np.sqrt(se[-1] / job_nnz)),
-                                  "launches_per_epoch_per_gpu": di["launches_per_epoch"],
-                                  "workload": "%s: the same ratings, %d x %d user/item blocks, every block in its own "
-                                              "minimum-level (balanced) order, block rotation over a ncclSend/Recv ring; "
-                                              "bit-identical to the sequential loop on that order "
-                                              "(tests/test_gpu_fakeworld.py)" % (cfg_name, world, world * m_blocks),
-                                  "blocks_on_the_resident_epoch": di.get("resident_blocks")}
-            d.close()
+            one = one_gpu_same_workload(J)
+            line["one_gpu_same_workload"] = one
+            line["speedup_vs_one_gpu"] = line["value"] / one["value"]
         except Exception as e:
-            fail_line(rank, world, "dsgd leg", e)
-            also["dsgd_exact"] = {"error": repr(e)}
-        dog.cancel()
+            fail_line(rank, J.world, "one-GPU run of the same workload", e)
+            line["one_gpu_same_workload"] = {"error": repr(e)}
+            line["speedup_vs_one_gpu"] = None
 
-    # ---- N = 1: the other kernels of the path (secondary, clearly labelled; never `value`) -----------
-    if rank == 0 and not multi and not a.no_also and a.storage == "f64" and (nu, ni, nnz, k) == CFG2 \
+    if multi and a.scaling == "strong" and not a.no_also:
+        dsgd_leg(J, line, also, emit)
+
+    if rank == 0 and not multi and not a.no_also and a.storage == "f64" and (J.nu, J.ni, J.nnz, J.k) == CFG2 \
             and a.order == "shuffled":
-        v0n = v0
-
-        only = set(x for x in a.also_only.split(",") if x)
-
-        def leg(name, fn):
-            if only and name not in only:
-                return
-            if os.environ.get("MFX_BENCH_TRACE") == "1":
-                sys.stderr.write("[bench] leg %s\n" % name); sys.stderr.flush()
-            t = time.perf_counter()
-            try:
-                also[name] = fn()
-                also[name]["leg_wall_s"] = round(time.perf_counter() - t, 1)
-            except Exception as e:                      # never let a secondary leg break the bench line
-                also[name] = {"error": repr(e)}
-
-        plan.close()
-        plan = None
-        leg("k1_levels", lambda: also_k1_order(idx, r, nu, ni, k, u0, v0n, a.steps, a.warmup, "shuffled", epoch="levels"))
-        leg("k1_user_major", lambda: also_k1_order(idx, r, nu, ni, k, u0, v0n, a.steps, a.warmup, "user-major"))
-        leg("k1_balanced", lambda: also_k1_order(idx, r, nu, ni, k, u0, v0n, a.steps, a.warmup, "balanced"))
-        leg("k1_tolerance_mode", lambda: also_k1_tolerance(idx, r, nu, ni, k, u0, v0n, a.steps, a.warmup, "shuffled"))
-        leg("k1_tolerance_mode_balanced", lambda: also_k1_tolerance(idx, r, nu, ni, k, u0, v0n, a.steps, a.warmup, "balanced"))
-        leg("k1_f32_rows", lambda: also_k1_tolerance(idx, r, nu, ni, k, u0, v0n, a.steps, a.warmup, "shuffled", variant="f32"))
-        leg("k1_f32_rows_balanced", lambda: also_k1_tolerance(idx, r, nu, ni, k, u0, v0n, a.steps, a.warmup, "balanced", variant="f32"))
-        leg("k1_zipf08", lambda: also_k1_skew(nu, ni, nnz, k, u0, v0n, 0.8))
-        leg("k2_funk", lambda: also_funk(idx, r, nu, ni, k, "shuffled"))
-        leg("k2_funk_balanced", lambda: also_funk(idx, r, nu, ni, k, "balanced"))
-        if not a.no_cpu and "k2_funk" in also and "error" not in also["k2_funk"]:
-            try:
-                also["k2_funk"]["cpu_baseline"] = cpu_baseline_funk(idx, r, nu, ni)
-            except Exception as e:
-                also["k2_funk"]["cpu_baseline"] = {"error": repr(e)}
-
-        leg("k2_funk_ml10m_shape", lambda: also_funk_ml10m(not a.no_cpu))
-        leg("topn_batch", lambda: also_topn(idx, r, nu, ni, k, not a.no_cpu))
-
-        def cfg3_and_als():
-            nu3, ni3, nnz3, k3 = CFG3
-            idx3, r3 = synth.make_ratings(nu3, ni3, nnz3)
-            out = {}
-            with SgdPlan(idx3, r3, nu3, ni3, k3) as p3:
-                p3.set_factors(synth.init_normal(k3, ni3, synth.SEED_INIT), synth.init_normal(k3, nu3, synth.SEED_INIT + 1),
-                               np.zeros(ni3), np.zeros(nu3))
-                m = k1_measure(p3, nnz3, nu3, k3, a.steps, a.warmup,
-                               lambda n: p3.run_kmf(LINEAR, n, LR, KU, KI, KB, want_rmse=False))
-            m["unit"] = "rating-updates/s"
-            m["workload"] = "cfg3 whole on ONE GPU (1M x 200K, 100M ratings, k=64): the N=1 point of the strong-scaling " \
-                            "curve that `--gpus N` (N>1) continues"
-            out["k1_cfg3_whole_1gpu"] = m
-            # the same 100 M ratings in get_ratings(randomize_order=False)'s order (base.py:1115-1126): user rows
-            # resident, one persistent launch per epoch (MFX_EPOCH_TICKET by the cost model)
-            try:
-                i3u, r3u = synth.user_major(idx3, r3)
-                with SgdPlan(i3u, r3u, nu3, ni3, k3) as p3:
-                    p3.set_factors(synth.init_normal(k3, ni3, synth.SEED_INIT), synth.init_normal(k3, nu3, synth.SEED_INIT + 1),
-                                   np.zeros(ni3), np.zeros(nu3))
-                    m2 = k1_measure(p3, nnz3, nu3, k3, a.steps, a.warmup,
-                                    lambda n: p3.run_kmf(LINEAR, n, LR, KU, KI, KB, want_rmse=False))
-                m2["unit"] = "rating-updates/s"
-                m2["workload"] = "cfg3 whole on ONE GPU, user-major order (get_ratings(randomize_order=False)): user rows " \
-                                 "resident in registers, item rows travel behind chain counters; epoch kernel: %s" % m2["epoch_kernel"]
-                out["k1_user_resident_cfg3"] = m2
-                del i3u, r3u
-            except Exception as e:
-                out["k1_user_resident_cfg3"] = {"error": repr(e)}
-            # the same 100 M ratings on the item-block order (sharding.DsgdKMF, world = 1): 200 K items do not fit the register file
-            # at once, four blocks of 50 K do -- every block on the static resident-side epoch; exact on that order.  Twice: the
-            # given order inside the blocks, and every block in its own minimum-level (balanced) order (`value`)
-            try:
-                from mfrec_amd.sharding import DsgdKMF
-                from mfrec_amd.plan import Timer
-                from mfrec_amd.sharding import one_gpu_block_counts
-                nb = one_gpu_block_counts(nu3, ni3, k3)[1]
-                res_b = {}
-                for bal in (False, True):
-                    t0 = time.perf_counter()
-                    dk = DsgdKMF(idx3, r3, nu3, ni3, k3, -1, 1, balanced=bal, item_blocks_1gpu=nb)
-                    build_s = time.perf_counter() - t0
-                    dk.set_factors(synth.init_normal(k3, ni3, synth.SEED_INIT), synth.init_normal(k3, nu3, synth.SEED_INIT + 1),
-                                   np.zeros(ni3), np.zeros(nu3))
-                    dk.train(LINEAR, max(a.warmup, 1), LR, KU, KI, KB)
-                    with Timer() as tmb:
-                        se_b = dk.train(LINEAR, a.steps, LR, KU, KI, KB)
-                    info_b = dk.info()
-                    dk.close()
-                    res_b[bal] = (nnz3 * a.steps / (tmb.ms * 1e-3), tmb.ms / a.steps, info_b, build_s, float(np.sqrt(se_b[-1] / nnz3)))
-                rate_b, ms_b, info_b, build_s, rm_b = res_b[True]
-                br3 = algorithmic_bytes(k3, nnz3, nu3)[0]
-                out["k1_cfg3_item_blocks_1gpu"] = {
-                    "value": rate_b, "unit": "rating-updates/s", "device_ms_per_step": ms_b, "item_blocks": nb,
-                    "blocks_on_the_resident_epoch": info_b["resident_blocks"], "levels_total": info_b["levels_total"],
-                    "plan_build_s": round(build_s, 1), "rmse_online_last": rm_b,
-                    "given_order_inside_the_blocks": {"value": res_b[False][0], "device_ms_per_step": res_b[False][1],
-                                                      "levels_total": res_b[False][2]["levels_total"], "plan_build_s": round(res_b[False][3], 1)},
-                    "roofline": {"bound": "hbm", "achieved": rate_b * br3 / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                                 "frac": rate_b * br3 / HBM_PEAK, "traffic": None,
-                                 "kernel": "k1_res (static), one persistent launch per item block and epoch",
-                                 "note": "measured ceiling of the access pattern: 5.5 G ratings/s (tools/rmw_ceiling.hip)"},
-                    "workload": "cfg3 whole on ONE GPU, ITEM-BLOCK order: the given (shuffled) ratings grouped by %d item blocks (stable), "
-                                "every block in its own minimum-level order; exact on that order (bit-identical to the sequential loop: "
-                                "tests/test_gpu_fakeworld.py, tests/test_gpu_scale.py).  The N = 1 point of the curve `--gpus N` continues: "
-                                "at N > 1 every user shard runs this very local epoch (item blocks on the static resident-side epoch)" % nb}
-            except Exception as e:
-                out["k1_cfg3_item_blocks_1gpu"] = {"error": repr(e)}
-            del r3
-            t = time.perf_counter()
-            try:
-                out["k3_als_cfg4"] = also_als(idx3, nu3, ni3, 128)
-                out["k3_als_cfg4"]["leg_wall_s"] = round(time.perf_counter() - t, 1)
-            except Exception as e:
-                out["k3_als_cfg4"] = {"error": repr(e)}
-            return out
-
-        if not only or (only & {"k1_cfg3_whole_1gpu", "k1_user_resident_cfg3", "k1_cfg3_item_blocks_1gpu", "k3_als_cfg4"}):
-            if os.environ.get("MFX_BENCH_TRACE") == "1":
-                sys.stderr.write("[bench] leg cfg3 + als\n"); sys.stderr.flush()
-            try:
-                also.update(cfg3_and_als())
-            except Exception as e:
-                also["k1_cfg3_whole_1gpu"] = {"error": repr(e)}
-        if not a.no_cpu and "k3_als_cfg4" in also and "error" not in also["k3_als_cfg4"]:
-            try:
-                cb = cpu_baseline_als(128)
-                # scaled to cfg 4 by the FLOP model: seconds per epoch the CPU path would need
-                cb["cfg4_epoch_s_extrapolated"] = also["k3_als_cfg4"]["model_tflop_per_epoch"] * 1e3 / cb["model_gflops"]
-                also["k3_als_cfg4"]["cpu_baseline"] = cb
-            except Exception as e:
-                also["k3_als_cfg4"]["cpu_baseline"] = {"error": repr(e)}
+        also_legs(J, also)
 
     if rank == 0:
         if not a.no_cpu and not multi:          # rank 0 at N=1 only
-            line["cpu_baseline"] = cpu_baseline_k1(idx, r, nu, ni, k)
+            line["cpu_baseline"] = cpu_baseline_k1(J.idx, J.r, J.nu, J.ni, J.k)
     emit()
-    if plan is not None:
-        plan.close()
+    if J.plan is not None:
+        J.plan.close()
     if multi:
-        S.check(S.lib().mfx_comm_barrier())
-        S.check(S.lib().mfx_comm_destroy())
+        J.S.check(J.S.lib().mfx_comm_barrier())
+        J.S.check(J.S.lib().mfx_comm_destroy())
         from mfrec_amd import rendezvous
         rendezvous.cleanup(rank)
 

@@ -10,30 +10,28 @@
 #include <stdlib.h>
 #include <string.h>
 #include "mfx_sgd_internal.h"
+#include "mfx_rccl_abi.h"
 
 namespace {
 
-// minimal slice of the RCCL (NCCL-compatible) ABI
-typedef struct { char internal[128]; } ncclUniqueId;
-typedef void *ncclComm_t;
-enum { ncclSuccess = 0 };
-enum { ncclFloat64 = 8 };
-enum { ncclSum = 0, ncclMax = 2 };
+// the slice of the RCCL (NCCL-compatible) ABI this file binds by dlsym lives in mfx_rccl_abi.h, where
+// tests/rccl_abi_check.cpp static_asserts it against <rccl/rccl.h> (tests/test_abi.py, CPU suite)
+using namespace mfx_rccl;
 
 struct Rccl {
     void *h = nullptr;
-    int (*GetUniqueId)(ncclUniqueId *) = nullptr;
-    int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
-    int (*CommDestroy)(ncclComm_t) = nullptr;
-    int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*Broadcast)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    const char *(*GetErrorString)(int) = nullptr;
-    const char *(*GetLastError)(ncclComm_t) = nullptr;
+    GetUniqueId_t GetUniqueId = nullptr;
+    CommInitRank_t CommInitRank = nullptr;
+    CommDestroy_t CommDestroy = nullptr;
+    AllReduce_t AllReduce = nullptr;
+    AllGather_t AllGather = nullptr;
+    Broadcast_t Broadcast = nullptr;
+    Send_t Send = nullptr;
+    Recv_t Recv = nullptr;
+    GroupStart_t GroupStart = nullptr;
+    GroupEnd_t GroupEnd = nullptr;
+    GetErrorString_t GetErrorString = nullptr;
+    GetLastError_t GetLastError = nullptr;
 } R;
 
 ncclComm_t g_comm = nullptr;

@@ -166,3 +166,18 @@ def test_balanced_order_is_a_permutation_with_max_degree_levels(lib):
     perm2, _ = balanced_order(idx, nu, ni, seed=3)
     assert np.array_equal(perm, perm2)                           # seeded, deterministic
     assert not np.array_equal(perm, balanced_order(idx, nu, ni, seed=4)[0])
+
+
+def test_rccl_abi_slice_matches_the_real_header():
+    """mfrec_amd/csrc/mfx_rccl_abi.h declares by hand the twelve RCCL entry points mfx_comm.hip binds with dlsym (libmfx.so
+    neither links librccl nor needs its headers to build).  tests/rccl_abi_check.cpp static_asserts every pointer type, the
+    enum values and the 128-byte id against <rccl/rccl.h> of this ROCm: if RCCL's ABI moves, this fails instead of a run."""
+    import shutil
+    import subprocess
+    hdr = "/opt/rocm/include/rccl/rccl.h"
+    if not os.path.exists(hdr) or not shutil.which("g++"):
+        pytest.skip("no RCCL header / g++ here")
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_abi_check.cpp")
+    out = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", src],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-3000:]

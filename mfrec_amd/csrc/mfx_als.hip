@@ -992,386 +992,6 @@ __global__ __launch_bounds__(256, OCC) void k_als_rows3(const double *__restrict
 }
 
 // ------------------------------------------------------------------------------------
-// rowsn (round 5): k_als_rows3's algorithm with (a) NW = 2 OR 4 waves per row -- at two waves a row's 36 register tiles
-// need 2 x 256 registers instead of 4 x 168, so FOUR rows share a CU instead of three, and a SIMD's two waves belong to
-// different rows: one's serial phases run under the other's matrix phases --, and (b) PERSISTENT workgroups that take rows
-// from a ticket counter, so that no row slot of a CU stands empty between two workgroups (under k_als_rows3 2.6 of 3 slots
-// were occupied on average: profiles/r05_als_convoy.txt).  Role 0 owns the diagonal tiles and the serial block
-// factorisations as before; at NW = 2 it also owns block rows, dealt so that both waves hold 18 tiles at k = 128.
-// ------------------------------------------------------------------------------------
-template <int NT, int NW>
-struct RowsNMap {
-    static constexpr int NTT = NT * (NT + 1) / 2;
-    int I[NW][NTT] = {}, J[NW][NTT] = {}, n[NW] = {};
-    constexpr RowsNMap()
-    {
-        for (int s = 0; s < NT; ++s) { I[0][s] = s; J[0][s] = s; }       // slot s of role 0 = diagonal tile s
-        n[0] = NT;
-        const int first = NW > 2 ? 1 : 0;           // four waves: role 0 keeps to the diagonal (it has the serial chain)
-        for (int r = NT - 1; r >= 1; --r) {         // whole block rows (their tiles share the A operand), longest first, to the lightest role
-            int g = first;
-            for (int w = first + 1; w < NW; ++w) if (n[w] < n[g]) g = w;
-            for (int c = 0; c < r; ++c) { I[g][n[g]] = r; J[g][n[g]] = c; ++n[g]; }
-        }
-    }
-};
-
-template <int NW> __host__ __device__ constexpr int rowsn_chunk() { return NW == 2 ? 16 : 32; }
-size_t rowsn_lds_bytes(int KP, int NW)
-{
-    const size_t st = (size_t)(NW == 2 ? 16 : 32) * ych_stride(KP), xd = (size_t)2 * KP * 18;
-    return ((st > xd ? st : xd) + 2 * KP + 64) * sizeof(double) + (2 * 32 + 4) * sizeof(int);
-}
-
-template <int NT, int NW, int ROLE>
-__device__ __forceinline__ void als_rowsn_body(const double *__restrict__ Y, int k, const double *__restrict__ G,
-                                               const int64_t *__restrict__ off, const int32_t *__restrict__ col,
-                                               double c_pos, double one_plus_c, double lambda, double *X, int *status,
-                                               int n_rows, int *ticket)
-{
-    constexpr int KP = NT * 16;
-    constexpr RowsNMap<NT, NW> TM{};
-    constexpr int TS = TM.n[ROLE];                   // tile slots of this wave
-    constexpr int wid = ROLE;
-    constexpr int NTHR = 64 * NW;
-    constexpr int CHN = rowsn_chunk<NW>();           // neighbour rows per chunk
-    constexpr int PF = CHN * KP / NTHR;              // gathered doubles per thread and chunk
-    constexpr int XS = 18;                           // row stride of Xs / Dg: conflict-free MFMA operands
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int S = ych_stride(KP);
-    const int stage_elems = CHN * S;
-    const int region = (stage_elems > 2 * KP * XS ? stage_elems : 2 * KP * XS);
-    double *ych = lds;                               // SYRK staging; later:
-    double *Xs = lds;                                //   [KP][XS] current panel (rows below the block)
-    double *Dg = lds + KP * XS;                      //   [KP][XS] factored diagonal blocks, block J at rows 16J..
-    double *dinv = lds + region;                     // [KP]
-    double *bz = dinv + KP;                          // [KP] right-hand side -> z -> x
-    double *scratch = bz + KP;                       // [NW][16]
-    int *cidx = (int *)(scratch + 64);               // [2][CHN]
-    int *bad = cidx + 2 * 32;
-    int *nxt = bad + 1;                              // the workgroup's next row (ticket)
-
-    const int lane0 = threadIdx.x & 63;
-#define sI(s) (TM.I[ROLE][s])
-#define sJ(s) (TM.J[ROLE][s])
-    const bool from_g = (c_pos != 0.0);
-    const double inv_c = from_g ? 1.0 / c_pos : 0.0;
-    typedef double v2f64_a8 __attribute__((ext_vector_type(2), aligned(8)));
-    constexpr int PF2 = PF / 2;
-    static_assert(PF % 2 == 0, "pairs");
-    const bool keven = (k & 1) == 0;
-
-    auto wave_sync = [&]() __attribute__((always_inline)) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    };
-
-    int j = blockIdx.x;
-    while (j < n_rows) {
-        // (per-lane addresses are recomputed for every row: as invariants of this loop the compiler would hoist hundreds of them
-        //  out of it and spill them)
-        int lane = lane0;
-        asm volatile("" : "+v"(lane));
-        const int tid = ROLE * 64 + lane;
-        const double *Gp = G;
-        asm volatile("" : "+s"(Gp));
-        // the next row's ticket: asked for now, handed to the other waves through LDS behind the row's last barrier
-        int tk = 0;
-        if (tid == 0) tk = atomicAdd(ticket, 1);
-        const int64_t start = off[j];
-        const int span = (int)(off[j + 1] - start);
-        double *xrow = X + (size_t)j * k;
-        bool row_ok = true;
-        if (span == 0) {                             // b = 0  =>  x = 0 (als_implicit.pyx:298-302)
-            for (int f = tid; f < k; f += NTHR) xrow[f] = 0.0;
-        } else {
-            if (tid == 0) *bad = 0;
-            double4_t acc[TS > 0 ? TS : 1];
-            // accumulators start at G / c, so that A = c * acc needs no second pass over G (c != 0)
-#pragma unroll
-            for (int s = 0; s < TS; ++s) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int r = sI(s) * 16 + (lane >> 4) + 4 * q, c = sJ(s) * 16 + (lane & 15);
-                    acc[s][q] = from_g ? Gp[r * KP + c] * inv_c : 0.0;
-                }
-            }
-            double bsum = 0.0;
-
-            // ---- Y_N^T Y_N and b: chunked gather, next chunk in flight under the MFMAs ---------------------------
-            const int nchunks = (span + CHN - 1) / CHN;
-            if (tid < CHN) cidx[tid] = (tid < span) ? col[start + tid] : -1;
-            __syncthreads();
-            double2 pre[PF2];
-            auto fetch = [&](int cbase) __attribute__((always_inline)) {
-#pragma unroll
-                for (int i = 0; i < PF2; ++i) {
-                    const int e = 2 * (tid + NTHR * i), n = e / KP, f = e % KP;
-                    const int id = cidx[cbase + n];
-                    double2 v = make_double2(0.0, 0.0);
-                    if (id >= 0 && f < k) {
-                        const double *src = Y + (size_t)id * k + f;
-                        if (keven) {
-                            const v2f64_a8 w = *reinterpret_cast<const v2f64_a8 *>(src);
-                            v = make_double2(w.x, w.y);
-                        } else {
-                            v.x = src[0];
-                            if (f + 1 < k) v.y = src[1];
-                        }
-                    }
-                    pre[i] = v;
-                }
-            };
-            fetch(0);
-            int cnext = (tid < CHN && CHN + tid < span) ? col[start + CHN + tid] : -1;
-            for (int c = 0; c < nchunks; ++c) {
-#pragma unroll
-                for (int i = 0; i < PF2; ++i) {
-                    const int e = 2 * (tid + NTHR * i), n = e / KP, f = e % KP;
-                    *reinterpret_cast<double2 *>(ych + n * S + f) = pre[i];
-                }
-                const int nb = ((c + 1) & 1) * CHN;
-                if (tid < CHN) cidx[nb + tid] = cnext;
-                __syncthreads();
-                if (c + 1 < nchunks) {
-                    fetch(nb);
-                    const int t2 = (c + 2) * CHN + tid;
-                    cnext = (tid < CHN && t2 < span) ? col[start + t2] : -1;
-                }
-                if (tid < KP) {
-#pragma unroll
-                    for (int n = 0; n < CHN; ++n) bsum += ych[n * S + tid] * one_plus_c;
-                }
-                // a ragged last chunk skips its all-zero 4-row steps
-                const int nv = span - c * CHN, nv4 = nv >= CHN ? CHN : ((nv + 3) & ~3);
-#pragma unroll
-                for (int n0 = 0; n0 < CHN; n0 += 4) {
-                    if (n0 < nv4) {                                       // wave-uniform
-                        const double *base = ych + (n0 + (lane >> 4)) * S + (lane & 15);
-#pragma unroll
-                        for (int s = 0; s < TS; ++s)
-                            acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(base[sI(s) * 16], base[sJ(s) * 16], acc[s], 0, 0, 0);
-                    }
-                }
-                __syncthreads();
-            }
-
-            // ---- A = c * acc + lambda I (identity on the padding), in registers; b -> LDS -------------------------
-#pragma unroll
-            for (int s = 0; s < TS; ++s) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int r = sI(s) * 16 + (lane >> 4) + 4 * q, c = sJ(s) * 16 + (lane & 15);
-                    double a;
-                    if (r < k && c < k) {
-                        a = from_g ? acc[s][q] * c_pos : Gp[r * KP + c];
-                        if (r == c) a += lambda;
-                    } else {
-                        a = (r == c) ? 1.0 : 0.0;
-                    }
-                    acc[s][q] = a;
-                }
-            }
-            if (tid < KP) bz[tid] = (tid < k) ? bsum : 0.0;
-
-            // C-layout register tile -> Dg block Jd, then factor it in row-per-lane registers (role 0)
-            auto factor_block = [&](const double4_t &t, int Jd) __attribute__((always_inline)) {
-                double *blk = Dg + Jd * 16 * XS;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) blk[((lane >> 4) + 4 * q) * XS + (lane & 15)] = t[q];
-                wave_sync();
-                const int r = lane & 15;
-                double d[16];
-#pragma unroll
-                for (int c = 0; c < 16; ++c) d[c] = blk[r * XS + c];
-                double myinv = 1.0;
-                bool ok = true;
-                double pj = dpp_bcast<0>(d[0]);
-                double inv = rsqrt_fma(pj);
-                static_for<0, 16>([&](auto JJ) {
-                    constexpr int jj = JJ;
-                    ok = ok && (pj > 0.0);
-                    if (r == jj) myinv = inv;
-                    d[jj] *= inv;                                        // column jj of L (lane = row)
-                    if constexpr (jj < 15) {
-                        dpp_fnma<jj + 1>(d[jj + 1], d[jj], d[jj]);       // d[.][c] -= L[.][jj] * L[c][jj]
-                        pj = dpp_bcast<jj + 1>(d[jj + 1]);
-                        inv = rsqrt_fma(pj);
-                        static_for<jj + 2, 16>([&](auto C) {
-                            constexpr int c = C;
-                            dpp_fnma<c, false>(d[c], d[jj], d[jj]);
-                        });
-                    }
-                });
-                wave_sync();                                 // all lanes have read the raw block
-                if (lane < 16) {
-#pragma unroll
-                    for (int c = 0; c < 16; ++c)
-                        if (c <= r) blk[r * XS + c] = d[c];
-                    dinv[Jd * 16 + r] = myinv;
-                }
-                if (!ok && lane == 0) *bad = 1;
-            };
-            auto trailing_reg = [&](double4_t &t, int I, int J2) __attribute__((always_inline)) {
-                const double *pa = Xs + (I * 16 + (lane & 15)) * XS + (lane >> 4);
-                const double *pb = Xs + (J2 * 16 + (lane & 15)) * XS + (lane >> 4);
-#pragma unroll
-                for (int s4 = 0; s4 < 16; s4 += 4)
-                    t = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[s4], pb[s4], t, 0, 0, 0);
-            };
-
-            // ---- blocked Cholesky on the register tiles --------------------------------------------------------
-            if constexpr (wid == 0) factor_block(acc[0], 0);
-#pragma unroll
-            for (int Jb = 0; Jb < NT; ++Jb) {
-                const int c0 = Jb * 16;
-                __syncthreads();                             // Dg[Jb], dinv ready; Xs free
-#pragma unroll
-                for (int s = 0; s < TS; ++s)
-                    if (sJ(s) == Jb && sI(s) > Jb) {         // the raw panel tiles -> Xs
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            Xs[(sI(s) * 16 + (lane >> 4) + 4 * q) * XS + (lane & 15)] = acc[s][q];
-                    }
-                __syncthreads();
-                // panel rows and the border row: x = a * L11^{-T}, one lane per row.  L11 sits in registers, lane = its row, and
-                // reaches the other lanes by DPP broadcast (every lane of a taking-part wave stays active: surplus lanes redo the
-                // border row and skip the store).
-                if (c0 + 16 + wid * 64 <= KP) {                  // wave-uniform
-                    const int pr = c0 + 16 + tid;
-                    const bool mine = pr <= KP;
-                    double *rowp = (pr < KP) ? Xs + pr * XS : bz + c0;
-                    const double *L11 = Dg + (c0 + (lane & 15)) * XS;
-                    double Lr[16], a[16];
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) Lr[c] = L11[c];
-                    const double dv = dinv[c0 + (lane & 15)];
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) a[c] = rowp[c];
-                    static_for<0, 16>([&](auto JJ) {
-                        constexpr int jj = JJ;
-                        a[jj] *= dpp_bcast<jj>(dv);
-                        static_for<jj + 1, 16>([&](auto M) {             // a[m] -= L[m][jj] * x_jj
-                            constexpr int m = M;
-                            dpp_fnma<m, false>(a[m], Lr[jj], a[jj]);
-                        });
-                    });
-                    if (mine) {
-#pragma unroll
-                        for (int c = 0; c < 16; ++c) rowp[c] = a[c];
-                    }
-                }
-                __syncthreads();
-                if constexpr (wid == NW - 1) {   // border row of the trailing update (the last wave: off role 0's chain)
-                    for (int c = c0 + 16 + lane; c < KP; c += 64) {
-                        double sum = 0.0;
-#pragma unroll
-                        for (int m = 0; m < 16; ++m) sum += bz[c0 + m] * Xs[c * XS + m];
-                        bz[c] -= sum;
-                    }
-                }
-                // the solved panel tiles come back to registers
-#pragma unroll
-                for (int s = 0; s < TS; ++s)
-                    if (sJ(s) == Jb && sI(s) > Jb) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            acc[s][q] = Xs[(sI(s) * 16 + (lane >> 4) + 4 * q) * XS + (lane & 15)];
-                    }
-                if constexpr (wid == 0) {
-                    if (Jb + 1 < NT) {
-                        trailing_reg(acc[Jb + 1], Jb + 1, Jb + 1);   // next diagonal tile first ...
-                        factor_block(acc[Jb + 1], Jb + 1);           // ... and factored right away (look-ahead), while the others update
-                    }
-#pragma unroll
-                    for (int s = 0; s < TS; ++s)
-                        if (sJ(s) > Jb && !(sI(s) == Jb + 1 && sJ(s) == Jb + 1)) trailing_reg(acc[s], sI(s), sJ(s));
-                } else {
-#pragma unroll
-                    for (int s = 0; s < TS; ++s)
-                        if (sJ(s) > Jb) trailing_reg(acc[s], sI(s), sJ(s));
-                }
-            }
-            __syncthreads();
-            row_ok = (*bad == 0);
-            if (!row_ok) {
-                if (tid == 0) atomicExch(status, j + 1);
-            } else {
-                // ---- back substitution: x_J = L_JJ^{-T} (z_J - sum_{I>J} L_IJ^T x_I), L_IJ in registers -----------
-#pragma unroll
-                for (int Jb = NT - 1; Jb >= 0; --Jb) {
-                    const int c0 = Jb * 16;
-                    double cs = 0.0;
-#pragma unroll
-                    for (int s = 0; s < TS; ++s)
-                        if (sJ(s) == Jb && sI(s) > Jb) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) cs += acc[s][q] * bz[sI(s) * 16 + (lane >> 4) + 4 * q];
-                        }
-                    {
-                        int lo = __double2loint(cs), hi = __double2hiint(cs);
-                        cs += __hiloint2double(__shfl_xor(hi, 16, 64), __shfl_xor(lo, 16, 64));
-                        lo = __double2loint(cs); hi = __double2hiint(cs);
-                        cs += __hiloint2double(__shfl_xor(hi, 32, 64), __shfl_xor(lo, 32, 64));
-                    }
-                    if (lane < 16) scratch[wid * 16 + lane] = cs;
-                    __syncthreads();
-                    if constexpr (wid == 0) {
-                        const int m = lane & 15;
-                        double rhs = bz[c0 + m];
-#pragma unroll
-                        for (int w = 0; w < NW; ++w) rhs -= scratch[w * 16 + m];
-                        double Lc[16];                                       // lane = column m of L11
-#pragma unroll
-                        for (int jj = 0; jj < 16; ++jj) Lc[jj] = Dg[(c0 + jj) * XS + m];
-                        const double dv = dinv[c0 + m];
-                        static_for<0, 16>([&](auto T) {
-                            constexpr int jj = 15 - T;
-                            const double x = dpp_bcast<jj>(rhs) * dpp_bcast<jj>(dv);
-                            const double upd = __builtin_fma(-Lc[jj], x, rhs);
-                            rhs = (m < jj) ? upd : (m == jj ? x : rhs);
-                        });
-                        if (lane < 16) bz[c0 + lane] = rhs;
-                    }
-                    __syncthreads();
-                }
-                for (int f = tid; f < k; f += NTHR) xrow[f] = bz[f];
-            }
-        }
-        // ---- the next row ----
-        if (tid == 0) *nxt = (int)gridDim.x + tk;
-        __syncthreads();
-        j = *nxt;
-        __syncthreads();                             // nobody overwrites cidx / bz / nxt of a wave still reading them
-    }
-#undef sI
-#undef sJ
-}
-
-template <int NT, int NW, int OCC>
-__global__ __launch_bounds__(64 * NW, OCC) void k_als_rowsn(const double *__restrict__ Y, int k, const double *__restrict__ G,
-                                                            const int64_t *__restrict__ off, const int32_t *__restrict__ col,
-                                                            double c_pos, double one_plus_c, double lambda, double *X, int *status,
-                                                            int n_rows, int *ticket)
-{
-    // every wave runs the same sequence of barriers; only its tile set differs
-    if constexpr (NW == 2) {
-        if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0)
-            als_rowsn_body<NT, 2, 0>(Y, k, G, off, col, c_pos, one_plus_c, lambda, X, status, n_rows, ticket);
-        else
-            als_rowsn_body<NT, 2, 1>(Y, k, G, off, col, c_pos, one_plus_c, lambda, X, status, n_rows, ticket);
-    } else {
-        switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
-        case 0: als_rowsn_body<NT, 4, 0>(Y, k, G, off, col, c_pos, one_plus_c, lambda, X, status, n_rows, ticket); break;
-        case 1: als_rowsn_body<NT, 4, 1>(Y, k, G, off, col, c_pos, one_plus_c, lambda, X, status, n_rows, ticket); break;
-        case 2: als_rowsn_body<NT, 4, 2>(Y, k, G, off, col, c_pos, one_plus_c, lambda, X, status, n_rows, ticket); break;
-        default: als_rowsn_body<NT, 4, 3>(Y, k, G, off, col, c_pos, one_plus_c, lambda, X, status, n_rows, ticket); break;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------
 // k > 128 (als_implicit.pyx:211-225 takes any dim): the same algorithm with the bordered matrix
 // [A; b^T] in a per-workgroup GLOBAL scratch slot (L2 resident: (KP+1) x (KP+2) doubles) instead of
 // LDS / registers, KP a run-time multiple of 16.  Y_N^T Y_N is accumulated on the matrix cores in
@@ -1662,8 +1282,6 @@ struct AlsKernels {
     void *rows2;
     int rows_waves;     // waves per workgroup of the row kernel
     bool reg_tiles = false;   // k_als_rows3: tiles in registers, small LDS
-    void *rowsn = nullptr;    // k_als_rowsn: persistent, NW waves per row (NT >= 5)
-    int rowsn_waves = 0, rowsn_per_cu = 0;
 };
 
 size_t rows3_lds_bytes(int KP)
@@ -1685,9 +1303,6 @@ AlsKernels als_kernels_nt()
     } else if constexpr (NT >= 5) {
         const char *e = getenv("MFX_ALS_ROWS2");              // tuning / cross-check hook
         if (e && e[0] == '1') return {(void *)k_gram_partial<NT>, (void *)k_als_rows2<NT, 4>, 4, false};
-        const char *kn = getenv("MFX_ALS_KERNEL");            // A/B hook: "n2" / "n4" = persistent k_als_rowsn at 2 / 4 waves per row
-        if (kn && !strcmp(kn, "n2")) return {(void *)k_gram_partial<NT>, (void *)k_als_rows3<NT, 3>, 4, true, (void *)k_als_rowsn<NT, 2, 2>, 2, 4};
-        if (kn && !strcmp(kn, "n4")) return {(void *)k_gram_partial<NT>, (void *)k_als_rows3<NT, 3>, 4, true, (void *)k_als_rowsn<NT, 4, 3>, 4, 3};
         // occupancy hint: k = 128 needs the cap to fit three workgroups per CU; below that the
         // kernel fits anyway and the uncapped schedule measured 4 % faster
         const char *o = getenv("MFX_ALS_OCC");
@@ -1744,21 +1359,6 @@ struct DevBuf {
 };
 
 constexpr int kGramBlocks = 512;
-
-int *g_als_ticket = nullptr;           // row ticket of the persistent row kernel (one call at a time)
-int g_num_cus = 0;
-int persistent_prepare()
-{
-    if (!g_num_cus) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        MFX_HIP(hipGetDevice(&dev));
-        MFX_HIP(hipGetDeviceProperties(&p, dev));
-        g_num_cus = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
-    }
-    if (!g_als_ticket) MFX_HIP(hipMalloc((void **)&g_als_ticket, sizeof(int)));
-    return MFX_OK;
-}
 
 constexpr int kBigSlabs = 64;
 double *g_big_scratch = nullptr;       // per-workgroup bordered matrices of the k > 128 path (one call at a time)
@@ -1859,24 +1459,6 @@ int als_half(int k, int NT, const AlsKernels &K, const double *dY, int ny, doubl
         for (int rr = r_first; rr <= r_last; ++rr) {
         const int64_t lo = (int64_t)rr * B < n_active ? (int64_t)rr * B : n_active;
         const int64_t hi = lo + B < n_active ? lo + B : n_active;
-        if (K.rowsn && hi > lo) {
-            // persistent: as many workgroups as the CUs hold at once, rows by ticket
-            int rc = persistent_prepare();
-            if (rc) return rc;
-            const size_t ldsn = rowsn_lds_bytes(KP, K.rowsn_waves);
-            if (ldsn > 64 * 1024) (void)hipFuncSetAttribute(K.rowsn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsn);
-            for (int64_t r0 = lo; r0 < hi; r0 += (1 << 30)) {
-                int n = (int)((hi - r0) < (1 << 30) ? (hi - r0) : (1 << 30));
-                const int slots = g_num_cus * K.rowsn_per_cu;
-                const int grid = n < slots ? n : slots;
-                const int64_t *off_s = d_off + r0;
-                double *X_s = dX + (size_t)r0 * k;
-                MFX_HIP(hipMemsetAsync(g_als_ticket, 0, sizeof(int), s));
-                void *wargs[] = {&Yc, &kk, &Gc, &off_s, &d_col, &c, &opc, &lam, &X_s, &d_status, &n, &g_als_ticket};
-                MFX_HIP(hipLaunchKernel(K.rowsn, dim3(grid), dim3(64 * K.rowsn_waves), wargs, ldsn, s));
-            }
-            continue;
-        }
         // the grid is one block per active row; launch in slices of <= 2^20 rows
         for (int64_t r0 = lo; r0 < hi; r0 += (1 << 20)) {
             const int n = (int)((hi - r0) < (1 << 20) ? (hi - r0) : (1 << 20));

@@ -36,6 +36,10 @@
 
 namespace mfx {
 
+#ifdef MFX_BURST_STATS
+__device__ unsigned long long g_burst_stats[16];
+#endif
+
 typedef ResRec URec;          // {travelling entity, its chain rank, rating}: 16 bytes, built by res_build_device
 struct __attribute__((aligned(16))) THdr { double bias; int32_t cnt; int32_t pad; };  // travelling entity: bias + chain counter
 
@@ -364,6 +368,13 @@ __device__ __forceinline__ void res_step(const ResParams &P, unsigned long long 
     }
 }
 
+// Diagnostic builds only (-DMFX_BURST_STATS): what the burst walk covers and how it ends (tools/burst_stats.py)
+#ifdef MFX_BURST_STATS
+#define BST(i, n) do { if (lane == 0) atomicAdd(&g_burst_stats[i], (unsigned long long)(n)); } while (0)
+#else
+#define BST(i, n) do { } while (0)
+#endif
+
 // BURST (static binding, skewed data): a resident entity with a long run ahead -- the hot item of a power-law catalogue:
 // its ratings come from different, mostly idle travelling entities -- walks up to eight of its ratings in ONE step.  The
 // three memory round trips of a step (granule polls, row loads, store acknowledge) are paid once for the eight; the
@@ -401,7 +412,9 @@ __device__ __forceinline__ int res_burst(const ResParams &P, int s, int &pos, in
     for (int w = 0; w < 8 && nd > 0; ++w) {                   // (bounded: the wave's other slots get their turn again)
         const unsigned long long okm = __ballot(lane < nd && bh.cnt == br.seq);
         const int depth = __builtin_ctzll(~okm);               // leading ready ratings of the window
-        if (depth == 0) break;
+        if (w == 0) BST(0, 1);
+        if (depth == 0) { BST(w == 0 ? 1 : 5, 1); break; }
+        BST(2, 1); BST(3, depth); if (depth < nd) BST(4, 1); if (depth == 8) BST(6, 1);
         // the travelling rows of the window: one block of loads, parked in LDS so that the walk below is ONE loop body with a
         // run-time rating index (registers cannot be indexed at run time)
         {
@@ -574,6 +587,7 @@ __global__ __launch_bounds__(64, STATIC ? ((NR <= 9 && !BURST) ? 3 : 2) : 4) voi
                     bail = true;
                     break;
                 }
+                BST(9, 1);
                 __builtin_amdgcn_s_sleep(1);
                 if (act) h = __builtin_bit_cast(THdr, ld16c(rH, (unsigned)rec.trav * 16u));
                 RS_SPIN();
@@ -593,6 +607,7 @@ __global__ __launch_bounds__(64, STATIC ? ((NR <= 9 && !BURST) ? 3 : 2) : 4) voi
                     }
                 }
             }
+            BST(7, 1); BST(8, __popcll(mask));
             double tbn = 0.0;
             if (!STATIC && mask == ALL) res_step<KP, NR, MODE, true, DOT, TS>(P, mask, ready, rec, h.bias, rbv, se, vv, prod, rT, lane, g, q, tbn RS_ARG);
             else res_step<KP, NR, MODE, false, DOT, TS>(P, mask, ready, rec, h.bias, rbv, se, vv, prod, rT, lane, g, q, tbn RS_ARG);
@@ -1828,5 +1843,17 @@ int res2_cache_to_levels(Res2Plan *rp, double *d_cache_levels)
 extern "C" int mfx_debug_res_stamps(unsigned long long *out)
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(mfx::g_res_stamps), sizeof(unsigned long long) * 64 * 16) == hipSuccess ? 0 : -4;
+}
+#endif
+
+#ifdef MFX_BURST_STATS
+extern "C" int mfx_debug_burst_stats(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mfx::g_burst_stats), sizeof(unsigned long long) * 16) != hipSuccess) return -4;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(mfx::g_burst_stats), z, sizeof z) != hipSuccess) return -4;
+    }
+    return 0;
 }
 #endif

@@ -239,21 +239,46 @@ class BaseRecommender(object):
         """Inverse of save_state; also reads a file set written by the reference itself (its pickles are
         Python 2 text pickles, its svd_s an object array): base.py:578-596.  The ratings come back as a
         lil_matrix (the reference keeps mmread's coo_matrix; every consumer here indexes the matrix).
-        TRUST: the five dictionaries are pickles and svd_s is a pickled object array (the reference's format):
-        loading a state executes whatever the files' author put there -- only load files you wrote yourself.
-        The factor arrays themselves are read WITHOUT pickle."""
+        TRUST: the five dictionaries are pickles (the reference's format): loading a state executes whatever the files' author
+        put there -- only load files you wrote yourself.  The members of `_svd.npz` are read WITHOUT a general unpickle: a trained
+        factor is a plain f64 array; a member stored as an object array may only be np.savez's image of None (svd_s of the SGD /
+        ALS families; svd_u / svd_v of a recommender saved before training) and is decoded by an unpickler that admits numpy's
+        three array constructors and refuses every other global -- anything else in it is an error, not executed."""
+        import io
+        import zipfile
         import scipy.io
         z = np.load(filename + "_svd.npz", allow_pickle=False)
 
+        class _NoGlobals(pickle.Unpickler):
+            # np.save pickles the 0-d object ARRAY (three numpy constructors), its element inline: None needs no global at all
+            _ARRAY = {("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+                      ("numpy", "ndarray"), ("numpy", "dtype")}
+
+            def find_class(self, module, name):
+                if (module, name) in self._ARRAY:
+                    return super().find_class(module, name)
+                raise pickle.UnpicklingError("%s_svd.npz: object member names %s.%s -- refused" % (filename, module, name))
+
+        def none_only(key):
+            with zipfile.ZipFile(filename + "_svd.npz") as zf, zf.open(key + ".npy") as f:
+                version = np.lib.format.read_magic(f)
+                shape, _, dtype = (np.lib.format.read_array_header_1_0(f) if version == (1, 0)
+                                   else np.lib.format.read_array_header_2_0(f))
+                if dtype != object or shape != ():
+                    raise ValueError("%s_svd.npz: member %s is an object array of shape %r; only np.savez's image of None is "
+                                     "accepted" % (filename, key, shape))
+                value = _NoGlobals(io.BytesIO(f.read()), encoding="latin1").load()
+            if isinstance(value, np.ndarray) and value.dtype == object and value.shape == ():
+                value = value.item()
+            if value is not None:
+                raise ValueError("%s_svd.npz: member %s holds a pickled %s, not None -- refused" % (filename, key, type(value).__name__))
+            return None
+
         def member(key):
-            # trained factors are plain f64 arrays: no pickle involved.  A member that np.savez stored as an object array -- svd_s
-            # of the SGD / ALS families, and svd_u / svd_v of a recommender saved BEFORE training (None) -- is re-read with
-            # allow_pickle for THAT member only, as the reference's own np.load does, and a 0-d object array comes back as its item
             try:
-                a = z[key]
-            except ValueError:
-                a = np.load(filename + "_svd.npz", allow_pickle=True)[key]
-            return a.item() if (a.dtype == object and a.shape == ()) else a
+                return z[key]                        # a plain array: no pickle involved
+            except ValueError:                       # "Object arrays cannot be loaded when allow_pickle=False"
+                return none_only(key)
 
         self.svd_u, self.svd_v, self.svd_s = member("svd_u"), member("svd_v"), member("svd_s")
         self.relationship_matrix = lil_matrix(scipy.io.mmread(filename + "_relations.mtx"))

@@ -440,8 +440,12 @@ def main():
     # difference (record: tests/golden/g12_topn_pin.json, bound to the golden file by its SHA-256).
     topn_fixture(save)
     import pin_topn
-    pin_topn.main()
-    pin_topn.pin_snapshots()
+    if os.path.isdir(os.path.join(pin_topn.REF, "mfrec")):
+        pin_topn.main()
+        pin_topn.pin_snapshots()
+    else:
+        print("pin step SKIPPED: the reference tree (%s) is not here -- g12 and the snapshot fixtures keep their committed pins "
+              "(tests/golden/g12_topn_pin.json, snapshot_pin.json); regenerate them in the build container" % pin_topn.REF)
 
     for name, size in written:
         print("%-18s %8d B" % (name, size))

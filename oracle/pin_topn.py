@@ -68,6 +68,21 @@ def translate(src):
     return str(tool.refactor_string(src, "<reference>"))
 
 
+def _check_cut_text(pieces, record_name):
+    """Nothing cut from the (untrusted) reference tree is executed unless the SHA-256 of ALL the cut text equals the one in the
+    committed record -- i.e. unless it is the very text that was reviewed when the record was made.  `--repin` (after reading the
+    text) accepts a new hash."""
+    sha = hashlib.sha256()
+    for src in pieces:
+        sha.update(src.encode())
+    path = os.path.join(GOLD, record_name)
+    want = json.load(open(path)).get("sha256_of_the_cut_text") if os.path.exists(path) else None
+    if want != sha.hexdigest() and "--repin" not in sys.argv:
+        raise SystemExit("pin_topn: the text cut from %s hashes to %s, the committed record %s says %s -- nothing was executed; "
+                         "read the definitions, then run with --repin" % (REF, sha.hexdigest(), record_name, want))
+    return sha
+
+
 def main():
     if not os.path.isdir(os.path.join(REF, "mfrec")):
         raise SystemExit("pin_topn: the reference is not present (build container only)")
@@ -75,11 +90,11 @@ def main():
     from scipy.sparse import find, lil_matrix
     from oracle import oracle as O
     ns = {"np": np, "find": find, "itemgetter": itemgetter}
-    record, sha = [], hashlib.sha256()
+    record = []
     fns = {}
-    for fname, head, indent in CUTS:
-        src, (a, b) = cut(fname, head, indent)
-        sha.update(src.encode())
+    cuts = [(fname, head) + cut(fname, head, indent) for fname, head, indent in CUTS]
+    sha = _check_cut_text([c[2] for c in cuts], "g12_topn_pin.json")      # before any of it runs
+    for fname, head, src, (a, b) in cuts:
         record.append({"file": "mfrec/recommendation/" + fname, "definition": head, "lines": "%d-%d" % (a, b)})
         code = translate(textwrap.dedent(src))
         before = set(ns)
@@ -166,7 +181,7 @@ def pin_snapshots():
     from scipy.sparse import lil_matrix
     from mfrec_amd.recommendation.base import BaseRecommender
     ns = {"np": np, "scipy": __import__("scipy")}
-    rec, sha = [], hashlib.sha256()
+    rec, pieces = [], []
     for head in ("def save_model_snapshot", "def load_model_snapshot", "def save_state"):
         src, (a, b) = cut("base.py", head, 4)
         if head == "def save_state":                     # the statements up to (not including) the first Python-2-only `file(` call
@@ -178,7 +193,9 @@ def pin_snapshots():
                     continue
                 keep.append(l)
             src = "\n".join(keep) + "\n"
-        sha.update(src.encode())
+        pieces.append((head, src, a, b))
+    sha = _check_cut_text([p_[1] for p_ in pieces], "snapshot_pin.json")   # before any of it runs
+    for head, src, a, b in pieces:
         rec.append({"file": "mfrec/recommendation/base.py", "definition": head, "lines": "%d-%d" % (a, b)})
         exec(compile(translate(textwrap.dedent(src)), "<base.py:%d>" % a, "exec"), ns)
 

@@ -269,3 +269,33 @@ def test_bench_self_launch_without_a_gpu_fails_loudly_and_returns_the_child_code
     assert out.returncode != 0
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert "no CPU fallback" in out.stderr and "[bench launcher] child exit codes" in out.stderr
+
+
+def test_load_state_refuses_a_pickled_object_in_the_svd_file(tmp_path):
+    """`_svd.npz` members are never run through a general unpickle: np.savez's image of None is decoded by an unpickler that
+    admits numpy's array constructors only; an object member that names any other global is refused, not executed."""
+    import pickle
+    import scipy.sparse as sp
+    from mfrec_amd.recommendation import KMFRecommender
+    R = KMFRecommender(4, 6, {"nbr_features": 3})
+    R.relationship_matrix = sp.lil_matrix((4, 6))
+    R._nbr_users, R._nbr_items = 4, 6
+    R.svd_u, R.svd_v, R.svd_s = None, np.ones((3, 4)), None
+    base = str(tmp_path / "s")
+    R.save_state(base)
+    Q = KMFRecommender(4, 6, {"nbr_features": 3})
+    Q.load_state(base)
+    assert Q.svd_u is None and Q.svd_s is None and np.array_equal(Q.svd_v, np.ones((3, 4)))
+    hit = []
+
+    class Evil(object):
+        def __reduce__(self):
+            return (hit.append, ("executed",))
+
+    np.savez(base + "_svd.npz", svd_s=np.array(Evil(), dtype=object), svd_u=np.ones(2), svd_v=np.ones(2))
+    with pytest.raises(pickle.UnpicklingError):
+        Q.load_state(base)
+    assert not hit
+    np.savez(base + "_svd.npz", svd_s=np.array(7, dtype=object), svd_u=np.ones(2), svd_v=np.ones(2))
+    with pytest.raises(ValueError):
+        Q.load_state(base)

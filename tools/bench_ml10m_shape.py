@@ -6,6 +6,8 @@ import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from mfrec_amd import _shim as S, synth
+if os.environ.get("MFX_LIB"):
+    S.LIB_PATH = os.environ["MFX_LIB"]
 from mfrec_amd.plan import SgdPlan, Timer
 S.init(0)
 nu, ni, nnz, k = 69878, 10677, 10000000, int(os.environ.get("K", "64"))
@@ -16,7 +18,7 @@ r = rs.randint(1, 6, nnz).astype(np.float64)
 print(json.dumps({"max_item_degree": int(np.bincount(idx[:, 1]).max()), "max_user_degree": int(np.bincount(idx[:, 0]).max())}), flush=True)
 u0, v0 = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)
 res = {}
-for epoch in ("levels", "auto"):
+for epoch in (("auto",) if os.environ.get("ONLY_AUTO") else ("levels", "auto")):
     u, v, ib, ub = u0.copy(), v0.copy(), np.zeros(ni), np.zeros(nu)
     with SgdPlan(idx, r, nu, ni, k, epoch=epoch) as p:
         p.set_factors(u, v, ib, ub)
@@ -36,4 +38,5 @@ for epoch in ("levels", "auto"):
     res[epoch] = (u, v, ib, ub)
     print(json.dumps({"epoch": epoch, "kernel": name, "levels": info["n_levels"], "ms_per_epoch": tm.ms / 3,
                       "updates_per_s": nnz * 3 / (tm.ms * 1e-3)}), flush=True)
-print(json.dumps({"auto_equals_levels_bit_for_bit": bool(all(np.array_equal(x, y) for x, y in zip(res["levels"], res["auto"])))}))
+if "levels" in res:
+    print(json.dumps({"auto_equals_levels_bit_for_bit": bool(all(np.array_equal(x, y) for x, y in zip(res["levels"], res["auto"])))}))

@@ -627,11 +627,314 @@ __global__ __launch_bounds__(256) void k_topn_tiled(int kind, int k, const doubl
 }
 
 
+// ---- the same ranking with the scores on the MATRIX cores (round 5) -------------------------------------------------
+// mf.py:161-173 is a dense contraction, scores = V^T U: 100 K users x 50 K items x 64 features = 0.64 TFLOP, which
+// k_topn_tiled did at 7 TFLOP/s on unfused vector f64.  Here a workgroup owns 32 users (their feature values in LDS: the A
+// operands of v_mfma_f64_16x16x4_f64) and its four waves walk the candidates in blocks of 32 items each, U straight from
+// global memory / L2 (B operands: one 16-byte load per lane and 4-feature step = items 2c, 2c + 1 -> two column sets), four
+// accumulator tiles per wave (2 x 16 users x 2 x 16 items).  Lane (c, g) of a wave then holds the scores of EIGHT users
+// (g + 4 q of both user tiles) for the items i0 + 2c, i0 + 2c + 1 of every block: the per-lane keep / drop bookkeeping is
+// k_topn_tiled's, a user's 64 holders (16 lanes x 4 waves) are merged by the same wave-wide arg-max through LDS.
+// EXACTNESS.  The matrix instruction does not add in the reference's order: these scores are APPROXIMATE (a few ulps).  They
+// only SELECT: k_topn_exactify recomputes the N selected scores of a user in the reference's order (k_scores' loop: the
+// bits the single-user query returns), orders them by (score descending, item ascending), and flags the user for the sort
+// path unless everything that was not selected lies below the N-th exact score by more than the rigorous error bound of the
+// approximate scores, 2 (k + 4) 2^-53 (||u||_max ||v_user|| + |biases|) -- so a flagged-or-exact result, as before.
+constexpr int kMK = 128;                            // features held in LDS (k <= kMK; more: k_topn_tiled)
+constexpr int kVS = 48;                             // row stride of the user tile: 32 users + pad (A operand reads conflict-free)
+constexpr int kRL = 192;                            // rated items per user kept in LDS
+typedef double double4_mf __attribute__((ext_vector_type(4)));
+typedef double v2f64_u8 __attribute__((ext_vector_type(2), aligned(8)));
+
+__global__ __launch_bounds__(256, 2) void k_topn_mfma(int kind, int k, const double *__restrict__ u,
+                                                      const double *__restrict__ vs, const double *__restrict__ ib,
+                                                      const double *__restrict__ sub, double mu,
+                                                      const int32_t *__restrict__ users, int n_sel, int n_pad, int ni,
+                                                      int n_cand, int N, const int64_t *__restrict__ off, const int64_t *__restrict__ off_hi,
+                                                      const int32_t *__restrict__ rated,
+                                                      int32_t *out_items, double *out_scores, double *pdrop)
+{
+    // LDS: the user tile while the candidates are walked; the holders' kept lists of 16 users at a time afterwards
+    constexpr int kMergeU = 16;
+    constexpr size_t kVtBytes = (size_t)kMK * kVS * 8, kMgBytes = (size_t)kMergeU * 64 * (kTM * 12 + 8);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kVtBytes > kMgBytes ? kVtBytes : kMgBytes];
+    double(*vt)[kVS] = reinterpret_cast<double(*)[kVS]>(smem);
+    // the users' rated lists (ascending) in LDS: the kept / dropped bookkeeping asks "is this item rated?" a few hundred times per
+    // user and lane, and a binary search of seven DEPENDENT global loads each was what the whole kernel waited for (both this kernel
+    // and k_topn_tiled ran 85-95 ms whatever the arithmetic cost); a list longer than kRL stays in global memory
+    __shared__ int32_t rl[32][kRL];
+    __shared__ int rn[32];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const int j0 = blockIdx.x * 32;                                          // < n_pad (a multiple of 32)
+    const int nks = (k + 3) >> 2;                                            // 4-feature steps
+    for (int e = tid; e < kMK * 32; e += 256) {                              // (rows k .. kMK - 1: zeros, the padded steps of the last group)
+        const int f = e >> 5, q = e & 31;
+        vt[f][q] = f < k ? vs[(size_t)f * n_pad + j0 + q] : 0.0;
+    }
+    for (int q = wid; q < 32; q += 4) {                                      // a wave copies a user's list
+        const int j = j0 + q;
+        int n = -1;                                                          // -1: no lists at all / list too long -> global search
+        if (off && j < n_sel) {
+            const int64_t lo = off[j], hi = off_hi[j];
+            if (hi - lo <= kRL) {
+                n = (int)(hi - lo);
+                for (int e = lane; e < n; e += 64) rl[q][e] = rated[lo + e];
+            }
+        } else if (!off) n = 0;
+        if (lane == 0) rn[q] = n;
+    }
+    __shared__ unsigned rmask[4][32];                                        // per wave: bit i of [q] = item i0 + i of the block is rated by user q
+    int cur = 0;                                                             // lane q < 32: cursor into user q's (ascending) list
+    // this lane's eight users: slot s = 4 t + q <-> user j0 + 16 t + g + 4 q
+    double bu[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int j = j0 + 16 * (s >> 2) + g + 4 * (s & 3);
+        bu[s] = (sub && j < n_sel) ? sub[j] : 0.0;
+    }
+    double ks[8][kTM];
+    int ki[8][kTM];
+    double dropped[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        dropped[s] = -INFINITY;
+#pragma unroll
+        for (int m = 0; m < kTM; ++m) { ks[s][m] = -INFINITY; ki[s][m] = 0x7fffffff; }
+    }
+    __syncthreads();
+    // gridDim.y > 1 (small batches): the candidate blocks are split over blockIdx.y (k_topn_merge joins the lists)
+    const int n_blk_all = (n_cand + 31) / 32;
+    const int b_lo = (int)((int64_t)n_blk_all * blockIdx.y / gridDim.y), b_hi = (int)((int64_t)n_blk_all * (blockIdx.y + 1) / gridDim.y);
+    // B operands: groups of eight 4-feature steps, the NEXT group's loads (the next block's first group after a block's last) in
+    // flight under this group's 32 matrix instructions
+    constexpr int GS = 4;
+    const int ngr = (nks + GS - 1) / GS;
+    // (two groups ahead measured slower: 50 against 43 ms for 100 K users; groups of eight steps spill)
+    double bxn[GS], byn[GS];
+    auto loadB = [&](int blk, int gr) __attribute__((always_inline)) {
+        const int it = blk * 32 + 2 * c;
+        const bool two = it + 1 < n_cand, one = it < n_cand;
+        const double *up = u + (size_t)(gr * GS * 4 + g) * ni + it;          // feature 4 (gr GS + s) + g of step s
+#pragma unroll
+        for (int s = 0; s < GS; ++s) {
+            bxn[s] = 0.0; byn[s] = 0.0;
+            if (4 * (gr * GS + s) + g < k && blk < b_hi) {
+                if (two) { const v2f64_u8 w = *reinterpret_cast<const v2f64_u8 *>(up + (size_t)4 * s * ni); bxn[s] = w.x; byn[s] = w.y; }
+                else if (one) bxn[s] = up[(size_t)4 * s * ni];
+            }
+        }
+    };
+    if (b_lo + wid < b_hi) loadB(b_lo + wid, 0);
+    for (int b = b_lo + wid; b < b_hi; b += 4) {
+        const int i0 = b * 32, it0 = i0 + 2 * c;                            // this lane's items: it0, it0 + 1
+        // which of the block's 32 items each user has rated: the lists ascend and so do a wave's blocks, so lane q walks user q's
+        // list once per launch (a couple of LDS reads per block; the tests below are then bit tests, no search, no divergence)
+        if (lane < 32) {
+            const int n = rn[lane];
+            unsigned m = 0u;
+            while (cur < n && rl[lane][cur] < i0) ++cur;
+            for (int t = cur; t < n && rl[lane][t] < i0 + 32; ++t) m |= 1u << (rl[lane][t] - i0);
+            rmask[wid][lane] = m;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        double4_mf acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = (double4_mf){0.0, 0.0, 0.0, 0.0};
+        for (int gr = 0; gr < ngr; ++gr) {
+            double bx[GS], by[GS];
+#pragma unroll
+            for (int s = 0; s < GS; ++s) { bx[s] = bxn[s]; by[s] = byn[s]; }
+            if (gr + 1 < ngr) loadB(b, gr + 1); else loadB(b + 4, 0);
+#pragma unroll
+            for (int s = 0; s < GS; ++s) {
+                const int f = 4 * (gr * GS + s) + g;                        // < kMK: the tile's rows beyond k hold zeros
+                const double a0 = vt[f][c], a1 = vt[f][16 + c];
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bx[s], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, by[s], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bx[s], acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, by[s], acc[3], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {                                 // the lane's two items, ascending
+            const int item = it0 + par;
+            if (item >= n_cand) continue;
+            const double bi = ib ? ib[item] : 0.0;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int lu = 16 * (s >> 2) + g + 4 * (s & 3), j = j0 + lu;
+                if (j >= n_sel) continue;
+                const double a = acc[2 * (s >> 2) + par][s & 3];
+                auto rated_here = [&]() -> bool {
+                    if (rn[lu] < 0) return is_rated(off, off_hi, rated, j, item);      // a list too long for LDS
+                    return (rmask[wid][lu] >> (2 * c + par)) & 1u;
+                };
+                double p;
+                switch (kind) {
+                case 0: p = a + 1.0; break;
+                case 1: p = a + (bi + bu[s]); break;
+                case 2: p = 1.0 + (1.0 / (1.0 + exp(-(a + (bi + bu[s]))))) * 4.0; break;
+                case 3: p = a + mu + (bi + bu[s]); break;
+                default: p = a; break;
+                }
+                if (p != p || p == 0.0) {                                    // never listed (mf.py:162,176-182) -- if the EXACT score says so too:
+                    if (p == 0.0 && a != 0.0) dropped[s] = INFINITY;         // a sum that cancels to zero here need not in the reference's order
+                    continue;
+                }
+                if (item == users[j]) continue;
+                // (-inf: listable, but indistinguishable from the empty-slot sentinel -> flag the user for the sort path)
+                if (p == -INFINITY) { if (!rated_here()) dropped[s] = INFINITY; continue; }
+                if (p > ks[s][kTM - 1]) {                                    // would be kept
+                    if (rated_here()) continue;
+                    double cs = p;
+                    int ci = item;
+#pragma unroll
+                    for (int m = 0; m < kTM; ++m)
+                        if (ranks_before(cs, ci, ks[s][m], ki[s][m])) {
+                            const double ts = ks[s][m]; const int ti = ki[s][m];
+                            ks[s][m] = cs; ki[s][m] = ci;
+                            cs = ts; ci = ti;
+                        }
+                    if (cs > dropped[s]) dropped[s] = cs;
+                } else if (p > dropped[s]) {
+                    if (!rated_here()) dropped[s] = p;
+                }
+            }
+        }
+    }
+    // ---- merge: a user's 64 holders (lanes (c, g) of the four waves) through LDS, 16 users at a time; wave w then takes four users:
+    //      lane = holder, N rounds of a wave-wide arg-max over the sorted kept lists (k_topn_tiled's merge) -------------------------
+    double *m_s = reinterpret_cast<double *>(smem);                          // [16][64][kTM]
+    double *m_d = m_s + kMergeU * 64 * kTM;                                  // [16][64]
+    int *m_i = reinterpret_cast<int *>(m_d + kMergeU * 64);                  // [16][64][kTM]
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();                                                     // the user tile / the previous half has been read
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if ((s >> 2) != half) continue;                                  // user tile `half`: local users 16 half + g + 4 q
+            const int lu = g + 4 * (s & 3), holder = wid * 16 + c;
+#pragma unroll
+            for (int m = 0; m < kTM; ++m) { m_s[(lu * 64 + holder) * kTM + m] = ks[s][m]; m_i[(lu * 64 + holder) * kTM + m] = ki[s][m]; }
+            m_d[lu * 64 + holder] = dropped[s];
+        }
+        __syncthreads();
+        for (int uq = 0; uq < 4; ++uq) {
+            const int lu = wid * 4 + uq, j = j0 + 16 * half + lu;
+            if (j >= n_sel) continue;                                        // uniform
+            double ls[kTM];
+            int li[kTM];
+#pragma unroll
+            for (int m = 0; m < kTM; ++m) { ls[m] = m_s[(lu * 64 + lane) * kTM + m]; li[m] = m_i[(lu * 64 + lane) * kTM + m]; }
+            double dm = m_d[lu * 64 + lane];
+            const size_t orow = (size_t)j * gridDim.y + blockIdx.y;
+            int taken = 0, n_out = 0;
+            for (int t = 0; t <= N; ++t) {                                   // round N: the best entry NOT taken counts as dropped
+                double s = -INFINITY;
+                int it = 0x7fffffff;
+#pragma unroll
+                for (int m = 0; m < kTM; ++m)
+                    if (m == taken) { s = ls[m]; it = li[m]; }
+                int owner = lane;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) {
+                    const double s2 = __shfl_xor(s, d, 64);
+                    const int it2 = __shfl_xor(it, d, 64), o2 = __shfl_xor(owner, d, 64);
+                    if (ranks_before(s2, it2, s, it)) { s = s2; it = it2; owner = o2; }
+                }
+                if (s == -INFINITY) break;                                   // nothing left (uniform)
+                if (t == N) { dm = s > dm ? s : dm; break; }
+                if (owner == lane) ++taken;
+                if (lane == 0) { out_items[orow * N + t] = it; out_scores[orow * N + t] = s; }
+                ++n_out;
+            }
+            if (lane == 0)
+                for (int t = n_out; t < N; ++t) { out_items[orow * N + t] = -1; out_scores[orow * N + t] = 0.0; }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { const double o = __shfl_xor(dm, d, 64); dm = o > dm ? o : dm; }
+            if (lane == 0) pdrop[orow] = dm;
+        }
+    }
+}
+
+// ||u_item||^2 over the candidates -> its maximum (bit pattern of a non-negative double orders like the integer)
+__global__ __launch_bounds__(256) void k_item_norm_max(int k, const double *__restrict__ u, int ni, int n_cand, unsigned long long *out)
+{
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    double s = 0.0;
+    if (item < n_cand)
+        for (int f = 0; f < k; ++f) { const double x = u[(size_t)f * ni + item]; s += x * x; }
+    if (!(s == s)) s = INFINITY;                                             // a NaN factor: every margin test fails -> sort path
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const double o = __shfl_xor(s, d, 64); s = o > s ? o : s; }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(s));
+}
+
+// One wave per user: the N selected items (approximate scores, any order) -> their EXACT scores (k_scores' loop: the reference's
+// order of operations), ordered by (score descending, item ascending); the user is flagged unless every score that was not selected
+// is below the N-th exact score by more than the error bound of the approximate scores.
+__global__ __launch_bounds__(64) void k_topn_exactify(int kind, int k, const double *__restrict__ u, const double *__restrict__ vs,
+                                                      const double *__restrict__ ib, const double *__restrict__ sub, double mu,
+                                                      int n_sel, int n_pad, int ni, int N, const int32_t *__restrict__ in_items,
+                                                      const double *__restrict__ pdrop, const unsigned long long *__restrict__ unorm2_max,
+                                                      int force_unsafe, int32_t *out_items, double *out_scores, int32_t *unsafe)
+{
+    const int j = blockIdx.x, lane = threadIdx.x;
+    const int item = lane < N ? in_items[(size_t)j * N + lane] : -1;
+    const double bu = sub ? sub[j] : 0.0;
+    double p = -INFINITY, acc = 0.0, vn2 = 0.0;
+    for (int f = 0; f < k; ++f) {
+        const double vf = vs[(size_t)f * n_pad + j];
+        vn2 += vf * vf;
+        if (item >= 0) acc += u[(size_t)f * ni + item] * vf;
+    }
+    bool lost = false;
+    double bi = 0.0;
+    if (item >= 0) {
+        bi = ib ? ib[item] : 0.0;
+        switch (kind) {
+        case 0: p = acc + 1.0; break;
+        case 1: p = acc + (bi + bu); break;
+        case 2: p = 1.0 + (1.0 / (1.0 + exp(-(acc + (bi + bu))))) * 4.0; break;
+        case 3: p = acc + mu + (bi + bu); break;
+        default: p = acc; break;
+        }
+        if (p != p || p == 0.0 || p == -INFINITY) lost = true;               // the exact score is one the list never holds: redo
+    }
+    // rank among the selected (distinct items): entries that rank before this one
+    int rank = 0, n_out = 0;
+    double T = INFINITY, bmax = 0.0;
+    for (int t = 0; t < kTopMaxN; ++t) {
+        const double s2 = __shfl(p, t, 64), b2 = __shfl(bi, t, 64);
+        const int it2 = __shfl(item, t, 64);
+        if (it2 < 0) continue;                                               // uniform
+        ++n_out;
+        T = s2 < T ? s2 : T;
+        bmax = fabs(b2) > bmax ? fabs(b2) : bmax;
+        if (item >= 0 && ranks_before(s2, it2, p, item)) ++rank;
+    }
+    if (item >= 0) { out_items[(size_t)j * N + rank] = item; out_scores[(size_t)j * N + rank] = p; }
+    else if (lane < N) { out_items[(size_t)j * N + lane] = -1; out_scores[(size_t)j * N + lane] = 0.0; }   // (ranks fill 0 .. n_out - 1)
+    // |approximate - exact| <= gamma (sum |u_f v_f| + |biases|) <= gamma (||u|| ||v|| + ...), gamma = (k + 4) 2^-53, doubled for slack
+    const double unmax = sqrt(__longlong_as_double((long long)*unorm2_max));
+    const double delta = 2.0 * (k + 4) * 1.1102230246251565e-16 * (unmax * sqrt(vn2) + bmax + fabs(bu) + fabs(mu) + 1.0);
+    const double dm = pdrop[j];
+    const bool margin_ok = n_out == N ? dm < T - delta : dm == -INFINITY;
+    const bool bad = !margin_ok || !(delta == delta) || delta == INFINITY || (force_unsafe && (j % 3) == 0);
+    const bool any_bad = __any(bad || lost);
+    if (lane == 0) unsafe[j] = any_bad ? 1 : 0;
+}
+
 // small batches: the N best of `splits` lists of N (each sorted: score descending, item ascending; -1 = no entry).
 // One wave per user, lane y holds split y's list; the same arg-max rounds as above (splits <= 64, N <= kTopMaxN).
+// drop_out != null (lists of APPROXIMATE scores, k_topn_mfma): instead of deciding, hand k_topn_exactify the best score that is NOT
+// in the merged list -- the splits' dropped scores and the merged list's own runner-up.
 __global__ __launch_bounds__(64) void k_topn_merge(const int32_t *__restrict__ pit, const double *__restrict__ psc,
                                                    const double *__restrict__ pdrop, int splits, int N, int force_unsafe,
-                                                   int32_t *out_items, double *out_scores, int32_t *unsafe)
+                                                   int32_t *out_items, double *out_scores, int32_t *unsafe, double *drop_out)
 {
     const int j = blockIdx.x, lane = threadIdx.x;
     double ls[kTopMaxN];
@@ -643,8 +946,8 @@ __global__ __launch_bounds__(64) void k_topn_merge(const int32_t *__restrict__ p
         ls[m] = have ? psc[((size_t)j * splits + lane) * N + m] : -INFINITY;
     }
     int taken = 0, n_out = 0;
-    double T = -INFINITY;
-    for (int t = 0; t < N; ++t) {
+    double T = -INFINITY, runner_up = -INFINITY;
+    for (int t = 0; t < N + (drop_out ? 1 : 0); ++t) {
         double s = -INFINITY;
         int it = 0x7fffffff;
 #pragma unroll
@@ -657,6 +960,7 @@ __global__ __launch_bounds__(64) void k_topn_merge(const int32_t *__restrict__ p
             if (ranks_before(s2, it2, s, it)) { s = s2; it = it2; }
         }
         if (s == -INFINITY) break;
+        if (t == N) { runner_up = s; break; }
         if (taken < kTopMaxN) {
             double hs = -INFINITY; int hi = 0x7fffffff;
 #pragma unroll
@@ -671,7 +975,14 @@ __global__ __launch_bounds__(64) void k_topn_merge(const int32_t *__restrict__ p
     if (lane == 0)
         for (int t = n_out; t < N; ++t) { out_items[(size_t)j * N + t] = -1; out_scores[(size_t)j * N + t] = 0.0; }
     // a split that dropped something which could belong to the merged list makes the user unsafe
-    const double dm = lane < splits ? pdrop[(size_t)j * splits + lane] : -INFINITY;
+    double dm = lane < splits ? pdrop[(size_t)j * splits + lane] : -INFINITY;
+    if (drop_out) {
+        dm = runner_up > dm ? runner_up : dm;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const double o = __shfl_xor(dm, d, 64); dm = o > dm ? o : dm; }
+        if (lane == 0) drop_out[j] = dm;
+        return;
+    }
     const bool bad = n_out == N ? dm >= T : dm > -INFINITY;
     const bool any_bad = __any(bad || (force_unsafe && (j % 3) == 0));
     if (lane == 0) unsafe[j] = any_bad ? 1 : 0;
@@ -792,7 +1103,7 @@ static int topn_query(mfx_topn_plan &S, const int32_t *pos, const int32_t *label
         int32_t *d_unsafe;
         TOPN_TRY(B.get(&d_unsafe, (size_t)n_sel));
         const char *fu = getenv("MFX_TOPN_FORCE_UNSAFE");          // test hook: every third user goes the long way
-        const char *tv = getenv("MFX_TOPN_KERNEL");                // "strided": the first fused kernel (A/B, tests)
+        const char *tv = getenv("MFX_TOPN_KERNEL");                // "strided": the first fused kernel; "tiled": the vector-f64 tiled kernel (A/B, tests)
         const int force = (fu && fu[0] == '1') ? 1 : 0;
         TOPN_TRY(hipMemsetAsync(d_unsafe, 0, (size_t)n_sel * 4, st));
         // few users: one workgroup per 32 users would walk all candidates alone (4.8 ms for ONE user at 50 K items);
@@ -814,12 +1125,36 @@ static int topn_query(mfx_topn_plan &S, const int32_t *pos, const int32_t *label
             k_topn_fused<<<(n_sel + kUB - 1) / kUB, 256, 0, st>>>(kind, dim, S.dU, dv, S.dib, dubs, S.mu, d_label, n_sel, n_pad, ni,
                                                                    n_cand, N, d_lo, d_lo ? d_lo + n_sel : nullptr, S.d_rated, force,
                                                                    d_items, d_scores, d_unsafe);
+        else if (dim <= kMK && !(tv && tv[0] == 't'))
+        {
+            // scores on the matrix cores (approximate: they only select), then the selected scores again in the reference's order
+            int32_t *a_items;                                       // the merged approximate lists
+            double *a_scores, *a_drop;
+            unsigned long long *d_un2;
+            TOPN_TRY(B.get(&a_items, (size_t)n_sel * N)); TOPN_TRY(B.get(&a_scores, (size_t)n_sel * N)); TOPN_TRY(B.get(&a_drop, (size_t)n_sel));
+            TOPN_TRY(B.get(&d_un2, (size_t)1));
+            TOPN_TRY(hipMemsetAsync(d_un2, 0, 8, st));
+            k_item_norm_max<<<(n_cand + 255) / 256, 256, 0, st>>>(dim, S.dU, ni, n_cand, d_un2);
+            const int n_blk = (n_cand + 31) / 32;
+            if (splits > n_blk) splits = n_blk;
+            if (splits > 1 && !p_drop) TOPN_TRY(B.get(&p_drop, (size_t)n_sel * splits));
+            if (splits > 1) {
+                k_topn_mfma<<<dim3(groups, splits), 256, 0, st>>>(kind, dim, S.dU, dv, S.dib, dubs, S.mu, d_label, n_sel, n_pad, ni, n_cand,
+                                                                  N, d_lo, d_lo ? d_lo + n_sel : nullptr, S.d_rated, p_items, p_scores, p_drop);
+                k_topn_merge<<<n_sel, 64, 0, st>>>(p_items, p_scores, p_drop, splits, N, force, a_items, a_scores, d_unsafe, a_drop);
+            } else {
+                k_topn_mfma<<<dim3(groups, 1), 256, 0, st>>>(kind, dim, S.dU, dv, S.dib, dubs, S.mu, d_label, n_sel, n_pad, ni, n_cand,
+                                                             N, d_lo, d_lo ? d_lo + n_sel : nullptr, S.d_rated, a_items, a_scores, a_drop);
+            }
+            k_topn_exactify<<<n_sel, 64, 0, st>>>(kind, dim, S.dU, dv, S.dib, dubs, S.mu, n_sel, n_pad, ni, N, a_items, a_drop, d_un2, force,
+                                                  d_items, d_scores, d_unsafe);
+        }
         else
         {
             k_topn_tiled<<<dim3(groups, splits), 256, 0, st>>>(kind, dim, S.dU, dv, S.dib, dubs, S.mu, d_label, n_sel, n_pad, ni,
                                                                n_cand, N, d_lo, d_lo ? d_lo + n_sel : nullptr, S.d_rated, force,
                                                                p_items, p_scores, d_unsafe, p_drop);
-            if (splits > 1) k_topn_merge<<<n_sel, 64, 0, st>>>(p_items, p_scores, p_drop, splits, N, force, d_items, d_scores, d_unsafe);
+            if (splits > 1) k_topn_merge<<<n_sel, 64, 0, st>>>(p_items, p_scores, p_drop, splits, N, force, d_items, d_scores, d_unsafe, nullptr);
         }
         TOPN_TRY(hipGetLastError());
         std::vector<int32_t> flag((size_t)n_sel);

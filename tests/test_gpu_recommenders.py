@@ -392,7 +392,7 @@ def test_batched_top_n_equals_the_single_user_ranking():
         G.find_recommended_items_batch([nu], 3)
 
 
-@pytest.mark.parametrize("kernel", ["tiled", "strided"])
+@pytest.mark.parametrize("kernel", ["mfma", "tiled", "strided"])
 def test_fused_top_n_proves_or_falls_back(monkeypatch, kernel):
     """N <= 16 goes through the fused kernel (no score matrix).  It must (a) equal the sort path and the single-user
     ranking, (b) notice when a thread visits more than its three kept slots' worth of the list -- four of the best
@@ -402,7 +402,9 @@ def test_fused_top_n_proves_or_falls_back(monkeypatch, kernel):
     from mfrec_amd import _shim as S
     from mfrec_amd.recommendation import KMFRecommender
 
-    monkeypatch.setenv("MFX_TOPN_KERNEL", kernel)          # LDS-tiled (default) / column-strided fused kernel
+    # matrix-core kernel (the default: approximate scores select, k_topn_exactify restores the reference's bits or flags) /
+    # LDS-tiled vector kernel / column-strided fused kernel
+    monkeypatch.setenv("MFX_TOPN_KERNEL", kernel)
 
     def stats():
         a = (C.c_int64 * 2)()
@@ -432,7 +434,8 @@ def test_fused_top_n_proves_or_falls_back(monkeypatch, kernel):
         monkeypatch.delenv("MFX_TOPN_FORCE_UNSAFE")
         assert stats()[1] - r1 >= (nu + 2) // 3
         assert np.array_equal(fi, ui) and np.array_equal(fs, us)
-    # (b): items 5, 261, 517, 773 are visited by the same thread (stride 256) / lane (stride 64); make them user 9's four best by far
+    # (b): items 5, 261, 517, 773 are visited by the same thread (stride 256) / lane (stride 64) / holder of the matrix-core kernel
+    # (blocks 0, 8, 16, 24 = wave 0, column pair 2); make them user 9's four best by far
     for it in (5, 261, 517, 773):
         R.svd_u[:, it] = 0.0
         R.items_bias[it] = 50.0 + it / 1000.0
@@ -556,3 +559,34 @@ def test_serving_plan_answers_like_the_batch_call():
         with pytest.raises(IndexError):
             plan.query([201], 3)
     assert S.lib().mfx_topn_plan_query(None, None, 0, 1, 1, None, None) != 0
+
+
+def test_matrix_core_top_n_with_long_rated_lists_and_every_predictor(monkeypatch):
+    """k_topn_mfma keeps a user's rated list in LDS up to 192 items and searches global memory beyond that; its scores are
+    approximate and only select -- the rows returned carry the bits of the sort path and of the single-user query for every
+    predictor, also when the best-scored items are exactly the rated (excluded) ones."""
+    from mfrec_amd.recommendation import KMFRecommender
+    nu, ni, k = 40, 2500, 20
+    rs = np.random.RandomState(3)
+    R = KMFRecommender(nu, ni, {"nbr_features": k})
+    users_r = np.concatenate([rs.randint(0, nu, 3000), np.full(400, 7), np.full(193, 8), np.full(192, 9)])
+    items_r = np.concatenate([rs.randint(0, ni, 3000), rs.choice(ni, 400, replace=False), rs.choice(ni, 193, replace=False),
+                              rs.choice(ni, 192, replace=False)])
+    R.set_ratings(np.stack([users_r, items_r], 1), rs.randint(1, 6, users_r.shape[0]).astype(float))
+    R.svd_u, R.svd_v = rs.normal(0, 0.3, (k, ni)), rs.normal(0, 0.3, (k, nu))
+    R.items_bias, R.users_bias, R.overall_bias = rs.normal(0, 0.1, ni), rs.normal(0, 0.1, nu), 3.0
+    for it in np.unique(items_r[users_r == 7])[:60]:          # user 7's best items by far are rated ones: all must be skipped
+        R.items_bias[it] += 30.0
+    R.neighborhood = ni
+    users = list(range(nu))
+    for pred in ("predict_linear", "predict_logistic"):
+        fi, fs = R.find_recommended_items_batch(users, 12, pred)
+        monkeypatch.setenv("MFX_TOPN_FUSED", "0")
+        si, ss = R.find_recommended_items_batch(users, 12, pred)
+        monkeypatch.delenv("MFX_TOPN_FUSED")
+        assert np.array_equal(fi, si) and np.array_equal(fs, ss)
+        rated7 = set(int(x) for x in items_r[users_r == 7])
+        assert not (set(int(x) for x in fi[7]) & rated7)
+        for user in (7, 8, 9, 0):
+            wi, ws = R.find_recommended_items(user_index=user, nbr_recommendations=12, predictor=pred)
+            assert list(fi[user]) == wi and np.array_equal(fs[user], np.array(ws))

@@ -72,6 +72,7 @@ struct mfx_dsgd {
     std::vector<double *> snapV, snapub;                 // [rank of this process]
     std::vector<std::vector<double *>> snapU, snapib;    // [rank of this process][item block]
     int guard = -1;                         // -1: not decided; 1: some block of the JOB runs a resident-side epoch -> snapshot per run call
+    int guard_collective = -1;              // the kind of call (inside a communicator or not) the decision was taken for
 };
 
 
@@ -90,15 +91,19 @@ static bool any_resident(const mfx_dsgd *d)
 // `collective`: the call is one that every rank of the communicator makes together -- the block rotation over real ranks, the averaging
 // mode inside a communicator -- so the ranks can (and must) agree; a one-process object decides for itself
 // decided once (among real ranks: every rank asks in its first run call), cleared for good by a recovery
+// (decided again whenever the KIND of call changes -- a first run outside a communicator, later ones inside one: ranks that decided
+//  alone could disagree on whether the verdict's agreement step runs at all)
 static int dsgd_guard(mfx_dsgd *d, bool collective)
 {
-    if (d->guard >= 0) return MFX_OK;
+    if (d->guard >= 0 && d->guard_collective == (collective ? 1 : 0)) return MFX_OK;
+    if (d->guard == 0 && !collective) { d->guard_collective = 0; return MFX_OK; }     // recovered for good: nothing resident is left
     int g = any_resident(d) ? 1 : 0;
     if (collective) {
         int rc = comm_agree_max(&g);
         if (rc) return rc;
     }
     d->guard = g;
+    d->guard_collective = collective ? 1 : 0;
     return MFX_OK;
 }
 static int dsgd_copy_state(mfx_dsgd *d, bool save)
@@ -134,6 +139,20 @@ static int dsgd_copy_state(mfx_dsgd *d, bool save)
     }
     return MFX_OK;
 }
+// the snapshot step allocates on first use: a rank that cannot must not leave its peers alone in the collectives of the body -- the
+// ranks agree on the outcome first, and every rank takes the error path together
+static int dsgd_snapshot(mfx_dsgd *d, bool collective, const char *what)
+{
+    if (!d->guard) return MFX_OK;
+    const int rc_local = dsgd_copy_state(d, true);
+    if (!collective) return rc_local;
+    int bad = rc_local ? 1 : 0;
+    const int rc = comm_agree_max(&bad);
+    if (rc) return rc;
+    if (rc_local) return rc_local;
+    if (bad) return fail(MFX_E_STATE, "%s: another rank could not take the snapshot of its factors; nothing was run", what);
+    return MFX_OK;
+}
 // after the run's stream syncs: *redo = 1 when some rank of the job lost a co-residency check (every rank then restores and goes to
 // the level schedule); a chain-counter time-out anywhere is an error on every rank
 static int dsgd_verdict(mfx_dsgd *d, bool collective, const char *what, int *redo)
@@ -150,6 +169,19 @@ static int dsgd_verdict(mfx_dsgd *d, bool collective, const char *what, int *red
     if (collective && d->guard != 0 && (rc = comm_agree_max(&worst))) return rc;
     if (worst >= 2) return fail(MFX_E_HIP, "%s: a resident-side block epoch timed out waiting for a chain counter (on this rank or another)", what);
     if (worst == 1) {
+        // a PERMANENT change of schedule for this object: say so once, where a bench log or an operator sees it (the kernel labels
+        // say it too, but only to who asks)
+        {
+            int lost = 0, first = -1;
+            for (DsgdRank &R : d->ranks)
+                for (size_t j = 0; j < R.plans.size(); ++j) {
+                    unsigned st = 0;
+                    if (!sgd_res_poll(R.plans[j], &st) && st == 1) { ++lost; if (first < 0) first = (int)j; }
+                }
+            fprintf(stderr, "[mfx] %s: rank %d: %d block epoch(s) lost the co-residency check on this rank (first: block %d; status 1 = launch "
+                            "not applied)%s -- factors restored, ALL blocks of the job go to the level schedule for good, the call is repeated\n",
+                    what, d->rank < 0 ? 0 : (comm_active() ? comm_rank() : d->rank), lost, first, lost ? "" : " [another rank reported it]");
+        }
         if ((rc = dsgd_copy_state(d, false))) return rc;
         for (DsgdRank &R : d->ranks)
             for (mfx_sgd_plan *p : R.plans) plan_force_levels(p);
@@ -575,7 +607,7 @@ int mfx_dsgd_run_kmf(mfx_dsgd *d, int mode, int nbr_epochs, double lr, double Ku
     int rc, redo = 0;
     const bool collective = d->rank >= 0 && d->world > 1;            // real ranks: every rank is in this call
     if ((rc = dsgd_guard(d, collective))) return rc;
-    if (d->guard && (rc = dsgd_copy_state(d, true))) return rc;
+    if ((rc = dsgd_snapshot(d, collective, "mfx_dsgd_run_kmf"))) return rc;
     if ((rc = dsgd_rotation_body(d, mode, nbr_epochs, lr, Ku, Ki, Kb, se_out))) return rc;
     if ((rc = dsgd_verdict(d, collective, "mfx_dsgd_run_kmf", &redo))) return rc;
     if (redo) rc = dsgd_rotation_body(d, mode, nbr_epochs, lr, Ku, Ki, Kb, se_out);     // every block on the level schedule now
@@ -659,7 +691,7 @@ int mfx_dsgd_run_kmf_averaged(mfx_dsgd *d, int mode, int nbr_epochs, double lr, 
     int rc, redo = 0;
     const bool collective = comm_active() && comm_world() > 1;       // the all-reduces make this call a collective one
     if ((rc = dsgd_guard(d, collective))) return rc;
-    if (d->guard && (rc = dsgd_copy_state(d, true))) return rc;
+    if ((rc = dsgd_snapshot(d, collective, "mfx_dsgd_run_kmf_averaged"))) return rc;
     if ((rc = dsgd_averaged_body(d, mode, nbr_epochs, lr, Ku, Ki, Kb, scale, se_out))) return rc;
     if ((rc = dsgd_verdict(d, collective, "mfx_dsgd_run_kmf_averaged", &redo))) return rc;
     if (redo) rc = dsgd_averaged_body(d, mode, nbr_epochs, lr, Ku, Ki, Kb, scale, se_out);

@@ -954,7 +954,7 @@ int res_enqueue_epoch(ResPlan *rp, int mode, double *U_nk, double *V_nk, double 
     MFX_HIP(hipMemsetAsync(rp->d_ctl + kCtlReg, 0, sizeof(unsigned), stream()));                // registration
     hipLaunchKernelGGL(k_hdr_reset, dim3(ceil_div(rp->n_trav, 256)), dim3(256), 0, stream(), rp->d_hdr, (const double *)tb, rp->n_trav);
     void *args[] = {&P};
-    MFX_HIP(hipLaunchKernel(s.fn, dim3(rp->waves), dim3(64), args, res_lds_bytes(rp->kp, rp->nr), stream()));   // (the dot mode leaves the tile unused)
+    MFX_HIP(hipLaunchKernel(s.fn, dim3(rp->waves), dim3(64), args, res_lds_bytes(rp->kp, rp->nr), stream()));   // (the dot mode parks its per-lane partials in the same tile: tree_sum)
     hipLaunchKernelGGL(k_hdr_finish, dim3(ceil_div(rp->n_trav, 256)), dim3(256), 0, stream(), (const THdr *)rp->d_hdr, tb, rp->n_trav);
     MFX_HIP(hipGetLastError());
     return MFX_OK;

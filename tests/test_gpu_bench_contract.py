@@ -26,6 +26,11 @@ def test_main_line_and_roofline_are_consistent():
                 "vs_baseline", "dtype", "data", "config", "roofline"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["vs_baseline"] is None
+    assert d["scaling"] == "n/a"                            # one GPU: neither weak nor strong
+    # the epoch is a chain of hand-offs: the floor that chain sets is printed beside the byte roofline
+    cf = d["roofline"]
+    assert cf["chain_levels"] == d["config"]["levels"] and cf["min_hop_us"] > 0
+    assert abs(cf["chain_floor_ms"] - cf["chain_levels"] * cf["min_hop_us"] * 1e-3) < 1e-12 and 0 < cf["frac_of_chain_floor"] < 1
     assert d["dtype"] == "f64" and d["data"] == "synthetic" and "cfg2" in d["config"]["workload"]
     assert abs(d["value"] - 10000000 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-9
     r = d["roofline"]
@@ -60,5 +65,6 @@ def test_multi_path_rehearsal_prints_one_line_with_the_exact_leg(monkeypatch):
     assert "cpu_baseline" not in d
     assert d["also"]["dsgd_exact"]["value"] > 0 and "error" not in d["also"]["dsgd_exact"]
     # the averaging `value` carries its RMSE gap to the sequential loop and names the parity-holding mode
+    assert "error" not in d["one_gpu_same_workload"] and d["speedup_vs_one_gpu"] > 0
     g = d["rmse_gap_vs_sequential"]
     assert "error" not in g and g["budget"] == 1e-5 and abs(g["value"]) < 0.5 and "dsgd_exact" in d["parity_mode"]

@@ -371,3 +371,12 @@ def test_bench_plain_invocation_launches_its_own_ranks(mock_lib):
     assert d["also"]["dsgd_exact"]["value"] > 0 and "error" not in d["also"]["dsgd_exact"]
     # the kernel named in the roofline is the one the epoch ran on
     assert ("k1_res" in d["roofline"]["kernel"]) == (d["config"]["epoch_kernel"].startswith("static"))
+    # the line carries its own denominator: the SAME job on rank 0's one GPU, timed in the same run (a driver that divides the
+    # N-GPU value by the N = 1 line's would compare cfg 3 with cfg 2)
+    one = d["one_gpu_same_workload"]
+    assert "error" not in one and one["value"] > 0 and one["unit"] == "rating-updates/s" and one["ms_per_step"] > 0
+    assert abs(d["speedup_vs_one_gpu"] - d["value"] / one["value"]) < 1e-9 * d["speedup_vs_one_gpu"]
+    assert abs(d["also"]["dsgd_exact"]["speedup_vs_one_gpu"] - d["also"]["dsgd_exact"]["value"] / one["value"]) < 1e-6
+    # `value` is the averaging mode: its workload string must not claim the sequential loop's bits (also.dsgd_exact does)
+    assert "bit-identical" not in d["config"]["workload"] and "AVERAGING" in d["config"]["workload"]
+    assert "bit-identical" in d["also"]["dsgd_exact"]["workload"]

@@ -398,6 +398,14 @@ int mfx_dsgd_run_kmf(mfx_dsgd *d, int mode, int nbr_epochs, double learning_rate
  * the communicator of mfx_comm_init (none / world 1: no combine).  se_out (nullable): f64[nbr_epochs], this rank's squared errors. */
 int mfx_dsgd_run_kmf_averaged(mfx_dsgd *d, int mode, int nbr_epochs, double learning_rate, double K_users, double K_items,
                               double K_bias, double scale, double *se_out);
+/* The Funk per-feature loops (estimator_loop_without_bias / _with_bias / _with_bias_dev, gd_estimator.pyx:691-779, :489-685; same
+ * arguments as mfx_sgd_run_funk) on the ITEM-BLOCK order of a one-process object (world = 1): a pass of a feature = the item blocks
+ * one after the other on the one user side, one stopping rule over the whole pass -- the reference's loop on the order
+ * mfx_dsgd_get_order reports, bit for bit.  For catalogues with more items than the resident-side pass has lanes (~450 K): every
+ * block gets the persistent pass.  use_bias: the biases of mfx_dsgd_set_factors are the (read-only) inputs of _with_bias. */
+int mfx_dsgd_run_funk(mfx_dsgd *d, int min_epochs, double min_improvement, double f_init, double learning_rate, double K,
+                      double overall_avg, int use_bias, int update_users, int update_items, int epoch_cap, double *rmse_hist,
+                      int64_t hist_cap, int64_t *n_hist);
 int mfx_dsgd_get_factors(mfx_dsgd *d, double *u, double *v, double *items_bias, double *users_bias);
 
 #ifdef __cplusplus

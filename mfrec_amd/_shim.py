@@ -116,6 +116,8 @@ SIGNATURES = {
     "mfx_dsgd_run_kmf_averaged": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                             C.c_double, C.c_double, _dp]),
     "mfx_dsgd_get_factors": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp]),
+    "mfx_dsgd_run_funk": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, _dp, C.c_int64, _lp]),
 }
 
 _lib = None

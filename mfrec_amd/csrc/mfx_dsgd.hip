@@ -698,6 +698,27 @@ int mfx_dsgd_run_kmf_averaged(mfx_dsgd *d, int mode, int nbr_epochs, double lr, 
     return rc;
 }
 
+// The Funk family (estimator_loop_without_bias / _with_bias / _with_bias_dev, gd_estimator.pyx:691-779, :489-685) on the ITEM-BLOCK
+// order of a ONE-process object (world = 1, or rank = -1 with world = 1 user block): a pass of a feature walks the item blocks one
+// after the other on the one shared user side, so it IS the reference's loop on the order mfx_dsgd_get_order reports, with one
+// stopping rule over the whole pass -- and every block is small enough for the resident-side pass (a lane per item) where the whole
+// catalogue is not (more than ~450 K items).  use_bias: the biases given to mfx_dsgd_set_factors are the inputs of _with_bias.
+int mfx_dsgd_run_funk(mfx_dsgd *d, int min_epochs, double min_improvement, double f_init, double learning_rate, double K,
+                      double overall_avg, int use_bias, int update_users, int update_items, int epoch_cap, double *rmse_hist,
+                      int64_t hist_cap, int64_t *n_hist)
+{
+    TraceRange trace_("mfx:dsgd_run_funk (item-block order)");
+    if (!d) return fail(MFX_E_ARG, "mfx_dsgd_run_funk: NULL");
+    if (d->world != 1 || d->ranks.size() != 1)
+        return fail(MFX_E_ARG, "mfx_dsgd_run_funk: the object must live in one process with ONE user block (created with world = 1)");
+    if (!d->have_factors) return fail(MFX_E_STATE, "mfx_dsgd_run_funk: mfx_dsgd_set_factors has not been called");
+    if (n_hist) *n_hist = 0;
+    DsgdRank &R = d->ranks[0];
+    MFX_HIP(hipStreamSynchronize(d->xfer));
+    return funk_blocks_core(R.plans.data(), (int)R.plans.size(), min_epochs, min_improvement, f_init, learning_rate, K, overall_avg,
+                            use_bias, update_users, update_items, epoch_cap, rmse_hist, hist_cap, n_hist);
+}
+
 // u [k, ni] / items_bias [ni] (nullable): the full item side, gathered from the ranks that hold the
 // blocks (collective: every rank must call).  v / users_bias: as in mfx_dsgd_set_factors.
 int mfx_dsgd_get_factors(mfx_dsgd *d, double *u, double *v, double *items_bias, double *users_bias)

@@ -1089,12 +1089,29 @@ static int enqueue_k2x_pass(mfx_sgd_plan *p, const K2Params &P)
     return enqueue_reduce(p, p->k2x_slots, p->d_se_x);
 }
 
-int funk_core(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_init, double lr,
-              double K, double mu, int use_bias, int upd_u, int upd_i, int epoch_cap,
-              double *rmse_hist, int64_t hist_cap, int64_t *n_hist, const FunkHooks *hk)
+// ---- the Funk run of ONE plan, in the four steps funk_core and funk_blocks_core are made of ------------------------------------
+struct FunkRun {
+    mfx_sgd_plan *p = nullptr;
+    const FunkHooks *hk = nullptr;
+    K2Params P;
+    K2Dyn dyn;
+    bool k2r = false, graph = false;
+    int commit_blocks = 1;
+};
+
+// everything in front of the feature loop: layout, residual cache, the choice of the pass kernel, the captured epoch
+static int funk_setup(FunkRun &R, mfx_sgd_plan *p, double lr, double K, double mu, int use_bias, int upd_u, int upd_i, const FunkHooks *hk,
+                      bool users_km_done = false)
 {
+    R.p = p;
+    R.hk = hk;
     int rc = check_plan(p, "mfx_sgd_run_funk");
     if (rc) return rc;
+    if (users_km_done && !p->km_current) {                    // (a block that shares its user side with a plan already converted)
+        rc = transpose((const double *)p->d_U_nk, p->d_U_km, p->ni, p->k);
+        if (rc) return rc;
+        p->km_current = true;
+    }
     rc = to_km(p);
     if (rc) return rc;
     p->nk_current = false;
@@ -1116,19 +1133,17 @@ int funk_core(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_
             if (p->res2) { p->k2r_state = 1; p->dev_bytes += res2_dev_bytes(p->res2); }
         }
     }
-    bool k2r = !hk && p->k2r_state == 1;
+    R.k2r = !hk && p->k2r_state == 1;
     // may re-order the ratings inside their levels: before the cache is used.  The XCD-resident pass is an optional
     // acceleration: if its preparation fails (scratch memory, attribute), the records are either untouched or fully
     // re-ordered inside their levels -- both are valid inputs of the launch path -- so the run goes on there
-    if (!k2r && ensure_k2x(p) != MFX_OK) {
+    if (!R.k2r && ensure_k2x(p) != MFX_OK) {
         (void)hipGetLastError();
         p->k2x_state = -1;
     }
     MFX_HIP(hipMemsetAsync(p->d_cache, 0, (size_t)(p->nnz ? p->nnz : 1) * sizeof(double), stream()));
-    if (k2r && (rc = res2_reset_cache(p->res2))) return rc;
-    double rmse = 2.0, rmse_last = 0.0;
-    int64_t nh = 0;
-    K2Params P;
+    if (R.k2r && (rc = res2_reset_cache(p->res2))) return rc;
+    K2Params &P = R.P;
     memset(&P, 0, sizeof(P));
     P.recs = p->d_recs;
     P.dyn = p->d_k2dyn;
@@ -1141,12 +1156,12 @@ int funk_core(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_
     P.mu = mu;
     P.upd_u = upd_u ? 1 : 0;
     P.upd_i = upd_i ? 1 : 0;
-    const int commit_blocks = (int)(p->nnz ? (ceil_div(p->nnz, (int64_t)256) < 4096 ? ceil_div(p->nnz, (int64_t)256) : 4096) : 1);
+    R.commit_blocks = (int)(p->nnz ? (ceil_div(p->nnz, (int64_t)256) < 4096 ? ceil_div(p->nnz, (int64_t)256) : 4096) : 1);
 
     // one epoch = all levels + the SE reduction, captured once and replayed for every
     // (feature, epoch): the per-feature pointers live behind P.dyn
-    const bool graph = use_graph() && p->segs2.size() <= kMaxGraphNodes;
-    if (graph && !k2r && !(p->graph2 && memcmp(&p->graph2_params, &P, sizeof(P)) == 0)) {
+    R.graph = use_graph() && p->segs2.size() <= kMaxGraphNodes;
+    if (R.graph && !R.k2r && !(p->graph2 && memcmp(&p->graph2_params, &P, sizeof(P)) == 0)) {
         if (p->graph2) (void)hipGraphExecDestroy(p->graph2);
         p->graph2 = nullptr;
         hipGraph_t g = nullptr;
@@ -1165,13 +1180,111 @@ int funk_core(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_
         }
         p->graph2_params = P;
     }
+    return MFX_OK;
+}
+
+// the per-feature pointers behind P.dyn (enqueue + sync: `dyn` is a host object)
+static int funk_set_feature(FunkRun &R, int f, double f_init)
+{
+    mfx_sgd_plan *p = R.p;
+    R.dyn.uf = p->d_U_km + (size_t)f * p->ni;
+    R.dyn.vf = p->d_V_km + (size_t)f * p->nu;
+    R.dyn.trail = (p->k - f - 1) * f_init * f_init;        // gd_estimator.pyx:70
+    MFX_HIP(hipMemcpyAsync(p->d_k2dyn, &R.dyn, sizeof(R.dyn), hipMemcpyHostToDevice, stream()));
+    MFX_HIP(hipStreamSynchronize(stream()));
+    return MFX_OK;
+}
+
+// `batch` (<= 32) passes of the current feature, enqueued back to back; their squared errors in se_b.  A persistent form that loses its
+// residency check has modified nothing from that pass on: the plan moves to the next form for good and the rest of the batch is redone.
+static int funk_passes(FunkRun &R, int batch, double *se_b)
+{
+    mfx_sgd_plan *p = R.p;
+    const FunkHooks *hk = R.hk;
+    K2Params &P = R.P;
+    int rc;
+    int b0 = 0;                 // passes of this batch already applied (by the resident-side pass, before a fall-back)
+    for (;;) {
+        if (R.k2r) {
+            // ---- resident-side pass: granules, one persistent launch over every CU, values back, reduction ----
+            MFX_HIP(hipMemsetAsync(p->d_counter, 0, sizeof(int), stream()));
+            if ((rc = res2_begin_batch(p->res2))) return rc;
+            for (int b = 0; b < batch; ++b) {
+                if ((rc = res2_enqueue_pass(p->res2, p->d_k2dyn, P.ib, P.ub, P.mu, P.lr, P.K, P.upd_u, P.upd_i))) return rc;
+                if ((rc = enqueue_reduce(p, res2_se_slots(p->res2), res2_se_partials(p->res2)))) return rc;
+            }
+            MFX_HIP(hipMemcpyAsync(se_b, p->d_se_epoch, (size_t)batch * sizeof(double), hipMemcpyDeviceToHost, stream()));
+            MFX_HIP(hipStreamSynchronize(stream()));
+            unsigned status = 0, applied = 0;
+            if ((rc = res2_status(p->res2, &status, &applied))) return rc;
+            if (status == 0) break;
+            if (status != 1) return fail(MFX_E_HIP, "mfx_sgd_run_funk: the resident-side pass timed out waiting for a granule");
+            // a pass found its grid not co-resident: the first `applied` passes of the batch ran in full, that one and the
+            // later ones did NOTHING.  The residual cache moves to the level-major layout and the run goes on, for good, with
+            // one launch per level -- from the first pass that was not applied.
+            if ((rc = res2_cache_to_levels(p->res2, p->d_cache))) return rc;
+            p->k2r_state = -1;
+            R.k2r = false;
+            if (p->k2x_state == 0) p->k2x_state = -1;       // (its preparation would re-order records the cache now follows)
+            b0 = (int)applied < batch ? (int)applied : batch;
+            if (b0 == batch) break;
+            continue;
+        }
+        const bool xcd = p->k2x_state == 1;
+        MFX_HIP(hipMemcpyAsync(p->d_counter, &b0, sizeof(int), hipMemcpyHostToDevice, stream()));   // squared errors b0 .. batch-1
+        if (xcd) MFX_HIP(hipMemsetAsync(p->d_xctl + 512, 0, sizeof(unsigned), stream()));   // status: sticky inside a batch
+        for (int b = b0; b < batch; ++b) {
+            if (hk && (rc = hk->pre(hk->ctx, R.dyn.uf, p->ni))) return rc;
+            if (xcd) rc = enqueue_k2x_pass(p, P);
+            else if (R.graph && p->graph2) {
+                MFX_HIP(hipGraphLaunch(p->graph2, stream()));
+                rc = MFX_OK;
+            } else rc = enqueue_k2_epoch(p, P);
+            if (rc) return rc;
+        }
+        unsigned status = 0;
+        if (xcd) MFX_HIP(hipMemcpyAsync(&status, p->d_xctl + 512, sizeof(unsigned), hipMemcpyDeviceToHost, stream()));
+        if (!xcd && hk && (rc = hk->post(hk->ctx, R.dyn.uf, p->ni))) return rc;
+        MFX_HIP(hipMemcpyAsync(se_b, p->d_se_epoch, (size_t)batch * sizeof(double), hipMemcpyDeviceToHost, stream()));
+        MFX_HIP(hipStreamSynchronize(stream()));
+        if (!xcd) break;
+        if (status == 0) {
+            if (hk) {
+                if ((rc = hk->post(hk->ctx, R.dyn.uf, p->ni))) return rc;
+                MFX_HIP(hipStreamSynchronize(stream()));
+            }
+            break;
+        }
+        if (status == 3)
+            return fail(MFX_E_HIP, "mfx_sgd_run_funk: the XCD-resident pass lost a workgroup mid-pass");
+        // registration failed or LDS too small: NOTHING was modified (the status is sticky: the later
+        // passes of the batch left at once) -- redo the batch on the launch path, and stay there
+        p->k2x_state = -1;
+    }
+    return MFX_OK;
+}
+
+// the cache-commit pass of the finished feature (gd_estimator.pyx:771-777)
+static int funk_commit(FunkRun &R)
+{
+    mfx_sgd_plan *p = R.p;
+    if (R.k2r) return res2_enqueue_commit(p->res2, p->d_k2dyn, R.P.ib, R.P.ub, R.P.mu);
+    hipLaunchKernelGGL(k2_commit, dim3(R.commit_blocks), dim3(256), 0, stream(), R.P, p->nnz);
+    MFX_HIP(hipGetLastError());
+    return MFX_OK;
+}
+
+int funk_core(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_init, double lr,
+              double K, double mu, int use_bias, int upd_u, int upd_i, int epoch_cap,
+              double *rmse_hist, int64_t hist_cap, int64_t *n_hist, const FunkHooks *hk)
+{
+    FunkRun R;
+    int rc = funk_setup(R, p, lr, K, mu, use_bias, upd_u, upd_i, hk);
+    if (rc) return rc;
+    double rmse = 2.0, rmse_last = 0.0;
+    int64_t nh = 0;
     for (int f = 0; f < p->k; ++f) {
-        K2Dyn dyn;
-        dyn.uf = p->d_U_km + (size_t)f * p->ni;
-        dyn.vf = p->d_V_km + (size_t)f * p->nu;
-        dyn.trail = (p->k - f - 1) * f_init * f_init;        // gd_estimator.pyx:70
-        MFX_HIP(hipMemcpyAsync(p->d_k2dyn, &dyn, sizeof(dyn), hipMemcpyHostToDevice, stream()));
-        MFX_HIP(hipStreamSynchronize(stream()));             // `dyn` is a stack object
+        if ((rc = funk_set_feature(R, f, f_init))) return rc;
         int epoch = 0;
         while (epoch < min_epochs || rmse <= rmse_last - min_improvement) {
             if (epoch_cap > 0 && epoch >= epoch_cap) break;
@@ -1186,64 +1299,7 @@ int funk_core(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_
             }
             double se_b[32];
             double nn = (double)p->nnz;
-            int b0 = 0;                 // passes of this batch already applied (by the resident-side pass, before a fall-back)
-            for (;;) {
-                if (k2r) {
-                    // ---- resident-side pass: granules, one persistent launch over every CU, values back, reduction ----
-                    MFX_HIP(hipMemsetAsync(p->d_counter, 0, sizeof(int), stream()));
-                    if ((rc = res2_begin_batch(p->res2))) return rc;
-                    for (int b = 0; b < batch; ++b) {
-                        if ((rc = res2_enqueue_pass(p->res2, p->d_k2dyn, P.ib, P.ub, P.mu, P.lr, P.K, P.upd_u, P.upd_i))) return rc;
-                        if ((rc = enqueue_reduce(p, res2_se_slots(p->res2), res2_se_partials(p->res2)))) return rc;
-                    }
-                    MFX_HIP(hipMemcpyAsync(se_b, p->d_se_epoch, (size_t)batch * sizeof(double), hipMemcpyDeviceToHost, stream()));
-                    MFX_HIP(hipStreamSynchronize(stream()));
-                    unsigned status = 0, applied = 0;
-                    if ((rc = res2_status(p->res2, &status, &applied))) return rc;
-                    if (status == 0) break;
-                    if (status != 1) return fail(MFX_E_HIP, "mfx_sgd_run_funk: the resident-side pass timed out waiting for a granule");
-                    // a pass found its grid not co-resident: the first `applied` passes of the batch ran in full, that one and the
-                    // later ones did NOTHING.  The residual cache moves to the level-major layout and the run goes on, for good, with
-                    // one launch per level -- from the first pass that was not applied.
-                    if ((rc = res2_cache_to_levels(p->res2, p->d_cache))) return rc;
-                    p->k2r_state = -1;
-                    k2r = false;
-                    if (p->k2x_state == 0) p->k2x_state = -1;       // (its preparation would re-order records the cache now follows)
-                    b0 = (int)applied < batch ? (int)applied : batch;
-                    if (b0 == batch) break;
-                    continue;
-                }
-                const bool xcd = p->k2x_state == 1;
-                MFX_HIP(hipMemcpyAsync(p->d_counter, &b0, sizeof(int), hipMemcpyHostToDevice, stream()));   // squared errors b0 .. batch-1
-                if (xcd) MFX_HIP(hipMemsetAsync(p->d_xctl + 512, 0, sizeof(unsigned), stream()));   // status: sticky inside a batch
-                for (int b = b0; b < batch; ++b) {
-                    if (hk && (rc = hk->pre(hk->ctx, dyn.uf, p->ni))) return rc;
-                    if (xcd) rc = enqueue_k2x_pass(p, P);
-                    else if (graph && p->graph2) {
-                        MFX_HIP(hipGraphLaunch(p->graph2, stream()));
-                        rc = MFX_OK;
-                    } else rc = enqueue_k2_epoch(p, P);
-                    if (rc) return rc;
-                }
-                unsigned status = 0;
-                if (xcd) MFX_HIP(hipMemcpyAsync(&status, p->d_xctl + 512, sizeof(unsigned), hipMemcpyDeviceToHost, stream()));
-                if (!xcd && hk && (rc = hk->post(hk->ctx, dyn.uf, p->ni))) return rc;
-                MFX_HIP(hipMemcpyAsync(se_b, p->d_se_epoch, (size_t)batch * sizeof(double), hipMemcpyDeviceToHost, stream()));
-                MFX_HIP(hipStreamSynchronize(stream()));
-                if (!xcd) break;
-                if (status == 0) {
-                    if (hk) {
-                        if ((rc = hk->post(hk->ctx, dyn.uf, p->ni))) return rc;
-                        MFX_HIP(hipStreamSynchronize(stream()));
-                    }
-                    break;
-                }
-                if (status == 3)
-                    return fail(MFX_E_HIP, "mfx_sgd_run_funk: the XCD-resident pass lost a workgroup mid-pass");
-                // registration failed or LDS too small: NOTHING was modified (the status is sticky: the later
-                // passes of the batch left at once) -- redo the batch on the launch path, and stay there
-                p->k2x_state = -1;
-            }
+            if ((rc = funk_passes(R, batch, se_b))) return rc;
             for (int b = 0; b < batch; ++b) {
                 double se = se_b[b];
                 if (hk && (rc = hk->global_se(hk->ctx, &se, &nn))) return rc;
@@ -1254,13 +1310,69 @@ int funk_core(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_
                 ++epoch;
             }
         }
-        if (k2r) {
-            if ((rc = res2_enqueue_commit(p->res2, p->d_k2dyn, P.ib, P.ub, P.mu))) return rc;
-        } else {
-            hipLaunchKernelGGL(k2_commit, dim3(commit_blocks), dim3(256), 0, stream(), P, p->nnz);
-            MFX_HIP(hipGetLastError());
-        }
+        if ((rc = funk_commit(R))) return rc;
     }
+    MFX_HIP(hipStreamSynchronize(stream()));
+    if (n_hist) *n_hist = nh;
+    return MFX_OK;
+}
+
+// The Funk run on an ITEM-BLOCK order (round 5): plans[j] holds the ratings of item block j (item ids local to the block) and all of
+// them share ONE user side (plan_alias_users: mfx_dsgd_create with world = 1).  A pass of feature f is the sequential loop over
+// block 0's ratings, then block 1's, ...: block j's pass reads and writes the SAME V[f,:] the block before left -- i.e. the
+// reference's loop (gd_estimator.pyx:691-779) on the order "blocks one after the other, every block in its own order", with ONE
+// stopping rule over the whole pass (the squared errors of the blocks are added in block order).  Every block is small enough for the
+// resident-side pass (a lane per item: k2_res_box) where the whole catalogue is not (more than ~450 K items: BASELINE cfg 5's 1 M).
+int funk_blocks_core(mfx_sgd_plan *const *plans, int B, int min_epochs, double min_improvement, double f_init, double lr, double K,
+                     double mu, int use_bias, int upd_u, int upd_i, int epoch_cap, double *rmse_hist, int64_t hist_cap, int64_t *n_hist)
+{
+    if (!plans || B < 1) return fail(MFX_E_ARG, "mfx_dsgd_run_funk: no blocks");
+    for (int j = 0; j < B; ++j) {
+        int rc = check_plan(plans[j], "mfx_dsgd_run_funk");
+        if (rc) return rc;
+        if (plans[j]->k != plans[0]->k || plans[j]->nu != plans[0]->nu || plans[j]->f32 ||
+            (j > 0 && (plans[j]->d_V_km != plans[0]->d_V_km || plans[j]->d_V_nk != plans[0]->d_V_nk)))
+            return fail(MFX_E_ARG, "mfx_dsgd_run_funk: the blocks must share one f64 user side");
+    }
+    std::vector<FunkRun> R((size_t)B);
+    int rc;
+    int64_t nnz = 0;
+    for (int j = 0; j < B; ++j) {
+        // the shared user side is converted to the feature-major layout ONCE, by block 0
+        if ((rc = funk_setup(R[(size_t)j], plans[j], lr, K, mu, use_bias, upd_u, upd_i, nullptr, j > 0))) return rc;
+        nnz += plans[j]->nnz;
+    }
+    const int k = plans[0]->k;
+    double rmse = 2.0, rmse_last = 0.0;
+    int64_t nh = 0;
+    for (int f = 0; f < k; ++f) {
+        for (int j = 0; j < B; ++j)
+            if ((rc = funk_set_feature(R[(size_t)j], f, f_init))) return rc;
+        int epoch = 0;
+        while (epoch < min_epochs || rmse <= rmse_last - min_improvement) {
+            if (epoch_cap > 0 && epoch >= epoch_cap) break;
+            double se = 0.0;
+            for (int j = 0; j < B; ++j) {                     // one pass = the blocks one after the other on the library stream
+                double sj = 0.0;
+                if ((rc = funk_passes(R[(size_t)j], 1, &sj))) return rc;
+                se += sj;
+            }
+            rmse_last = rmse;
+            rmse = sqrt(se / (double)nnz);
+            if (rmse_hist && nh < hist_cap) rmse_hist[nh] = rmse;
+            ++nh;
+            ++epoch;
+        }
+        for (int j = 0; j < B; ++j)
+            if ((rc = funk_commit(R[(size_t)j]))) return rc;
+    }
+    // back to the row-major copies the block object keeps live (plan_mark_ready): every block's items, the shared user side once
+    for (int j = 0; j < B; ++j) {
+        if ((rc = transpose(plans[j]->d_U_km, plans[j]->d_U_nk, k, plans[j]->ni))) return rc;
+        plans[j]->nk_current = true;
+        plans[j]->km_current = false;
+    }
+    if ((rc = transpose(plans[0]->d_V_km, plans[0]->d_V_nk, k, plans[0]->nu))) return rc;
     MFX_HIP(hipStreamSynchronize(stream()));
     if (n_hist) *n_hist = nh;
     return MFX_OK;

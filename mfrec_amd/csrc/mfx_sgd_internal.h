@@ -106,6 +106,9 @@ struct FunkHooks {
 int funk_core(mfx_sgd_plan *p, int min_epochs, double min_improvement, double f_init, double lr,
               double K, double mu, int use_bias, int upd_u, int upd_i, int epoch_cap,
               double *rmse_hist, int64_t hist_cap, int64_t *n_hist, const FunkHooks *hk);
+// the same run over item blocks that share one user side, a pass = the blocks one after the other (mfx_dsgd_run_funk)
+int funk_blocks_core(mfx_sgd_plan *const *plans, int B, int min_epochs, double min_improvement, double f_init, double lr, double K,
+                     double mu, int use_bias, int upd_u, int upd_i, int epoch_cap, double *rmse_hist, int64_t hist_cap, int64_t *n_hist);
 
 // ---- communicator (mfx_comm.hip) -----------------------------------------------------------
 bool comm_active();

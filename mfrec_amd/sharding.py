@@ -227,6 +227,21 @@ class DsgdKMF(object):
                                                   float(K_items), float(K_bias), float(scale), S.f64(se, "se", 1)))
         return se[:int(nbr_epochs)]
 
+    def train_funk(self, min_epochs, min_improvement, f_init, learning_rate, K, overall_avg=1.0, use_bias=False,
+                   update_users=True, update_items=True, epoch_cap=0):
+        """world = 1 objects only: the Funk per-feature loops (estimator_loop_without_bias / _with_bias[_dev]) on the item-block order
+        -- a pass of a feature = the blocks one after the other (mfx_dsgd_run_funk).  -> f64[] RMSE after every (feature, epoch)."""
+        import ctypes as C
+        from . import _shim as S
+        cap = max(1, self.k * max(int(min_epochs), int(epoch_cap), 64))
+        for _ in range(2):
+            hist = np.zeros(cap)
+            n = C.c_int64(0)
+            S.check(S.lib().mfx_dsgd_run_funk(self._h, int(min_epochs), float(min_improvement), float(f_init), float(learning_rate),
+                                              float(K), float(overall_avg), 1 if use_bias else 0, 1 if update_users else 0,
+                                              1 if update_items else 0, int(epoch_cap), S.f64(hist, "rmse_hist", 1), cap, C.byref(n)))
+            return hist[:min(int(n.value), cap)]
+
     def get_factors(self, u, v, items_bias=None, users_bias=None):
         from . import _shim as S
         S.check(S.lib().mfx_dsgd_get_factors(self._h, *self._args(u, v, items_bias, users_bias)))
@@ -346,6 +361,36 @@ def one_gpu_block_counts(nbr_users, nbr_items, dim):
     rows = max(1, int((ROWS_PER_BLOCK_ALONE if ub == 1 and ROWS_PER_BLOCK == 42000 else ROWS_PER_BLOCK) * 64 // max(int(dim), 64)))
     nb = max(1, -(-int(nbr_items) // rows))
     return ub, -(-nb // ub) * ub
+
+
+FUNK_ITEMS_PER_BLOCK = 400000        # a lane per item of the resident-side Funk pass: ~450 K lanes at 7 / 8 of the chip
+
+
+def funk_block_order(min_epochs, max_epochs, min_improvement, dim, feature_init, learning_rate, K, u, v, ratings_index, ratings,
+                     nbr_users, nbr_items, overall_avg=None, items_bias=None, users_bias=None, update_users=True, update_items=True,
+                     item_blocks=None, epoch_cap=0):
+    """estimator_loop_without_bias (gd_estimator.pyx:691-779; with items_bias / users_bias given: estimator_loop_with_bias[_dev],
+    :489-685 -- same positional meaning, max_epochs ignored as the reference ignores it) on ONE GPU on the ITEM-BLOCK order: the
+    given ratings grouped by item block (stable), a pass of a feature = block 0's ratings, then block 1's, ... on the one user side.
+    For catalogues with more items than the resident-side pass has lanes (BASELINE cfg 5: 1 M items): every block of <= 400 K
+    items gets the persistent pass instead of the whole problem falling to one launch per dependency level.  Bit-identical to the
+    sequential loop ON THAT ORDER, which is returned (int64 perm) with the RMSE history: (perm, rmse_hist).  u [k, ni], v [k, nu]
+    are updated in place."""
+    nb = int(item_blocks) if item_blocks else max(1, -(-int(nbr_items) // FUNK_ITEMS_PER_BLOCK))
+    d = DsgdKMF(ratings_index, ratings, nbr_users, nbr_items, dim, -1, 1, item_blocks_1gpu=nb)
+    try:
+        use_bias = items_bias is not None
+        if overall_avg is None:
+            if use_bias:
+                raise ValueError("funk_block_order: overall_avg is needed with biases (estimator_loop_with_bias)")
+            overall_avg = 1.0                                   # gd_estimator.pyx:750: an empty cache counts as 1.0
+        d.set_factors(u, v, items_bias, users_bias)
+        hist = d.train_funk(min_epochs, min_improvement, feature_init, learning_rate, K, overall_avg, use_bias,
+                            update_users, update_items, epoch_cap)
+        d.get_factors(u, v)
+        return d.order(), hist
+    finally:
+        d.close()
 
 
 def kmf_train_block_order(mode, nbr_epochs, dim, learning_rate, K_users, K_items, K_bias, u, v, ratings_index, ratings,

@@ -335,3 +335,24 @@ def test_cfg5_whole_one_gpu_properties():
         pinfo = p.info()
     assert pinfo["schedule_builder"] == "device" and pinfo["n_levels"] == nl.value
     assert pinfo["max_level"] == int(np.bincount(lev).max())
+
+
+def test_funk_on_a_one_million_item_catalogue_block_order_bitexact():
+    """BASELINE cfg 5's item side (1 M items: more than the resident-side Funk pass has lanes) with 2 M users and 40 M ratings, k = 2
+    features x 2 epochs: sharding.funk_block_order cuts the catalogue into blocks of <= 400 K items, every block takes the
+    persistent pass, a pass of a feature = the blocks one after the other on the one user side -- bit for bit the oracle's
+    estimator_loop_without_bias (gd_estimator.pyx:691-779) on the order the object reports, RMSE history included."""
+    from mfrec_amd import sharding as SH
+    from oracle import oracle as O
+    nu, ni, nnz, k = 2000000, 1000000, 40000000, 2
+    idx, r = synth.make_ratings(nu, ni, nnz)
+    u, v = synth.init_const(k, ni), synth.init_const(k, nu)
+    perm, hist = SH.funk_block_order(2, 2, 1e9, k, 0.1, 0.001, 0.05, u, v, idx, r, nu, ni)
+    assert len(hist) == 2 * k
+    ip, rp = np.ascontiguousarray(idx[perm]), np.ascontiguousarray(r[perm])
+    del idx, r, perm
+    u2, v2 = synth.init_const(k, ni), synth.init_const(k, nu)
+    h2 = np.zeros(16)
+    n2 = O.estimator_loop_without_bias(2, 2, 1e9, k, 0.1, 0.001, 0.05, u2, v2, ip, rp, nu, ni, rmse_hist=h2)
+    assert n2 == 2 * k and np.allclose(hist, h2[:n2], rtol=1e-12, atol=0)
+    assert np.array_equal(u, u2) and np.array_equal(v, v2)

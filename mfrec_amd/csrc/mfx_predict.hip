@@ -780,6 +780,9 @@ __global__ __launch_bounds__(256, 2) void k_topn_mfma(int kind, int k, const dou
                 case 3: p = a + mu + (bi + bu[s]); break;
                 default: p = a; break;
                 }
+                // fast reject: nothing below both the lane's weakest kept entry and its best dropped score changes the bookkeeping (a NaN
+                // compares false and is never listed anyway); the two special values keep their way through the rules below
+                if (!(p > (ks[s][kTM - 1] < dropped[s] ? ks[s][kTM - 1] : dropped[s])) && p != -INFINITY && !(p == 0.0 && a != 0.0)) continue;
                 if (p != p || p == 0.0) {                                    // never listed (mf.py:162,176-182) -- if the EXACT score says so too:
                     if (p == 0.0 && a != 0.0) dropped[s] = INFINITY;         // a sum that cancels to zero here need not in the reference's order
                     continue;

@@ -658,10 +658,7 @@ __device__ __forceinline__ void als_rows3_body(const double *__restrict__ Y, int
             acc[s][q] = from_g ? G[r * KP + c] * inv_c : 0.0;
         }
     }
-    constexpr int NBS = (512 % KP == 0) ? 1 : PF / 2;
-    double2 bs2[NBS];
-#pragma unroll
-    for (int i = 0; i < NBS; ++i) bs2[i] = make_double2(0.0, 0.0);
+    double bsum = 0.0;
 
     ALS_STAMP(0);
     ALS_STAMP_WHERE();
@@ -704,10 +701,6 @@ __device__ __forceinline__ void als_rows3_body(const double *__restrict__ Y, int
         for (int i = 0; i < PF2; ++i) {
             const int e = 2 * (tid + 256 * i), n = e / KP, f = e % KP;
             *reinterpret_cast<double2 *>(ych + n * S + f) = pre[i];
-            // b: every thread sums the rows it moves (one feature pair: e % KP does not depend on i when 512 % KP == 0, and the
-            // partial sums are kept per i otherwise); the threads of a pair meet in LDS below
-            bs2[(512 % KP == 0) ? 0 : i].x += pre[i].x;
-            bs2[(512 % KP == 0) ? 0 : i].y += pre[i].y;
         }
         const int nb = ((c + 1) & 1) * CH2;
         if (tid < CH2) cidx[nb + tid] = cnext;
@@ -718,20 +711,17 @@ __device__ __forceinline__ void als_rows3_body(const double *__restrict__ Y, int
             const int t2 = (c + 2) * CH2 + tid;
             cnext = (tid < CH2 && t2 < span) ? col[start + t2] : -1;
         }
-        // a ragged last chunk (span = 100: 4 valid rows of 32) skips its all-zero 4-row steps; a full chunk runs straight-line code, so
-        // that the operand loads of a 4-row step are issued under the matrix instructions of the step before
+        if (tid < KP && !ALS_KO(KO_BSUM)) {
+#pragma unroll
+            for (int n = 0; n < CH2; ++n) bsum += ych[n * S + tid] * one_plus_c;
+        }
+        // a ragged last chunk (span = 100: 4 valid rows of 32) skips its all-zero 4-row steps
+        // (round 5: `b` summed from the gather registers and straight-line 4-row steps for full chunks were measured here -- 27 against
+        //  18 ms: the kernel sits at 165 of its 168 registers and any addition spills; profiles/r05_als_diagnosis.md)
         const int nv = span - c * CH2, nv4 = nv >= CH2 ? CH2 : ((nv + 3) & ~3);
-        if (ALS_KO(KO_SYRK)) {
-        } else if (nv4 == CH2) {
 #pragma unroll
-            for (int n0 = 0; n0 < CH2; n0 += 4) {
-                const double *base = ych + (n0 + (lane >> 4)) * S + (lane & 15);
-#pragma unroll
-                for (int s = 0; s < TS; ++s)
-                    acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(base[sI(s) * 16], base[sJ(s) * 16], acc[s], 0, 0, 0);
-            }
-        } else {
-            for (int n0 = 0; n0 < nv4; n0 += 4) {
+        for (int n0 = 0; n0 < CH2; n0 += 4) {
+            if (n0 < nv4 && !ALS_KO(KO_SYRK)) {                   // wave-uniform
                 const double *base = ych + (n0 + (lane >> 4)) * S + (lane & 15);
 #pragma unroll
                 for (int s = 0; s < TS; ++s)
@@ -758,20 +748,7 @@ __device__ __forceinline__ void als_rows3_body(const double *__restrict__ Y, int
             acc[s][q] = a;
         }
     }
-    {   // b = (1 + c) * sum: the partial sums of the threads that moved the same feature pair meet in the (free) staging area
-        double *part = ych;                                      // [256 * NBS] pairs, read back by feature
-#pragma unroll
-        for (int i = 0; i < NBS; ++i) *reinterpret_cast<double2 *>(part + 2 * (tid + 256 * i)) = bs2[i];
-        __syncthreads();
-        if (tid < KP) {
-            // element e = 2 (t + 256 i) belongs to feature pair (e % KP) / 2: t' = (tid / 2) + (KP / 2) m over all stored partials
-            double sum = 0.0;
-            constexpr int NP = 256 * NBS;                        // stored pairs
-            for (int p = tid >> 1; p < NP; p += KP / 2) sum += part[2 * p + (tid & 1)];
-            bz[tid] = (tid < k) ? sum * one_plus_c : 0.0;
-        }
-        __syncthreads();                                         // the staging area becomes Xs / Dg
-    }
+    if (tid < KP) bz[tid] = (tid < k) ? bsum : 0.0;
 
     auto wave_sync = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1307,7 +1284,6 @@ AlsKernels als_kernels_nt()
         // kernel fits anyway and the uncapped schedule measured 4 % faster
         const char *o = getenv("MFX_ALS_OCC");
         const bool occ3 = o ? o[0] == '3' : NT == 8;
-        if (o && o[0] == '4') return {(void *)k_gram_partial<NT>, (void *)k_als_rows3<NT, 4>, 4, true};
         if (!occ3) return {(void *)k_gram_partial<NT>, (void *)k_als_rows3<NT, 2>, 4, true};
         return {(void *)k_gram_partial<NT>, (void *)k_als_rows3<NT, 3>, 4, true};
     } else {                                                  // NT = 3, 4

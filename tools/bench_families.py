@@ -12,6 +12,8 @@ import numpy as np  # noqa: E402
 import scipy.sparse as sp  # noqa: E402
 
 from mfrec_amd import _shim as S, synth  # noqa: E402
+if os.environ.get("MFX_LIB"):
+    S.LIB_PATH = os.environ["MFX_LIB"]
 from mfrec_amd.plan import SgdPlan, Timer  # noqa: E402
 
 

@@ -642,16 +642,23 @@ __global__ __launch_bounds__(256) void k_topn_tiled(int kind, int k, const doubl
 // approximate scores, 2 (k + 4) 2^-53 (||u||_max ||v_user|| + |biases|) -- so a flagged-or-exact result, as before.
 constexpr int kMK = 128;                            // features held in LDS (k <= kMK; more: k_topn_tiled)
 constexpr int kVS = 48;                             // row stride of the user tile: 32 users + pad (A operand reads conflict-free)
-constexpr int kRL = 192;                            // rated items per user kept in LDS
+constexpr int kRL = 176;                            // rated items per user kept in LDS
 typedef double double4_mf __attribute__((ext_vector_type(4)));
 typedef double v2f64_u8 __attribute__((ext_vector_type(2), aligned(8)));
 
+#ifdef MFX_TOPN_KO
+// diagnostic build only (tools/r05_topn_ko.sh): knock single phases out of k_topn_mfma to price them; results are garbage
+__device__ int g_topn_ko = 0;
+#define TOPN_KO(bit) (g_topn_ko & (bit))
+#else
+#define TOPN_KO(bit) 0
+#endif
 __global__ __launch_bounds__(256, 2) void k_topn_mfma(int kind, int k, const double *__restrict__ u,
                                                       const double *__restrict__ vs, const double *__restrict__ ib,
                                                       const double *__restrict__ sub, double mu,
                                                       const int32_t *__restrict__ users, int n_sel, int n_pad, int ni,
                                                       int n_cand, int N, const int64_t *__restrict__ off, const int64_t *__restrict__ off_hi,
-                                                      const int32_t *__restrict__ rated,
+                                                      const int32_t *__restrict__ rated, const unsigned long long *__restrict__ unorm2_max,
                                                       int32_t *out_items, double *out_scores, double *pdrop)
 {
     // LDS: the user tile while the candidates are walked; the holders' kept lists of 16 users at a time afterwards
@@ -685,6 +692,16 @@ __global__ __launch_bounds__(256, 2) void k_topn_mfma(int kind, int k, const dou
         if (lane == 0) rn[q] = n;
     }
     __shared__ unsigned rmask[4][32];                                        // per wave: bit i of [q] = item i0 + i of the block is rated by user q
+    // THE USER'S BAR.  A lane's own bookkeeping rejects what lies below ITS weakest dropped score, but a user's scores sit in 64 holders
+    // (16 lanes x 4 waves): with 64 lanes per wave SOME lane took the slow path in 59 % of the (item, user) steps and the selection cost
+    // as much as the matrix instructions (knock-outs, profiles/r05_topn_knockouts.txt).  After 4, 8, 16, ... blocks per wave the
+    // workgroup therefore takes, per user, the N-th largest of the 64 holders' BEST kept scores -- N distinct candidates score at least
+    // that, so nothing below it can enter the user's top N -- lowers it by a margin above the approximate scores' error bound
+    // (k_topn_exactify's delta; too small a margin would only flag the user for the sort path, never return a wrong list) and raises
+    // every holder's `dropped` to it: the fast reject below then passes ~N / (items seen) of the scores instead of ~3 x 64 / (items seen).
+    // `dropped` stays what the merge needs: an upper bound of every score the lane did not keep.
+    __shared__ double xb[16][64];                                            // heads of 16 users' holders
+    __shared__ double xbar[32], mg[32];                                      // the users' bars; their margins
     int cur = 0;                                                             // lane q < 32: cursor into user q's (ascending) list
     // this lane's eight users: slot s = 4 t + q <-> user j0 + 16 t + g + 4 q
     double bu[8];
@@ -703,6 +720,48 @@ __global__ __launch_bounds__(256, 2) void k_topn_mfma(int kind, int k, const dou
         for (int m = 0; m < kTM; ++m) { ks[s][m] = -INFINITY; ki[s][m] = 0x7fffffff; }
     }
     __syncthreads();
+    if (tid < 32) {
+        double vn2 = 0.0;
+        for (int f = 0; f < k; ++f) vn2 += vt[f][tid] * vt[f][tid];
+        const int j = j0 + tid;
+        const double unmax = sqrt(__longlong_as_double((long long)*unorm2_max));
+        // 8 x (k + 4) 2^-53 x the magnitude bound (k_topn_exactify: 2 x), the |score| term is added where the bar is taken
+        mg[tid] = 8.0 * (k + 4) * 1.1102230246251565e-16 * (unmax * sqrt(vn2) + fabs((sub && j < n_sel) ? sub[j] : 0.0) + fabs(mu) + 1.0);
+        xbar[tid] = -INFINITY;
+    }
+    auto raise_bars = [&]() __attribute__((always_inline)) {                 // (workgroup-uniform call sites only)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                if ((s >> 2) == half) xb[g + 4 * (s & 3)][wid * 16 + c] = ks[s][0];
+            __syncthreads();
+#pragma unroll 1
+            for (int uq = 0; uq < 4; ++uq) {
+                const int lu16 = wid * 4 + uq;
+                const double v = xb[lu16][lane];
+                int cnt = 0;                                                 // holders whose head ranks before this one's
+#pragma unroll 2
+                for (int t = 0; t < 64; t += 2) {
+                    const double w0 = xb[lu16][t], w1 = xb[lu16][t + 1];
+                    cnt += ((w0 > v) || (w0 == v && t < lane)) ? 1 : 0;
+                    cnt += ((w1 > v) || (w1 == v && t + 1 < lane)) ? 1 : 0;
+                }
+                if (cnt == N - 1) {                                          // one lane at most (none for N > 64); -inf stays -inf
+                    const int lu = 16 * half + lu16;
+                    const double bar = v - (mg[lu] + fabs(v) * ((k + 4) * 8.881784197001252e-16));
+                    if (bar > xbar[lu]) xbar[lu] = bar;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const double bar = xbar[16 * (s >> 2) + g + 4 * (s & 3)];
+            if (bar > dropped[s]) dropped[s] = bar;
+        }
+    };
     // gridDim.y > 1 (small batches): the candidate blocks are split over blockIdx.y (k_topn_merge joins the lists)
     const int n_blk_all = (n_cand + 31) / 32;
     const int b_lo = (int)((int64_t)n_blk_all * blockIdx.y / gridDim.y), b_hi = (int)((int64_t)n_blk_all * (blockIdx.y + 1) / gridDim.y);
@@ -726,11 +785,15 @@ __global__ __launch_bounds__(256, 2) void k_topn_mfma(int kind, int k, const dou
         }
     };
     if (b_lo + wid < b_hi) loadB(b_lo + wid, 0);
-    for (int b = b_lo + wid; b < b_hi; b += 4) {
+    const int n_it = (b_hi - b_lo + 3) >> 2;                                 // the same trip count for the four waves (the bars need barriers)
+    for (int nb = 0; nb < n_it; ++nb) {
+        const int b = b_lo + wid + 4 * nb;
+        if (nb >= 4 && (nb & (nb - 1)) == 0 && !TOPN_KO(16)) raise_bars();
+        if (b >= b_hi) continue;
         const int i0 = b * 32, it0 = i0 + 2 * c;                            // this lane's items: it0, it0 + 1
         // which of the block's 32 items each user has rated: the lists ascend and so do a wave's blocks, so lane q walks user q's
         // list once per launch (a couple of LDS reads per block; the tests below are then bit tests, no search, no divergence)
-        if (lane < 32) {
+        if (lane < 32 && !TOPN_KO(8)) {
             const int n = rn[lane];
             unsigned m = 0u;
             while (cur < n && rl[lane][cur] < i0) ++cur;
@@ -747,7 +810,8 @@ __global__ __launch_bounds__(256, 2) void k_topn_mfma(int kind, int k, const dou
             double bx[GS], by[GS];
 #pragma unroll
             for (int s = 0; s < GS; ++s) { bx[s] = bxn[s]; by[s] = byn[s]; }
-            if (gr + 1 < ngr) loadB(b, gr + 1); else loadB(b + 4, 0);
+            if (!TOPN_KO(4)) { if (gr + 1 < ngr) loadB(b, gr + 1); else loadB(b + 4, 0); }
+            if (TOPN_KO(2)) continue;
 #pragma unroll
             for (int s = 0; s < GS; ++s) {
                 const int f = 4 * (gr * GS + s) + g;                        // < kMK: the tile's rows beyond k hold zeros
@@ -757,6 +821,21 @@ __global__ __launch_bounds__(256, 2) void k_topn_mfma(int kind, int k, const dou
                 acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bx[s], acc[2], 0, 0, 0);
                 acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, by[s], acc[3], 0, 0, 0);
             }
+        }
+        if (TOPN_KO(2)) {                                                   // no matrix instructions: scores with the same kind of order statistics
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    unsigned h = (unsigned)(i0 + 2 * c + (t & 1)) * 2654435761u ^ (unsigned)(j0 + 16 * (t >> 1) + g + 4 * q) * 40503u;
+                    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+                    acc[t][q] = (double)(h >> 8) * (1.0 / 16777216.0) + bxn[0] * 1e-30;
+                }
+        }
+        if (TOPN_KO(1)) {                                                   // no selection: keep the scores alive
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dropped[0] = fmax(dropped[0], (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]));
+            continue;
         }
 #pragma unroll
         for (int par = 0; par < 2; ++par) {                                 // the lane's two items, ascending
@@ -780,9 +859,10 @@ __global__ __launch_bounds__(256, 2) void k_topn_mfma(int kind, int k, const dou
                 case 3: p = a + mu + (bi + bu[s]); break;
                 default: p = a; break;
                 }
-                // fast reject: nothing below both the lane's weakest kept entry and its best dropped score changes the bookkeeping (a NaN
-                // compares false and is never listed anyway); the two special values keep their way through the rules below
-                if (!(p > (ks[s][kTM - 1] < dropped[s] ? ks[s][kTM - 1] : dropped[s])) && p != -INFINITY && !(p == 0.0 && a != 0.0)) continue;
+                // fast reject: nothing at or below `dropped` (the lane's best dropped score <= its weakest kept entry, or the user's bar)
+                // changes the bookkeeping: it is not kept and `dropped` already bounds it -- a NaN compares false and is never listed; an
+                // approximate 0.0 below the bar is one more unselected score under `dropped`, which k_topn_exactify's margin test covers
+                if (!(p > dropped[s]) && p != -INFINITY) continue;
                 if (p != p || p == 0.0) {                                    // never listed (mf.py:162,176-182) -- if the EXACT score says so too:
                     if (p == 0.0 && a != 0.0) dropped[s] = INFINITY;         // a sum that cancels to zero here need not in the reference's order
                     continue;
@@ -1137,17 +1217,20 @@ static int topn_query(mfx_topn_plan &S, const int32_t *pos, const int32_t *label
             TOPN_TRY(B.get(&a_items, (size_t)n_sel * N)); TOPN_TRY(B.get(&a_scores, (size_t)n_sel * N)); TOPN_TRY(B.get(&a_drop, (size_t)n_sel));
             TOPN_TRY(B.get(&d_un2, (size_t)1));
             TOPN_TRY(hipMemsetAsync(d_un2, 0, 8, st));
+#ifdef MFX_TOPN_KO
+            { const char *ko = getenv("MFX_TOPN_KO"); const int kv = ko ? atoi(ko) : 0; TOPN_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_topn_ko), &kv, 4, 0, hipMemcpyHostToDevice, st)); }
+#endif
             k_item_norm_max<<<(n_cand + 255) / 256, 256, 0, st>>>(dim, S.dU, ni, n_cand, d_un2);
             const int n_blk = (n_cand + 31) / 32;
             if (splits > n_blk) splits = n_blk;
             if (splits > 1 && !p_drop) TOPN_TRY(B.get(&p_drop, (size_t)n_sel * splits));
             if (splits > 1) {
                 k_topn_mfma<<<dim3(groups, splits), 256, 0, st>>>(kind, dim, S.dU, dv, S.dib, dubs, S.mu, d_label, n_sel, n_pad, ni, n_cand,
-                                                                  N, d_lo, d_lo ? d_lo + n_sel : nullptr, S.d_rated, p_items, p_scores, p_drop);
+                                                                  N, d_lo, d_lo ? d_lo + n_sel : nullptr, S.d_rated, d_un2, p_items, p_scores, p_drop);
                 k_topn_merge<<<n_sel, 64, 0, st>>>(p_items, p_scores, p_drop, splits, N, force, a_items, a_scores, d_unsafe, a_drop);
             } else {
                 k_topn_mfma<<<dim3(groups, 1), 256, 0, st>>>(kind, dim, S.dU, dv, S.dib, dubs, S.mu, d_label, n_sel, n_pad, ni, n_cand,
-                                                             N, d_lo, d_lo ? d_lo + n_sel : nullptr, S.d_rated, a_items, a_scores, a_drop);
+                                                             N, d_lo, d_lo ? d_lo + n_sel : nullptr, S.d_rated, d_un2, a_items, a_scores, a_drop);
             }
             k_topn_exactify<<<n_sel, 64, 0, st>>>(kind, dim, S.dU, dv, S.dib, dubs, S.mu, n_sel, n_pad, ni, N, a_items, a_drop, d_un2, force,
                                                   d_items, d_scores, d_unsafe);

@@ -562,16 +562,16 @@ def test_serving_plan_answers_like_the_batch_call():
 
 
 def test_matrix_core_top_n_with_long_rated_lists_and_every_predictor(monkeypatch):
-    """k_topn_mfma keeps a user's rated list in LDS up to 192 items and searches global memory beyond that; its scores are
+    """k_topn_mfma keeps a user's rated list in LDS up to 176 items and searches global memory beyond that; its scores are
     approximate and only select -- the rows returned carry the bits of the sort path and of the single-user query for every
     predictor, also when the best-scored items are exactly the rated (excluded) ones."""
     from mfrec_amd.recommendation import KMFRecommender
     nu, ni, k = 40, 2500, 20
     rs = np.random.RandomState(3)
     R = KMFRecommender(nu, ni, {"nbr_features": k})
-    users_r = np.concatenate([rs.randint(0, nu, 3000), np.full(400, 7), np.full(193, 8), np.full(192, 9)])
-    items_r = np.concatenate([rs.randint(0, ni, 3000), rs.choice(ni, 400, replace=False), rs.choice(ni, 193, replace=False),
-                              rs.choice(ni, 192, replace=False)])
+    users_r = np.concatenate([rs.randint(0, nu, 3000), np.full(400, 7), np.full(177, 8), np.full(176, 9)])
+    items_r = np.concatenate([rs.randint(0, ni, 3000), rs.choice(ni, 400, replace=False), rs.choice(ni, 177, replace=False),
+                              rs.choice(ni, 176, replace=False)])
     R.set_ratings(np.stack([users_r, items_r], 1), rs.randint(1, 6, users_r.shape[0]).astype(float))
     R.svd_u, R.svd_v = rs.normal(0, 0.3, (k, ni)), rs.normal(0, 0.3, (k, nu))
     R.items_bias, R.users_bias, R.overall_bias = rs.normal(0, 0.1, ni), rs.normal(0, 0.1, nu), 3.0
@@ -590,3 +590,63 @@ def test_matrix_core_top_n_with_long_rated_lists_and_every_predictor(monkeypatch
         for user in (7, 8, 9, 0):
             wi, ws = R.find_recommended_items(user_index=user, nbr_recommendations=12, predictor=pred)
             assert list(fi[user]) == wi and np.array_equal(fs[user], np.array(ws))
+
+
+@pytest.mark.parametrize("shape", ["normal", "ascending", "descending", "ties", "around_zero", "huge_biases", "saturated"])
+def test_matrix_core_top_n_user_bars(monkeypatch, shape):
+    """k_topn_mfma raises every holder's reject bar to (the N-th largest of the user's 64 holders' best scores - a margin) after
+    4, 8, 16, ... blocks per wave.  One workgroup walks a 20 000-item catalogue here (157 blocks per wave: six raises), on score
+    distributions chosen against the bar: the best items LAST (the bar never binds), FIRST (it binds at once), every score
+    equal (ties go by item id), scores straddling zero (an exact 0.0 is never listed), item biases far larger than the margin's
+    magnitude estimate (flagged and redone, never wrong), a saturated logistic predictor (ties at the cap).  The rows must be
+    the sort path's bit for bit, and outside the adversarial shapes the fused path must prove nearly every user itself."""
+    import ctypes as C
+    from mfrec_amd import _shim as S
+    from mfrec_amd.recommendation import KMFRecommender
+    nu, ni, k = 48, 20000, 12
+    rs = np.random.RandomState(11)
+    R = KMFRecommender(nu, ni, {"nbr_features": k})
+    R.set_ratings(np.stack([rs.randint(0, nu, 4000), rs.randint(0, ni, 4000)], 1), rs.randint(1, 6, 4000).astype(float))
+    R.svd_u, R.svd_v = rs.normal(0, 0.3, (k, ni)), rs.normal(0, 0.3, (k, nu))
+    R.items_bias, R.users_bias, R.overall_bias = rs.normal(0, 0.1, ni), rs.normal(0, 0.1, nu), 3.0
+    pred = "predict_linear"
+    ramp = np.arange(ni, dtype=np.float64) / ni
+    if shape == "ascending":
+        R.items_bias = R.items_bias + 4.0 * ramp
+    elif shape == "descending":
+        R.items_bias = R.items_bias - 4.0 * ramp
+    elif shape == "ties":
+        R.svd_u[:] = 0.0; R.items_bias[:] = 0.25
+        R.items_bias[rs.choice(ni, 300, replace=False)] = 0.5          # 300 items tie at the top, the rest one step below
+    elif shape == "around_zero":
+        R.svd_u *= 1e-3; R.items_bias = rs.normal(0, 1e-3, ni); R.users_bias[:] = 0.0; R.overall_bias = 0.0
+        R.svd_u[:, ::7] = 0.0; R.items_bias[::7] = 0.0                  # exact zeros: never listed
+    elif shape == "huge_biases":
+        big = rs.choice(ni, 200, replace=False)
+        R.items_bias[big] = rs.choice([-1.0, 1.0], 200) * 1e9
+    elif shape == "saturated":
+        R.svd_u *= 40.0; pred = "predict_logistic"
+    R.neighborhood = ni
+    users = list(range(nu))
+    monkeypatch.setenv("MFX_TOPN_SPLITS", "1")
+
+    def stats():
+        a = (C.c_int64 * 2)()
+        S.check(S.lib().mfx_topn_stats(a))
+        return a[0], a[1]
+
+    for N in (1, 10, 16):
+        f0, r0 = stats()
+        fi, fs = R.find_recommended_items_batch(users, N, pred)
+        f1, r1 = stats()
+        monkeypatch.setenv("MFX_TOPN_FUSED", "0")
+        si, ss = R.find_recommended_items_batch(users, N, pred)
+        monkeypatch.delenv("MFX_TOPN_FUSED")
+        assert np.array_equal(fi, si) and np.array_equal(fs, ss), (shape, N)
+        assert (f1 - f0) + (r1 - r0) == nu
+        if shape in ("normal", "ascending", "descending"):
+            assert f1 - f0 >= nu - 4, (shape, N, f1 - f0)
+    for user in (0, 17, 47):
+        wi, ws = R.find_recommended_items(user_index=user, nbr_recommendations=16, predictor=pred)
+        got = [int(x) for x in fi[user] if x >= 0]
+        assert got == wi and np.array_equal(fs[user, :len(ws)], np.array(ws))

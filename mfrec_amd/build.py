@@ -26,7 +26,7 @@ def sources():
 def lint(srcs, isa_of, verbose=True):
     """ISA hazard lint of what is about to be linked; raises on any hazard."""
     from . import isa_lint
-    total = {"dpp": 0, "dpp_hazards": 0, "wide_asm_stores": 0, "store_hazards": 0}
+    total = {"dpp": 0, "dpp_hazards": 0, "wide_asm_stores": 0, "store_hazards": 0, "asm_loads": 0, "load_hazards": 0}
     for src in srcs:
         path = isa_of(src)
         if not os.path.exists(path):
@@ -36,8 +36,9 @@ def lint(srcs, isa_of, verbose=True):
             total[k] += r[k]
     if verbose:
         print("[mfrec_amd.build] ISA lint: %(dpp)d DPP instructions, %(dpp_hazards)d hazards; "
-              "%(wide_asm_stores)d wide asm stores, %(store_hazards)d without s_nop >= 1" % total, flush=True)
-    if total["dpp_hazards"] or total["store_hazards"]:
+              "%(wide_asm_stores)d wide asm stores, %(store_hazards)d without s_nop >= 1; "
+              "%(asm_loads)d asm loads, %(load_hazards)d named in flight" % total, flush=True)
+    if total["dpp_hazards"] or total["store_hazards"] or total["load_hazards"]:
         raise RuntimeError("ISA hazard lint failed: %r" % (total,))
     return total
 

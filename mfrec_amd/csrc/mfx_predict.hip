@@ -770,21 +770,54 @@ __global__ __launch_bounds__(256, 2) void k_topn_mfma(int kind, int k, const dou
     constexpr int GS = 4;
     const int ngr = (nks + GS - 1) / GS;
     // (two groups ahead measured slower: 50 against 43 ms for 100 K users; groups of eight steps spill)
-    double bxn[GS], byn[GS];
-    auto loadB = [&](int blk, int gr) __attribute__((always_inline)) {
-        const int it = blk * 32 + 2 * c;
-        const bool two = it + 1 < n_cand, one = it < n_cand;
-        const double *up = u + (size_t)(gr * GS * 4 + g) * ni + it;          // feature 4 (gr GS + s) + g of step s
+    // BRANCH-FREE loads through a buffer resource per feature group (base = the group's first feature row, extent = what is left of
+    // u + 8 pad bytes): rows beyond k and items beyond the array read 0 (or, inside the array, a neighbour's finite-or-not value in a
+    // COLUMN that is never looked at: items >= n_cand), so no `if` guards a load.  With the guards (one branch nest per load) the
+    // compiler put `s_waitcnt vmcnt(0)` behind the NEXT group's loads, in front of this group's first matrix instruction; with the
+    // loaded pairs copied into `double` variables it waited for them right behind the loads, to shuffle registers: either way
+    // nothing was in flight under the matrix instructions (profiles/r05_topn_knockouts.txt).  Hence: the raw 16-byte quads stay
+    // where they land, in TWO register sets that take turns (no copies), and the matrix instructions read their halves in place.
+    // (host: 16 ni 8 < 2^31, u allocated with the pad)
+    // The compiler's own wait counts were no better with plain builtin loads in two sets: it asked for vmcnt(3..0) in front of the
+    // matrix instructions of set A right behind the four loads of set B, i.e. for the loads it had just issued.  So the loads are
+    // `asm volatile` (invisible to the wait-count pass) and the waits are written here: vmcnt counts in order, so "at most four
+    // younger loads outstanding" = this set has landed, whatever else the compiler has in flight (its loads only make the wait
+    // stricter).  Every use of a set goes through landed(), which ties the registers to the wait.
+    // What the compiler may NOT do is copy a quad between its load and its landed() (a live-range split or a spill would read registers
+    // a load is still going to write).  It has no reason to at this register count, and mfrec_amd/isa_lint.py checks the built code:
+    // in a kernel with `asm` buffer loads, the loaded registers are named only by those loads, by matrix instructions, and by the
+    // copies of the odd-group tail right behind its vmcnt(0) -- anything else FAILS the build.  release() keeps a set allocated to
+    // the end of its group (else the compiler re-uses a consumed quad for the LDS operands: legal, but it blurs that rule).
+    // (in accumulation registers, "=a", the compiler split the file 128 + 128 and spilled.)
+    typedef unsigned v4u_mf __attribute__((ext_vector_type(4)));
+    typedef unsigned v2u_mf __attribute__((ext_vector_type(2)));
+    v4u_mf wA[GS], wB[GS];
+    auto loadB = [&](v4u_mf (&w)[GS], int blk, int gr) __attribute__((always_inline)) {
+        const int f0 = gr * GS * 4;                                          // uniform; < k
+        const size_t left = (size_t)(k - f0) * ni * 8 + 8;
+        const unsigned long long base = (unsigned long long)(u + (size_t)f0 * ni);
+        v4u_mf rs;                                                           // raw buffer: base, stride 0, extent, gfx9 data format word
+        rs.x = __builtin_amdgcn_readfirstlane((unsigned)base);
+        rs.y = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32) & 0xffffu);
+        rs.z = __builtin_amdgcn_readfirstlane(left > 0x7fffffffu ? 0x7fffffffu : (unsigned)left);
+        rs.w = 0x27000u;
+        const unsigned off = ((unsigned)g * (unsigned)ni + (unsigned)(blk * 32 + 2 * c)) * 8u;   // feature f0 + 4 s + g of step s
 #pragma unroll
         for (int s = 0; s < GS; ++s) {
-            bxn[s] = 0.0; byn[s] = 0.0;
-            if (4 * (gr * GS + s) + g < k && blk < b_hi) {
-                if (two) { const v2f64_u8 w = *reinterpret_cast<const v2f64_u8 *>(up + (size_t)4 * s * ni); bxn[s] = w.x; byn[s] = w.y; }
-                else if (one) bxn[s] = up[(size_t)4 * s * ni];
-            }
+            const unsigned o = off + (unsigned)(4 * s) * (unsigned)ni * 8u;
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(w[s]) : "v"(o), "s"(rs) : "memory");
         }
     };
-    if (b_lo + wid < b_hi) loadB(b_lo + wid, 0);
+    auto landed = [&](v4u_mf (&w)[GS], bool all) __attribute__((always_inline)) {
+        if (all) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < GS; ++s) asm volatile("" : "+v"(w[s]));
+    };
+    auto release = [&](v4u_mf (&w)[GS]) __attribute__((always_inline)) {   // the set stays allocated until here: see below
+#pragma unroll
+        for (int s = 0; s < GS; ++s) asm volatile("" :: "v"(w[s]));
+    };
+    loadB(wA, b_lo + wid, 0);                                                // (a block beyond the range: loaded, never used)
     const int n_it = (b_hi - b_lo + 3) >> 2;                                 // the same trip count for the four waves (the bars need barriers)
     for (int nb = 0; nb < n_it; ++nb) {
         const int b = b_lo + wid + 4 * nb;
@@ -806,20 +839,35 @@ __global__ __launch_bounds__(256, 2) void k_topn_mfma(int kind, int k, const dou
         double4_mf acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = (double4_mf){0.0, 0.0, 0.0, 0.0};
-        for (int gr = 0; gr < ngr; ++gr) {
-            double bx[GS], by[GS];
-#pragma unroll
-            for (int s = 0; s < GS; ++s) { bx[s] = bxn[s]; by[s] = byn[s]; }
-            if (!TOPN_KO(4)) { if (gr + 1 < ngr) loadB(b, gr + 1); else loadB(b + 4, 0); }
-            if (TOPN_KO(2)) continue;
+        auto mma = [&](const v4u_mf (&w)[GS], int gr) __attribute__((always_inline)) {
+            if (TOPN_KO(2)) return;
 #pragma unroll
             for (int s = 0; s < GS; ++s) {
                 const int f = 4 * (gr * GS + s) + g;                        // < kMK: the tile's rows beyond k hold zeros
                 const double a0 = vt[f][c], a1 = vt[f][16 + c];
-                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bx[s], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, by[s], acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bx[s], acc[2], 0, 0, 0);
-                acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, by[s], acc[3], 0, 0, 0);
+                const double bx = __builtin_bit_cast(double, (v2u_mf){w[s].x, w[s].y}), by = __builtin_bit_cast(double, (v2u_mf){w[s].z, w[s].w});
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bx, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, by, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bx, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, by, acc[3], 0, 0, 0);
+            }
+        };
+        // set A holds group `gr` on entry (of the loop and of every pair); the next group's (after a block's last: the next block's
+        // first) loads go out before this group's matrix instructions
+        for (int gr = 0; gr < ngr; gr += 2) {
+            if (gr + 1 < ngr) loadB(wB, b, gr + 1); else loadB(wB, b + 4, 0);
+            landed(wA, false);
+            mma(wA, gr);
+            release(wA);
+            if (gr + 1 < ngr) {
+                if (gr + 2 < ngr) loadB(wA, b, gr + 2); else loadB(wA, b + 4, 0);
+                landed(wB, false);
+                mma(wB, gr + 1);
+                release(wB);
+            } else {                                                         // an odd number of groups: the next block's first group sits in B
+                landed(wB, true);
+#pragma unroll
+                for (int s = 0; s < GS; ++s) wA[s] = wB[s];
             }
         }
         if (TOPN_KO(2)) {                                                   // no matrix instructions: scores with the same kind of order statistics
@@ -829,7 +877,7 @@ __global__ __launch_bounds__(256, 2) void k_topn_mfma(int kind, int k, const dou
                 for (int q = 0; q < 4; ++q) {
                     unsigned h = (unsigned)(i0 + 2 * c + (t & 1)) * 2654435761u ^ (unsigned)(j0 + 16 * (t >> 1) + g + 4 * q) * 40503u;
                     h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
-                    acc[t][q] = (double)(h >> 8) * (1.0 / 16777216.0) + bxn[0] * 1e-30;
+                    acc[t][q] = (double)(h >> 8) * (1.0 / 16777216.0) + (double)wA[0].x * 1e-300;
                 }
         }
         if (TOPN_KO(1)) {                                                   // no selection: keep the scores alive
@@ -888,6 +936,7 @@ __global__ __launch_bounds__(256, 2) void k_topn_mfma(int kind, int k, const dou
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the last prefetch (never used) must not land in re-used registers
     // ---- merge: a user's 64 holders (lanes (c, g) of the four waves) through LDS, 16 users at a time; wave w then takes four users:
     //      lane = holder, N rounds of a wave-wide arg-max over the sorted kept lists (k_topn_tiled's merge) -------------------------
     double *m_s = reinterpret_cast<double *>(smem);                          // [16][64][kTM]
@@ -1136,7 +1185,7 @@ static int topn_state_init(mfx_topn_plan &S, int kind, int dim, const double *u,
 {
     hipStream_t st = mfx::stream();
     S.kind = kind; S.k = dim; S.nu = nu; S.ni = ni; S.mu = mu;
-    TOPN_TRY(hipMalloc((void **)&S.dU, (size_t)dim * ni * 8));
+    TOPN_TRY(hipMalloc((void **)&S.dU, (size_t)dim * ni * 8 + 16));   // (+ pad: k_topn_mfma's 16-byte loads of an odd catalogue's last item)
     TOPN_TRY(hipMalloc((void **)&S.dV, (size_t)dim * nu * 8));
     TOPN_TRY(hipMemcpyAsync(S.dU, u, (size_t)dim * ni * 8, hipMemcpyHostToDevice, st));
     TOPN_TRY(hipMemcpyAsync(S.dV, v, (size_t)dim * nu * 8, hipMemcpyHostToDevice, st));
@@ -1208,7 +1257,7 @@ static int topn_query(mfx_topn_plan &S, const int32_t *pos, const int32_t *label
             k_topn_fused<<<(n_sel + kUB - 1) / kUB, 256, 0, st>>>(kind, dim, S.dU, dv, S.dib, dubs, S.mu, d_label, n_sel, n_pad, ni,
                                                                    n_cand, N, d_lo, d_lo ? d_lo + n_sel : nullptr, S.d_rated, force,
                                                                    d_items, d_scores, d_unsafe);
-        else if (dim <= kMK && !(tv && tv[0] == 't'))
+        else if (dim <= kMK && (size_t)ni * 128 < 0x7fffffffu && !(tv && tv[0] == 't'))
         {
             // scores on the matrix cores (approximate: they only select), then the selected scores again in the reference's order
             int32_t *a_items;                                       // the merged approximate lists

@@ -8,6 +8,11 @@ stores) and both have bitten before (an intermittent full-size mismatch, fixed b
   * a VMEM store of more than 8 bytes reads its data VGPRs after issue: the next instruction must not
     overwrite them, so an asm store must carry its own `s_nop 1` (2 wait states; `s_nop 0` is not enough).
 
+  * a VMEM LOAD written in inline asm (mfx_predict.hip: k_topn_mfma's B operands, so that the wait counts are the
+    kernel's own) is invisible to the compiler's wait-count pass: nothing may NAME its destination VGPRs -- no copy of a
+    live-range split, no spill, no re-use -- until a wait that covers it: `s_waitcnt vmcnt(0)` (anybody's), or an asm
+    `s_waitcnt vmcnt(N)` once at least N younger asm loads have been issued (vmcnt counts in order).  scan_asm_loads().
+
 The scan is linear, so at every label and after every branch the history is UNKNOWN: a hand-written DPP
 instruction (one inside an ;;#ASMSTART block) that close to such a point must bring its own `s_nop`
 (compiler-generated DPP moves are the hazard recogniser's business and are only checked against the
@@ -131,10 +136,85 @@ def scan_asm_stores(lines):
     return n, bad
 
 
+ASM_LOADS = ("buffer_load_dword", "global_load_dword", "flat_load_dword")
+
+
+def all_regs(text):
+    out = set()
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]", text):
+        out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    for m in re.finditer(r"\bv(\d+)\b", text):
+        out.add(int(m.group(1)))
+    return out
+
+
+def scan_asm_loads(lines, verbose=True):
+    """-> (asm VMEM loads, hazards).  Linear scan per kernel (state reset at every `.amdhsa_kernel` / function label is not needed: a
+    kernel ends with everything waited for or the scan reports it).  In flight: the destination registers of every asm load, youngest
+    last.  An asm `s_waitcnt vmcnt(N)` lands all but the N youngest; any `s_waitcnt` with vmcnt(0) lands all.  if / else twins that
+    load the SAME registers follow each other in linear order: re-loading a register that is in flight replaces the older entry
+    (the twin), it is not a hazard.  Every other instruction naming a register in flight is one.  A loop's back edge is not followed:
+    what is in flight at the bottom of a loop body stays in flight through the code behind the loop, which is the stricter reading."""
+    n = bad = 0
+    in_asm = False
+    flight = []                                   # [set of VGPRs] per load, oldest first
+    for line in lines:
+        t = line.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not t or t.startswith((";", ".", "//")) or t.endswith(":"):
+            if t.startswith(".end_amdhsa_kernel") or t.startswith(".amdhsa_kernel"):
+                if flight and t.startswith(".amdhsa_kernel"):
+                    pass
+            if t.endswith(":") and not t.startswith((";", "//")) and not t.startswith(".L"):   # a new function: nothing carries over
+                if flight:
+                    bad += 1
+                    if verbose:
+                        print("HAZARD (asm loads still in flight at the end of a function):", sorted(set().union(*flight))[:8])
+                flight = []
+            continue
+        op = t.split()[0]
+        body = t.split(";")[0]
+        if op.startswith("s_waitcnt"):
+            m = re.search(r"vmcnt\((\d+)\)", body)
+            if m:
+                k = int(m.group(1))
+                if k == 0:
+                    flight = []
+                elif in_asm:
+                    flight = flight[-k:]
+            continue
+        if op == "s_endpgm":
+            flight = []
+            continue
+        named = all_regs(body)
+        if in_asm and op.startswith(ASM_LOADS):
+            n += 1
+            dst = all_regs(body.split(",")[0])
+            flight = [f for f in flight if not (f & dst)]          # the twin of an if / else pair
+            src = named - dst
+            if any(f & src for f in flight):
+                bad += 1
+                if verbose:
+                    print("HAZARD (address of an asm load in registers a load is still going to write):", t)
+            flight.append(dst)
+            continue
+        if flight and any(f & named for f in flight):
+            bad += 1
+            if verbose:
+                print("HAZARD (names registers an asm load has in flight):", t)
+    return n, bad
+
+
 def lint_file(path, verbose=True):
-    """-> dict(dpp, dpp_hazards, wide_asm_stores, store_hazards) for one gfx950 assembly file."""
+    """-> dict(dpp, dpp_hazards, wide_asm_stores, store_hazards, asm_loads, load_hazards) for one gfx950 assembly file."""
     with open(path) as f:
         lines = f.readlines()
     n, bad = scan(lines, verbose)
     ns, bs = scan_asm_stores(lines)
-    return {"dpp": n, "dpp_hazards": bad, "wide_asm_stores": ns, "store_hazards": bs}
+    nl, bl = scan_asm_loads(lines, verbose)
+    return {"dpp": n, "dpp_hazards": bad, "wide_asm_stores": ns, "store_hazards": bs, "asm_loads": nl, "load_hazards": bl}

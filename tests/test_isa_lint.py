@@ -75,3 +75,43 @@ def test_the_build_lints_what_it_links():
     src = inspect.getsource(B.build)
     assert "-save-temps=obj" in src and "lint(srcs, isa_of" in src
     assert "ISA hazard lint failed" in inspect.getsource(B.lint)
+
+
+def test_lint_tracks_asm_loads_in_flight():
+    """k_topn_mfma's B operands are `asm` buffer loads with hand-written wait counts (the compiler's were in front of the matrix
+    instructions they were meant to overlap): nothing may name a loaded quad before a wait that covers it."""
+    from mfrec_amd import isa_lint as L
+    A, E = ";;#ASMSTART", ";;#ASMEND"
+    ld = lambda r, a: [A, "buffer_load_dwordx4 v[%d:%d], v%d, s[56:59], 0 offen" % (r, r + 3, a), E]
+    w = lambda n: [A, "s_waitcnt vmcnt(%d)" % n, E]
+    mf = lambda r: ["v_mfma_f64_16x16x4_f64 v[40:47], v[236:237], v[%d:%d], v[40:47]" % (r, r + 1)]
+    # set A (v0-15) loaded, set B (v48-63) loaded, vmcnt(4) -> A has landed, B has not
+    two_sets = sum((ld(r, 200) for r in (0, 4, 8, 12)), []) + sum((ld(r, 201) for r in (48, 52, 56, 60)), []) + w(4)
+    assert L.scan_asm_loads(two_sets + mf(0) + mf(14) + w(0), verbose=False) == (8, 0)
+    assert L.scan_asm_loads(two_sets + mf(48) + w(0), verbose=False) == (8, 1)                  # B is still in flight
+    # a copy of a quad before its wait (a live-range split), a spill, a re-use as a temporary
+    assert L.scan_asm_loads(ld(0, 200) + ["v_mov_b64_e32 v[100:101], v[2:3]"] + w(0), verbose=False) == (1, 1)
+    assert L.scan_asm_loads(ld(0, 200) + ["scratch_store_dwordx4 off, v[0:3], off offset:16"] + w(0), verbose=False) == (1, 1)
+    assert L.scan_asm_loads(ld(0, 200) + ["ds_read2_b64 v[0:3], v234 offset1:16"] + w(0), verbose=False) == (1, 1)
+    # the compiler's own vmcnt(0) lands everything; its vmcnt(N > 0) proves nothing about loads it cannot see
+    assert L.scan_asm_loads(ld(0, 200) + ["s_waitcnt vmcnt(0) lgkmcnt(0)"] + mf(0), verbose=False) == (1, 0)
+    assert L.scan_asm_loads(ld(0, 200) + ["s_waitcnt vmcnt(1)"] + mf(0) + w(0), verbose=False) == (1, 1)
+    # if / else twins load the same registers: the second replaces the first, four younger loads still cover set A
+    twins = sum((ld(r, 200) for r in (0, 4, 8, 12)), []) + sum((ld(r, 201) for r in (48, 52, 56, 60)), []) + \
+        ["s_branch .LBB9_9", ".LBB9_8:"] + sum((ld(r, 202) for r in (48, 52, 56, 60)), []) + [".LBB9_9:"] + w(4)
+    assert L.scan_asm_loads(twins + mf(0) + w(0), verbose=False) == (12, 0)
+    # loads left in flight when the next function starts
+    assert L.scan_asm_loads(ld(0, 200) + ["_Z3foov:", "s_endpgm"], verbose=False) == (1, 1)
+    # the address register of a load must not be in flight either
+    assert L.scan_asm_loads(ld(0, 200) + ld(4, 1) + w(0), verbose=False) == (2, 1)
+
+
+def test_the_linked_top_n_kernel_passes_the_load_lint():
+    import glob
+    from mfrec_amd import isa_lint as L
+    f = glob.glob(os.path.join(ROOT, "build", "obj", "mfx_predict-hip-amdgcn-amd-amdhsa-gfx950.s"))
+    if not f:
+        import pytest
+        pytest.skip("no build tree (the prebuilt library travels without its assembly)")
+    r = L.lint_file(f[0], verbose=False)
+    assert r["asm_loads"] >= 8 and r["load_hazards"] == 0

@@ -1208,8 +1208,11 @@ static int topn_state_init(mfx_topn_plan &S, int kind, int dim, const double *u,
 // pos[j]: the user's position in the state (row of V, list of the CSR); label[j]: its id for the "item named like the
 // user" rule (mf.py:162)
 static int topn_query(mfx_topn_plan &S, const int32_t *pos, const int32_t *label, int n_sel, int n_cand, int N,
-                      int32_t *out_items, double *out_scores, bool allow_fused)
+                      int32_t *out_items, double *out_scores, int level)
 {
+    // level 0: the fused path; 1: the users level 0 flagged, once more through the fused path (few users: their candidates are split
+    // over up to 64 workgroups, so the items that met in one holder at level 0 -- the usual reason, ~8e-4 of the users at N = 10 --
+    // meet different neighbours); 2: the sort path
     if (n_sel == 0) return MFX_OK;
     hipStream_t st = mfx::stream();
     DevBufs B;
@@ -1231,7 +1234,7 @@ static int topn_query(mfx_topn_plan &S, const int32_t *pos, const int32_t *label
 
     // ---- fused path (N <= 16, every rated list ascending): no score matrix at all ---------------------------
     const char *ef = getenv("MFX_TOPN_FUSED");
-    if (allow_fused && N <= kTopMaxN && S.ascending && !(ef && ef[0] == '0')) {
+    if (level < 2 && N <= kTopMaxN && S.ascending && !(ef && ef[0] == '0')) {
         int32_t *d_unsafe;
         TOPN_TRY(B.get(&d_unsafe, (size_t)n_sel));
         const char *fu = getenv("MFX_TOPN_FORCE_UNSAFE");          // test hook: every third user goes the long way
@@ -1302,13 +1305,14 @@ static int topn_query(mfx_topn_plan &S, const int32_t *pos, const int32_t *label
         for (int j = 0; j < n_sel; ++j)
             if (flag[(size_t)j]) { redo.push_back(j); rpos.push_back(pos[j]); rlab.push_back(label[j]); }
         g_topn_stats[0] += n_sel - (int64_t)redo.size();
-        g_topn_stats[1] += (int64_t)redo.size();
         if (redo.empty()) return MFX_OK;
-        // the flagged users once more, through the sort path, as a batch of their own
+        // the flagged users once more as a batch of their own: through the fused path if that splits their candidates differently
         const int m = (int)redo.size();
+        const int next = (level == 0 && !force && (size_t)m * 8 <= (size_t)n_sel) ? 1 : 2;
+        if (next == 2) g_topn_stats[1] += (int64_t)m;
         std::vector<int32_t> it2((size_t)m * N);
         std::vector<double> sc2((size_t)m * N);
-        int rc2 = topn_query(S, rpos.data(), rlab.data(), m, n_cand, N, it2.data(), sc2.data(), false);
+        int rc2 = topn_query(S, rpos.data(), rlab.data(), m, n_cand, N, it2.data(), sc2.data(), next);
         if (rc2) return rc2;
         for (int a = 0; a < m; ++a) {
             memcpy(out_items + (size_t)redo[(size_t)a] * N, it2.data() + (size_t)a * N, (size_t)N * 4);
@@ -1372,7 +1376,7 @@ extern "C" int mfx_topn_batch(int kind, int dim, const double *u, const double *
     if ((rc = topn_state_init(S, kind, dim, u, v_sel, ib, ub_sel, mu, n_sel, ni, rated_off, rated_items))) return rc;
     std::vector<int32_t> pos((size_t)n_sel);
     for (int j = 0; j < n_sel; ++j) pos[(size_t)j] = j;
-    return topn_query(S, pos.data(), users, n_sel, n_cand, N, out_items, out_scores, true);
+    return topn_query(S, pos.data(), users, n_sel, n_cand, N, out_items, out_scores, 0);
 }
 
 extern "C" mfx_topn_plan *mfx_topn_plan_create(int kind, int dim, const double *u, const double *v, const double *ib,
@@ -1401,7 +1405,7 @@ extern "C" int mfx_topn_plan_query(mfx_topn_plan *p, const int32_t *users, int n
         return mfx::fail(MFX_E_ARG, "mfx_topn_plan_query: bad argument");
     for (int j = 0; j < n_sel; ++j)
         if (users[j] < 0 || users[j] >= p->nu) return mfx::fail(MFX_E_RANGE, "mfx_topn_plan_query: user %d outside [0,%d)", users[j], p->nu);
-    return topn_query(*p, users, users, n_sel, n_cand, N, out_items, out_scores, true);
+    return topn_query(*p, users, users, n_sel, n_cand, N, out_items, out_scores, 0);
 }
 
 extern "C" void mfx_topn_plan_destroy(mfx_topn_plan *p)

@@ -287,7 +287,8 @@ def k1_measure(plan, nnz, nu, k, steps, warmup, run, label_plan=None):
                          "kernel": (label_plan or plan).kernel_name(LINEAR),
                          "bytes_per_update_read": b_read, "bytes_per_update_total": b_total,
                          "avg_launch_us": avg_launch_s * 1e6, "launches_per_epoch": launches,
-                         "frac_total_bytes": (b_total * nnz / launches) / avg_launch_s / HBM_PEAK},
+                         "frac_total_bytes": (b_total * nnz / launches) / avg_launch_s / HBM_PEAK,
+                         "us_per_chain_level": (tm.ms * 1e3 / steps) / max(info["n_levels"], 1)},
             "schedule_build_ms": info["schedule_us"] / 1e3}
 
 
@@ -1078,6 +1079,9 @@ def headline_line(J):
     if not multi and resident:
         # the epoch is a chain of dependent hand-offs, not a stream: the floor that chain sets
         line["roofline"].update(chain_floor(info["n_levels"], avg_launch_s * 1e3))
+        # what one level of the dependency DAG costs inside the launch (~3.7 us = one dependent step when the epoch is
+        # a pure chain, more when a level holds more ratings than the waves turn over per step)
+        line["roofline"]["us_per_chain_level"] = avg_launch_s * 1e6 / max(info["n_levels"], 1)
     if multi and "se_local" in J.last_rmse:
         line["rmse_online_last_rank0_shard"] = float(np.sqrt(J.last_rmse["se_local"] / max(my_nnz, 1)))
     if multi:

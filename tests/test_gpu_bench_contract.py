@@ -31,6 +31,7 @@ def test_main_line_and_roofline_are_consistent():
     cf = d["roofline"]
     assert cf["chain_levels"] == d["config"]["levels"] and cf["min_hop_us"] > 0
     assert abs(cf["chain_floor_ms"] - cf["chain_levels"] * cf["min_hop_us"] * 1e-3) < 1e-12 and 0 < cf["frac_of_chain_floor"] < 1
+    assert abs(cf["us_per_chain_level"] * cf["chain_levels"] - cf["avg_launch_us"]) < 1e-6 * cf["avg_launch_us"]
     assert d["dtype"] == "f64" and d["data"] == "synthetic" and "cfg2" in d["config"]["workload"]
     assert abs(d["value"] - 10000000 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-9
     r = d["roofline"]

@@ -704,11 +704,17 @@ __global__ __launch_bounds__(256, 2) void k_topn_mfma(int kind, int k, const dou
     __shared__ double xbar[32], mg[32];                                      // the users' bars; their margins
     int cur = 0;                                                             // lane q < 32: cursor into user q's (ascending) list
     // this lane's eight users: slot s = 4 t + q <-> user j0 + 16 t + g + 4 q
+    // the five predictors as ONE expression, p = (a + xk) + (bi + bu) (+ the logistic map for kind 2): a branch nest on `kind` per
+    // score was ~10 scalar branches x 16 scores per block.  -0.0 is the additive identity for every double (x + -0.0 == x bit for
+    // bit), so kind 1 is a + (bi + bu), kind 3 (a + mu) + (bi + bu), kind 0 (a + 1.0) + -0.0, default (a + -0.0) + -0.0: the very
+    // operations of k_scores' switch (these scores only select, but the error bound of k_topn_exactify is stated for them).
+    const bool biased = kind >= 1 && kind <= 3;
+    const double xk = kind == 0 ? 1.0 : (kind == 3 ? mu : -0.0);
     double bu[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         const int j = j0 + 16 * (s >> 2) + g + 4 * (s & 3);
-        bu[s] = (sub && j < n_sel) ? sub[j] : 0.0;
+        bu[s] = !biased ? -0.0 : ((sub && j < n_sel) ? sub[j] : 0.0);
     }
     double ks[8][kTM];
     int ki[8][kTM];
@@ -772,50 +778,25 @@ __global__ __launch_bounds__(256, 2) void k_topn_mfma(int kind, int k, const dou
     // (two groups ahead measured slower: 50 against 43 ms for 100 K users; groups of eight steps spill)
     // BRANCH-FREE loads through a buffer resource per feature group (base = the group's first feature row, extent = what is left of
     // u + 8 pad bytes): rows beyond k and items beyond the array read 0 (or, inside the array, a neighbour's finite-or-not value in a
-    // COLUMN that is never looked at: items >= n_cand), so no `if` guards a load.  With the guards (one branch nest per load) the
-    // compiler put `s_waitcnt vmcnt(0)` behind the NEXT group's loads, in front of this group's first matrix instruction; with the
-    // loaded pairs copied into `double` variables it waited for them right behind the loads, to shuffle registers: either way
-    // nothing was in flight under the matrix instructions (profiles/r05_topn_knockouts.txt).  Hence: the raw 16-byte quads stay
-    // where they land, in TWO register sets that take turns (no copies), and the matrix instructions read their halves in place.
-    // (host: 16 ni 8 < 2^31, u allocated with the pad)
-    // The compiler's own wait counts were no better with plain builtin loads in two sets: it asked for vmcnt(3..0) in front of the
-    // matrix instructions of set A right behind the four loads of set B, i.e. for the loads it had just issued.  So the loads are
-    // `asm volatile` (invisible to the wait-count pass) and the waits are written here: vmcnt counts in order, so "at most four
-    // younger loads outstanding" = this set has landed, whatever else the compiler has in flight (its loads only make the wait
-    // stricter).  Every use of a set goes through landed(), which ties the registers to the wait.
-    // What the compiler may NOT do is copy a quad between its load and its landed() (a live-range split or a spill would read registers
-    // a load is still going to write).  It has no reason to at this register count, and mfrec_amd/isa_lint.py checks the built code:
-    // in a kernel with `asm` buffer loads, the loaded registers are named only by those loads, by matrix instructions, and by the
-    // copies of the odd-group tail right behind its vmcnt(0) -- anything else FAILS the build.  release() keeps a set allocated to
-    // the end of its group (else the compiler re-uses a consumed quad for the LDS operands: legal, but it blurs that rule).
-    // (in accumulation registers, "=a", the compiler split the file 128 + 128 and spilled.)
+    // COLUMN that is never looked at: items >= n_cand), so no `if` guards a load (one branch nest per guarded load was what the
+    // compiler generated before).  The raw 16-byte quads stay where they land, in TWO register sets that take turns (no copies), and
+    // the matrix instructions read their halves in place.  (host: 16 ni 8 < 2^31, u allocated with 16 pad bytes, ZEROED: the first 8
+    // are addressable as item 0 of row k)
+    // The loads are the compiler's (`raw_buffer_load` builtins) and so are the wait counts.  They are conservative -- it asks for
+    // `vmcnt(3..0)` in front of set A's matrix instructions right behind set B's four loads -- and `asm volatile` loads with hand-written
+    // `vmcnt(4)` ran 19.5 instead of 25 ms, but returned a garbage list about once in 170 small queries (then k_topn_exactify faulted on
+    // it): measured, not understood, NOT in the product (profiles/experiments/r05_topn_asm_loads.hip.txt, profiles/r05_topn_asm_loads.txt).
     typedef unsigned v4u_mf __attribute__((ext_vector_type(4)));
     typedef unsigned v2u_mf __attribute__((ext_vector_type(2)));
     v4u_mf wA[GS], wB[GS];
     auto loadB = [&](v4u_mf (&w)[GS], int blk, int gr) __attribute__((always_inline)) {
         const int f0 = gr * GS * 4;                                          // uniform; < k
         const size_t left = (size_t)(k - f0) * ni * 8 + 8;
-        const unsigned long long base = (unsigned long long)(u + (size_t)f0 * ni);
-        v4u_mf rs;                                                           // raw buffer: base, stride 0, extent, gfx9 data format word
-        rs.x = __builtin_amdgcn_readfirstlane((unsigned)base);
-        rs.y = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32) & 0xffffu);
-        rs.z = __builtin_amdgcn_readfirstlane(left > 0x7fffffffu ? 0x7fffffffu : (unsigned)left);
-        rs.w = 0x27000u;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(u) + (size_t)f0 * ni, 0,
+                                                                           left > 0x7fffffffu ? 0x7fffffff : (int)left, 0x27000);
         const unsigned off = ((unsigned)g * (unsigned)ni + (unsigned)(blk * 32 + 2 * c)) * 8u;   // feature f0 + 4 s + g of step s
 #pragma unroll
-        for (int s = 0; s < GS; ++s) {
-            const unsigned o = off + (unsigned)(4 * s) * (unsigned)ni * 8u;
-            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(w[s]) : "v"(o), "s"(rs) : "memory");
-        }
-    };
-    auto landed = [&](v4u_mf (&w)[GS], bool all) __attribute__((always_inline)) {
-        if (all) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-#pragma unroll
-        for (int s = 0; s < GS; ++s) asm volatile("" : "+v"(w[s]));
-    };
-    auto release = [&](v4u_mf (&w)[GS]) __attribute__((always_inline)) {   // the set stays allocated until here: see below
-#pragma unroll
-        for (int s = 0; s < GS; ++s) asm volatile("" :: "v"(w[s]));
+        for (int s = 0; s < GS; ++s) w[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + (unsigned)(4 * s) * (unsigned)ni * 8u, 0, 0);
     };
     loadB(wA, b_lo + wid, 0);                                                // (a block beyond the range: loaded, never used)
     const int n_it = (b_hi - b_lo + 3) >> 2;                                 // the same trip count for the four waves (the bars need barriers)
@@ -856,16 +837,11 @@ __global__ __launch_bounds__(256, 2) void k_topn_mfma(int kind, int k, const dou
         // first) loads go out before this group's matrix instructions
         for (int gr = 0; gr < ngr; gr += 2) {
             if (gr + 1 < ngr) loadB(wB, b, gr + 1); else loadB(wB, b + 4, 0);
-            landed(wA, false);
             mma(wA, gr);
-            release(wA);
             if (gr + 1 < ngr) {
                 if (gr + 2 < ngr) loadB(wA, b, gr + 2); else loadB(wA, b + 4, 0);
-                landed(wB, false);
                 mma(wB, gr + 1);
-                release(wB);
             } else {                                                         // an odd number of groups: the next block's first group sits in B
-                landed(wB, true);
 #pragma unroll
                 for (int s = 0; s < GS; ++s) wA[s] = wB[s];
             }
@@ -889,7 +865,7 @@ __global__ __launch_bounds__(256, 2) void k_topn_mfma(int kind, int k, const dou
         for (int par = 0; par < 2; ++par) {                                 // the lane's two items, ascending
             const int item = it0 + par;
             if (item >= n_cand) continue;
-            const double bi = ib ? ib[item] : 0.0;
+            const double bi = !biased ? -0.0 : (ib ? ib[item] : 0.0);
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 const int lu = 16 * (s >> 2) + g + 4 * (s & 3), j = j0 + lu;
@@ -899,14 +875,8 @@ __global__ __launch_bounds__(256, 2) void k_topn_mfma(int kind, int k, const dou
                     if (rn[lu] < 0) return is_rated(off, off_hi, rated, j, item);      // a list too long for LDS
                     return (rmask[wid][lu] >> (2 * c + par)) & 1u;
                 };
-                double p;
-                switch (kind) {
-                case 0: p = a + 1.0; break;
-                case 1: p = a + (bi + bu[s]); break;
-                case 2: p = 1.0 + (1.0 / (1.0 + exp(-(a + (bi + bu[s]))))) * 4.0; break;
-                case 3: p = a + mu + (bi + bu[s]); break;
-                default: p = a; break;
-                }
+                double p = (a + xk) + (bi + bu[s]);
+                if (kind == 2) p = 1.0 + (1.0 / (1.0 + exp(-p))) * 4.0;
                 // fast reject: nothing at or below `dropped` (the lane's best dropped score <= its weakest kept entry, or the user's bar)
                 // changes the bookkeeping: it is not kept and `dropped` already bounds it -- a NaN compares false and is never listed; an
                 // approximate 0.0 below the bar is one more unselected score under `dropped`, which k_topn_exactify's margin test covers
@@ -936,7 +906,6 @@ __global__ __launch_bounds__(256, 2) void k_topn_mfma(int kind, int k, const dou
             }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the last prefetch (never used) must not land in re-used registers
     // ---- merge: a user's 64 holders (lanes (c, g) of the four waves) through LDS, 16 users at a time; wave w then takes four users:
     //      lane = holder, N rounds of a wave-wide arg-max over the sorted kept lists (k_topn_tiled's merge) -------------------------
     double *m_s = reinterpret_cast<double *>(smem);                          // [16][64][kTM]
@@ -999,7 +968,7 @@ __global__ __launch_bounds__(256) void k_item_norm_max(int k, const double *__re
     double s = 0.0;
     if (item < n_cand)
         for (int f = 0; f < k; ++f) { const double x = u[(size_t)f * ni + item]; s += x * x; }
-    if (!(s == s)) s = INFINITY;                                             // a NaN factor: every margin test fails -> sort path
+    if (!(s == s)) s = 0.0;              // a NaN factor: every score of that item is NaN in ANY order of the sum (never listed): no bound needed
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { const double o = __shfl_xor(s, d, 64); s = o > s ? o : s; }
     if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(s));
@@ -1188,6 +1157,9 @@ static int topn_state_init(mfx_topn_plan &S, int kind, int dim, const double *u,
     TOPN_TRY(hipMalloc((void **)&S.dU, (size_t)dim * ni * 8 + 16));   // (+ pad: k_topn_mfma's 16-byte loads of an odd catalogue's last item)
     TOPN_TRY(hipMalloc((void **)&S.dV, (size_t)dim * nu * 8));
     TOPN_TRY(hipMemcpyAsync(S.dU, u, (size_t)dim * ni * 8, hipMemcpyHostToDevice, st));
+    // the pad is READ: as item 0 of feature row k by the matrix-core kernel's padded feature steps (its A operand is 0 there, and
+    // 0 x a NaN left over in the allocation is NaN: a whole item silently unlisted -- tests/test_gpu_topn_golden.py caught it)
+    TOPN_TRY(hipMemsetAsync(reinterpret_cast<char *>(S.dU) + (size_t)dim * ni * 8, 0, 16, st));
     TOPN_TRY(hipMemcpyAsync(S.dV, v, (size_t)dim * nu * 8, hipMemcpyHostToDevice, st));
     if (ib) { TOPN_TRY(hipMalloc((void **)&S.dib, (size_t)ni * 8)); TOPN_TRY(hipMemcpyAsync(S.dib, ib, (size_t)ni * 8, hipMemcpyHostToDevice, st)); }
     if (ub) { TOPN_TRY(hipMalloc((void **)&S.dub, (size_t)nu * 8)); TOPN_TRY(hipMemcpyAsync(S.dub, ub, (size_t)nu * 8, hipMemcpyHostToDevice, st)); }

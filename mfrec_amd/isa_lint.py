@@ -8,8 +8,8 @@ stores) and both have bitten before (an intermittent full-size mismatch, fixed b
   * a VMEM store of more than 8 bytes reads its data VGPRs after issue: the next instruction must not
     overwrite them, so an asm store must carry its own `s_nop 1` (2 wait states; `s_nop 0` is not enough).
 
-  * a VMEM LOAD written in inline asm (mfx_predict.hip: k_topn_mfma's B operands, so that the wait counts are the
-    kernel's own) is invisible to the compiler's wait-count pass: nothing may NAME its destination VGPRs -- no copy of a
+  * a VMEM LOAD written in inline asm (rocprim's look-back scans; round 5's archived k_topn_mfma variant with hand-written
+    wait counts) is invisible to the compiler's wait-count pass: nothing may NAME its destination VGPRs -- no copy of a
     live-range split, no spill, no re-use -- until a wait that covers it: `s_waitcnt vmcnt(0)` (anybody's), or an asm
     `s_waitcnt vmcnt(N)` once at least N younger asm loads have been issued (vmcnt counts in order).  scan_asm_loads().
 

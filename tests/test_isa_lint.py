@@ -78,8 +78,9 @@ def test_the_build_lints_what_it_links():
 
 
 def test_lint_tracks_asm_loads_in_flight():
-    """k_topn_mfma's B operands are `asm` buffer loads with hand-written wait counts (the compiler's were in front of the matrix
-    instructions they were meant to overlap): nothing may name a loaded quad before a wait that covers it."""
+    """The rule for VMEM loads written in inline asm (round 5 tried them for k_topn_mfma's B operands; that variant is archived, not
+    shipped -- profiles/experiments/r05_topn_asm_loads.hip.txt -- but the rule stays in the build's lint): nothing may name a loaded
+    quad before a wait that covers it."""
     from mfrec_amd import isa_lint as L
     A, E = ";;#ASMSTART", ";;#ASMEND"
     ld = lambda r, a: [A, "buffer_load_dwordx4 v[%d:%d], v%d, s[56:59], 0 offen" % (r, r + 3, a), E]
@@ -106,7 +107,7 @@ def test_lint_tracks_asm_loads_in_flight():
     assert L.scan_asm_loads(ld(0, 200) + ld(4, 1) + w(0), verbose=False) == (2, 1)
 
 
-def test_the_linked_top_n_kernel_passes_the_load_lint():
+def test_the_linked_predict_object_passes_the_load_lint():
     import glob
     from mfrec_amd import isa_lint as L
     f = glob.glob(os.path.join(ROOT, "build", "obj", "mfx_predict-hip-amdgcn-amd-amdhsa-gfx950.s"))
@@ -114,4 +115,4 @@ def test_the_linked_top_n_kernel_passes_the_load_lint():
         import pytest
         pytest.skip("no build tree (the prebuilt library travels without its assembly)")
     r = L.lint_file(f[0], verbose=False)
-    assert r["asm_loads"] >= 8 and r["load_hazards"] == 0
+    assert r["load_hazards"] == 0            # (the asm loads left in this object are rocprim's look-back scan's)

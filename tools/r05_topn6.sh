@@ -3,7 +3,7 @@
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r05_topn6; rm -rf $O; mkdir -p $O
-timeout -k 5 300 python3 tools/_stress_topn.py ${REPS:-300} 2>&1 | tail -4 | tee $O/stress.txt
+timeout -k 5 300 python3 tools/stress_topn.py ${REPS:-300} 2>&1 | tail -4 | tee $O/stress.txt
 if grep -q "Memory access fault\|MISMATCH" $O/stress.txt; then echo "stress failed: stopping"; exit 1; fi
 timeout -k 5 600 python3 -m pytest tests/test_gpu_recommenders.py tests/test_gpu_topn_golden.py tests/test_gpu_predict.py -q -m gpu -p no:cacheprovider 2>&1 | tail -3 | tee $O/tests.txt
 for ni in 50000 200000; do echo "$(NI=$ni timeout -k 5 300 python3 tools/topn_kernel_probe.py 2>&1 | tail -1)" | tee -a $O/query.txt; done

@@ -127,3 +127,32 @@ def test_minus_infinity_score_is_listed_like_the_reference_does():
             assert [int(x) for x in items[j] if x >= 0] == it, (N, j)
             if N == 45:
                 assert it[-1] == 7 and sc[-1] == -np.inf
+
+
+def test_small_queries_in_a_loop_stay_golden(golden):
+    """Round 5: a variant of k_topn_mfma (asm loads with hand-written wait counts) returned one wrong row in ~170 of these queries and
+    passed every single-shot test; the product's loads are the compiler's again (profiles/r05_topn_asm_loads.txt).  The fixture's fused
+    cases, 40 times over, every list compared (tools/stress_topn.py is the long form)."""
+    g = golden("g12_topn")
+    calls = []
+    for tag in "ab":
+        u, v, ib, ub, mu, roff, rated, users, nu, ni = _model(g, tag)
+        v_sel, ub_sel = np.ascontiguousarray(v[:, users]), np.ascontiguousarray(ub[users])
+        lists = [rated[roff[x]:roff[x + 1]] if x < nu else np.zeros(0, np.int32) for x in users]
+        off = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.int64)
+        flat = np.ascontiguousarray(np.concatenate(lists + [np.zeros(1, np.int32)]), dtype=np.int32)
+        for kind in KINDS:
+            for ci in (0, 2):                                                   # (case 1 is N = 70: the sort path)
+                n_cand, N = (int(x) for x in g["p_%s_cases" % tag][ci])
+                calls.append((tag, kind, ci, u, v_sel, ib, ub_sel, mu, ni, users, n_cand, N, off, flat))
+    for rep in range(40):
+        for (tag, kind, ci, u, v_sel, ib, ub_sel, mu, ni, users, n_cand, N, off, flat) in calls:
+            items = np.full((users.shape[0], N), -1, dtype=np.int32)
+            scores = np.zeros((users.shape[0], N))
+            bias = kind in (1, 2, 3)
+            S.check(S.lib().mfx_topn_batch(kind, u.shape[0], S.f64(u, "u", 2), S.f64(v_sel, "v", 2),
+                                           S.f64(ib, "ib", 1) if bias else None, S.f64(ub_sel, "ub", 1) if bias else None,
+                                           mu, ni, S.i32(users, "users", 1), users.shape[0], n_cand, N,
+                                           off.ctypes.data_as(S._lp), S.i32(flat, "rated", 1),
+                                           S.i32(items, "items", 2), S.f64(scores, "scores", 2)))
+            assert np.array_equal(items, g["out_%s_items_kind%d_case%d" % (tag, kind, ci)]), (rep, tag, kind, ci)

@@ -54,6 +54,7 @@ struct ResParams {
     double *se_run;             // squared error per run (fixed layout: deterministic epoch RMSE)
     int n_runs, k, res_item;
     int reg_extra;              // test hook: waves that will never register (the co-residency check must fail)
+    int burst_w, burst_mask, burst_spin, burst_run;   // burst walk: windows per call; slots that may be ready when it is taken; polls of a window that is not ready before the walk gives up (tuning: MFX_K1_BURST_W / _MASK / _SPIN)
     double lr, Kres, Ktrav, Kb;
 };
 
@@ -409,9 +410,20 @@ __device__ __forceinline__ int res_burst(const ResParams &P, int s, int &pos, in
         bh = __builtin_bit_cast(THdr, ld16c(rH, (unsigned)br.trav * 16u));
     }
     int total = 0;
-    for (int w = 0; w < 8 && nd > 0; ++w) {                   // (bounded: the wave's other slots get their turn again)
-        const unsigned long long okm = __ballot(lane < nd && bh.cnt == br.seq);
-        const int depth = __builtin_ctzll(~okm);               // leading ready ratings of the window
+    for (int w = 0; w < P.burst_w && nd > 0; ++w) {           // (bounded: the wave's other slots get their turn again)
+        unsigned long long okm = __ballot(lane < nd && bh.cnt == br.seq);
+        int depth = __builtin_ctzll(~okm);                     // leading ready ratings of the window
+        // the next window is not ready: its first user is still in another wave.  Leaving now costs the hot chain two round trips on the
+        // way back in (the records, then their granules) before the rows even start -- and the walk averages 1.1 windows per call on
+        // power-law data (profiles/r05_k1_burst_stats.txt).  So the window's granules are polled again, a bounded number of times
+        // (the wave's other slots wait meanwhile: a hot wave has few ratings besides its hot item's).
+        for (int sp = 0; w > 0 && depth == 0 && sp < P.burst_spin; ++sp) {
+            __builtin_amdgcn_s_sleep(1);
+            if (lane < nd) bh = __builtin_bit_cast(THdr, ld16c(rH, (unsigned)br.trav * 16u));
+            okm = __ballot(lane < nd && bh.cnt == br.seq);
+            depth = __builtin_ctzll(~okm);
+            BST(10, 1);
+        }
         if (w == 0) BST(0, 1);
         if (depth == 0) { BST(w == 0 ? 1 : 5, 1); break; }
         BST(2, 1); BST(3, depth); if (depth < nd) BST(4, 1); if (depth == 8) BST(6, 1);
@@ -596,8 +608,8 @@ __global__ __launch_bounds__(64, STATIC ? ((NR <= 9 && !BURST) ? 3 : 2) : 4) voi
             }
             if constexpr (BURST) {
                 // at most two slots can move and one of them has a run ahead: walk up to eight of ITS ratings in this step
-                if (__popcll(mask) <= 2) {
-                    const unsigned long long cm = __ballot(ready && end - pos >= 3);
+                if (__popcll(mask) <= P.burst_mask) {
+                    const unsigned long long cm = __ballot(ready && end - pos >= P.burst_run);
                     if (cm) {
                         const int s = __builtin_amdgcn_readfirstlane(__builtin_ctzll(cm));
                         if (res_burst<KP, NR, MODE>(P, s, pos, end, rp, rec, nxt, h, rbv, se, vv, prod, rT, rH, lane, g, q) > 0) {
@@ -949,6 +961,18 @@ int res_enqueue_epoch(ResPlan *rp, int mode, double *U_nk, double *V_nk, double 
     P.n_runs = rp->n_runs; P.k = rp->k; P.res_item = rp->res_item ? 1 : 0;
     P.lr = lr; P.Kres = rp->res_item ? Ki : Ku; P.Ktrav = rp->res_item ? Ku : Ki; P.Kb = Kb;
     P.reg_extra = test_reg_extra();
+    // A burst pays two more round trips before its rows than the ordinary step does (the window's records, then their granules): worth
+    // it for an entity whose own run is the chain, a loss for everybody else -- above all for a heavy TRAVELLING entity, whose every
+    // rating is a hand-off between two waves (MovieLens-10M shape: the epoch was the heaviest user's 7 369 hand-offs x 8.7 us with
+    // every item bursting, tools/critical_path.c; 64.7 -> 45.5 ms with the rule below, profiles/r05_k1_burst_run.txt).  A slot
+    // bursts only while it has more ratings ahead than an average resident entity has in the whole epoch.
+    P.burst_w = 8; P.burst_mask = 2; P.burst_spin = 0;
+    P.burst_run = (int)(rp->nnz / (rp->n_res > 0 ? rp->n_res : 1));
+    if (P.burst_run < 3) P.burst_run = 3;
+    if (const char *e = getenv("MFX_K1_BURST_RUN")) P.burst_run = atoi(e);
+    if (const char *e = getenv("MFX_K1_BURST_SPIN")) P.burst_spin = atoi(e);
+    if (const char *e = getenv("MFX_K1_BURST_W")) P.burst_w = atoi(e) < 1 ? 1 : atoi(e);      // tuning hooks (tools/r05_burst_knobs.sh)
+    if (const char *e = getenv("MFX_K1_BURST_MASK")) P.burst_mask = atoi(e);
     const Sel s = select(rp->k, mode, rp->nr, variant);
     MFX_HIP(hipMemsetAsync(rp->d_ctl, 0, sizeof(unsigned), stream()));                          // ticket
     MFX_HIP(hipMemsetAsync(rp->d_ctl + kCtlReg, 0, sizeof(unsigned), stream()));                // registration

@@ -288,11 +288,15 @@ def _zipf(nu, ni, nnz, seed, a_users, a_items):
 
 @pytest.mark.parametrize("shape,k", [((3000, 2000), 64), ((2000, 3000), 64), ((3000, 2000), 24), ((2500, 1500), 128)])
 @pytest.mark.parametrize("mode", [LINEAR, LOGISTIC])
-def test_power_law_data_through_the_burst_variant(shape, k, mode, monkeypatch):
+@pytest.mark.parametrize("burst_run", [None, "3", "400"])
+def test_power_law_data_through_the_burst_variant(shape, k, mode, burst_run, monkeypatch):
     """Skewed degrees (both sides): the static binding's burst variant walks a hot resident entity's run eight ratings per
     step -- duplicates of a pair inside a window, runs shorter than a window and windows that stop at a rating that is not
-    ready yet included -- and must still give the sequential loop's bits."""
+    ready yet included -- and must still give the sequential loop's bits.  A slot bursts only while it has more ratings ahead
+    than an average resident entity has in the epoch (round 5; MFX_K1_BURST_RUN overrides: 3 = round 4's rule, every slot)."""
     monkeypatch.setenv("MFX_K1_BURST", "1")
+    if burst_run:
+        monkeypatch.setenv("MFX_K1_BURST_RUN", burst_run)
     nu, ni = shape
     idx, r = _zipf(nu, ni, 60000, 3, 0.8, 1.1)
     u0, v0 = synth.init_normal(k, ni, 1), synth.init_normal(k, nu, 2)

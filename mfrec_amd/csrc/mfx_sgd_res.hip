@@ -54,7 +54,7 @@ struct ResParams {
     double *se_run;             // squared error per run (fixed layout: deterministic epoch RMSE)
     int n_runs, k, res_item;
     int reg_extra;              // test hook: waves that will never register (the co-residency check must fail)
-    int burst_w, burst_mask, burst_spin, burst_run;   // burst walk: windows per call; slots that may be ready when it is taken; polls of a window that is not ready before the walk gives up (tuning: MFX_K1_BURST_W / _MASK / _SPIN)
+    int burst_run;              // burst walk: ratings a slot must have ahead for a burst to be taken (below)
     double lr, Kres, Ktrav, Kb;
 };
 
@@ -410,20 +410,9 @@ __device__ __forceinline__ int res_burst(const ResParams &P, int s, int &pos, in
         bh = __builtin_bit_cast(THdr, ld16c(rH, (unsigned)br.trav * 16u));
     }
     int total = 0;
-    for (int w = 0; w < P.burst_w && nd > 0; ++w) {           // (bounded: the wave's other slots get their turn again)
-        unsigned long long okm = __ballot(lane < nd && bh.cnt == br.seq);
-        int depth = __builtin_ctzll(~okm);                     // leading ready ratings of the window
-        // the next window is not ready: its first user is still in another wave.  Leaving now costs the hot chain two round trips on the
-        // way back in (the records, then their granules) before the rows even start -- and the walk averages 1.1 windows per call on
-        // power-law data (profiles/r05_k1_burst_stats.txt).  So the window's granules are polled again, a bounded number of times
-        // (the wave's other slots wait meanwhile: a hot wave has few ratings besides its hot item's).
-        for (int sp = 0; w > 0 && depth == 0 && sp < P.burst_spin; ++sp) {
-            __builtin_amdgcn_s_sleep(1);
-            if (lane < nd) bh = __builtin_bit_cast(THdr, ld16c(rH, (unsigned)br.trav * 16u));
-            okm = __ballot(lane < nd && bh.cnt == br.seq);
-            depth = __builtin_ctzll(~okm);
-            BST(10, 1);
-        }
+    for (int w = 0; w < 8 && nd > 0; ++w) {                   // (bounded: the wave's other slots get their turn again)
+        const unsigned long long okm = __ballot(lane < nd && bh.cnt == br.seq);
+        const int depth = __builtin_ctzll(~okm);               // leading ready ratings of the window
         if (w == 0) BST(0, 1);
         if (depth == 0) { BST(w == 0 ? 1 : 5, 1); break; }
         BST(2, 1); BST(3, depth); if (depth < nd) BST(4, 1); if (depth == 8) BST(6, 1);
@@ -608,7 +597,7 @@ __global__ __launch_bounds__(64, STATIC ? ((NR <= 9 && !BURST) ? 3 : 2) : 4) voi
             }
             if constexpr (BURST) {
                 // at most two slots can move and one of them has a run ahead: walk up to eight of ITS ratings in this step
-                if (__popcll(mask) <= P.burst_mask) {
+                if (__popcll(mask) <= 2) {
                     const unsigned long long cm = __ballot(ready && end - pos >= P.burst_run);
                     if (cm) {
                         const int s = __builtin_amdgcn_readfirstlane(__builtin_ctzll(cm));
@@ -860,7 +849,8 @@ int res_prepare(ResPlan **out, const int32_t *idx, const Rec *d_recs, int64_t nn
                 if (rc) return rc;
                 const int max_res = res_item ? mi : mu, max_trav = res_item ? mu : mi;
                 const double stream = nnz * 0.30e-6;
-                double e = max_res * 0.9e-3 > max_trav * 4.6e-3 ? max_res * 0.9e-3 : max_trav * 4.6e-3;
+                // (round 5, MovieLens-10M shape: 1.16 us per rating of the hottest resident entity, 6.2 us per hand-off of the heaviest travelling one)
+                double e = max_res * 1.15e-3 > max_trav * 6.2e-3 ? max_res * 1.15e-3 : max_trav * 6.2e-3;
                 e = e > stream ? e : stream;
                 if (benv == 1 || (2 * (int64_t)max_res >= n_levels && e < e_static)) {
                     burst = true;
@@ -965,14 +955,12 @@ int res_enqueue_epoch(ResPlan *rp, int mode, double *U_nk, double *V_nk, double 
     // it for an entity whose own run is the chain, a loss for everybody else -- above all for a heavy TRAVELLING entity, whose every
     // rating is a hand-off between two waves (MovieLens-10M shape: the epoch was the heaviest user's 7 369 hand-offs x 8.7 us with
     // every item bursting, tools/critical_path.c; 64.7 -> 45.5 ms with the rule below, profiles/r05_k1_burst_run.txt).  A slot
-    // bursts only while it has more ratings ahead than an average resident entity has in the whole epoch.
-    P.burst_w = 8; P.burst_mask = 2; P.burst_spin = 0;
+    // bursts only while it has more ratings ahead than an average resident entity has in the whole epoch.  (Measured and dropped
+    // beside it: windows per call, bursts only when one slot is ready, polling a not-yet-ready window again inside the burst, a
+    // first window made of the slot's head rating out of the caller's registers -- none better, same file.)
     P.burst_run = (int)(rp->nnz / (rp->n_res > 0 ? rp->n_res : 1));
     if (P.burst_run < 3) P.burst_run = 3;
-    if (const char *e = getenv("MFX_K1_BURST_RUN")) P.burst_run = atoi(e);
-    if (const char *e = getenv("MFX_K1_BURST_SPIN")) P.burst_spin = atoi(e);
-    if (const char *e = getenv("MFX_K1_BURST_W")) P.burst_w = atoi(e) < 1 ? 1 : atoi(e);      // tuning hooks (tools/r05_burst_knobs.sh)
-    if (const char *e = getenv("MFX_K1_BURST_MASK")) P.burst_mask = atoi(e);
+    if (const char *e = getenv("MFX_K1_BURST_RUN")) P.burst_run = atoi(e);                       // tuning, tests (3 = round 4's rule)
     const Sel s = select(rp->k, mode, rp->nr, variant);
     MFX_HIP(hipMemsetAsync(rp->d_ctl, 0, sizeof(unsigned), stream()));                          // ticket
     MFX_HIP(hipMemsetAsync(rp->d_ctl + kCtlReg, 0, sizeof(unsigned), stream()));                // registration

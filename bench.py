@@ -366,6 +366,10 @@ def also_k1_ml10m(k):
     m["roofline"]["chain_floor_ms"] = floor_ms
     m["roofline"]["chain_floor"] = "hottest item's degree x %.2f us of dependent f64 arithmetic per rating (exact mode)" % DEP_US_PER_RATING
     m["roofline"]["frac_of_chain_floor"] = floor_ms / m["device_ms_per_step"]
+    # the OTHER chain of this shape: the heaviest user's row travels, every one of its ratings is a hand-off between two waves
+    # (round 5: this, not the hot item, was the epoch -- 7 369 hand-offs x 8.7 us -- until only hot items burst)
+    m["roofline"]["heaviest_user_hand_offs"] = m["max_user_degree"]
+    m["roofline"]["us_per_hand_off_if_that_chain_is_the_epoch"] = m["device_ms_per_step"] * 1e3 / max(m["max_user_degree"], 1)
     m["north_star_floor_updates_per_s"] = 200e6
     m["workload"] = "MovieLens-10M SHAPE (synthetic, power-law degrees on both sides): 69 878 x 10 677, 10 M ratings, shuffled, k=%d, " \
                     "full-k SGD (train_linear_kernel), exact; epoch kernel: %s" % (k, m["epoch_kernel"])

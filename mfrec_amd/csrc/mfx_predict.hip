@@ -659,8 +659,9 @@ __global__ __launch_bounds__(256, 2) void k_topn_mfma(int kind, int k, const dou
                                                       const int32_t *__restrict__ users, int n_sel, int n_pad, int ni,
                                                       int n_cand, int N, const int64_t *__restrict__ off, const int64_t *__restrict__ off_hi,
                                                       const int32_t *__restrict__ rated, const unsigned long long *__restrict__ unorm2_max,
-                                                      int32_t *out_items, double *out_scores, double *pdrop)
+                                                      int32_t *out_items, double *out_scores, double *pdrop, int g_off)
 {
+    // g_off: the first user group of this launch (the lists go out relative to it: row (j - 32 g_off) gridDim.y + blockIdx.y)
     // LDS: the user tile while the candidates are walked; the holders' kept lists of 16 users at a time afterwards
     constexpr int kMergeU = 16;
     constexpr size_t kVtBytes = (size_t)kMK * kVS * 8, kMgBytes = (size_t)kMergeU * 64 * (kTM * 12 + 8);
@@ -673,7 +674,7 @@ __global__ __launch_bounds__(256, 2) void k_topn_mfma(int kind, int k, const dou
     __shared__ int rn[32];
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, g = lane >> 4;
-    const int j0 = blockIdx.x * 32;                                          // < n_pad (a multiple of 32)
+    const int j0 = (blockIdx.x + g_off) * 32;                                // < n_pad (a multiple of 32)
     const int nks = (k + 3) >> 2;                                            // 4-feature steps
     for (int e = tid; e < kMK * 32; e += 256) {                              // (rows k .. kMK - 1: zeros, the padded steps of the last group)
         const int f = e >> 5, q = e & 31;
@@ -931,7 +932,7 @@ __global__ __launch_bounds__(256, 2) void k_topn_mfma(int kind, int k, const dou
 #pragma unroll
             for (int m = 0; m < kTM; ++m) { ls[m] = m_s[(lu * 64 + lane) * kTM + m]; li[m] = m_i[(lu * 64 + lane) * kTM + m]; }
             double dm = m_d[lu * 64 + lane];
-            const size_t orow = (size_t)j * gridDim.y + blockIdx.y;
+            const size_t orow = (size_t)(j - 32 * g_off) * gridDim.y + blockIdx.y;
             int taken = 0, n_out = 0;
             for (int t = 0; t <= N; ++t) {                                   // round N: the best entry NOT taken counts as dropped
                 double s = -INFINITY;
@@ -1250,11 +1251,38 @@ static int topn_query(mfx_topn_plan &S, const int32_t *pos, const int32_t *label
             if (splits > 1 && !p_drop) TOPN_TRY(B.get(&p_drop, (size_t)n_sel * splits));
             if (splits > 1) {
                 k_topn_mfma<<<dim3(groups, splits), 256, 0, st>>>(kind, dim, S.dU, dv, S.dib, dubs, S.mu, d_label, n_sel, n_pad, ni, n_cand,
-                                                                  N, d_lo, d_lo ? d_lo + n_sel : nullptr, S.d_rated, d_un2, p_items, p_scores, p_drop);
+                                                                  N, d_lo, d_lo ? d_lo + n_sel : nullptr, S.d_rated, d_un2, p_items, p_scores, p_drop, 0);
                 k_topn_merge<<<n_sel, 64, 0, st>>>(p_items, p_scores, p_drop, splits, N, force, a_items, a_scores, d_unsafe, a_drop);
             } else {
-                k_topn_mfma<<<dim3(groups, 1), 256, 0, st>>>(kind, dim, S.dU, dv, S.dib, dubs, S.mu, d_label, n_sel, n_pad, ni, n_cand,
-                                                             N, d_lo, d_lo ? d_lo + n_sel : nullptr, S.d_rated, d_un2, a_items, a_scores, a_drop);
+                // Whole rounds of workgroups first, one workgroup per 32 users; the LAST, partial round's user groups with their candidates
+                // split over the idle slots (3 125 groups on 512 slots = 6.1 rounds used to cost 7: 98 304 users 19.8 ms, 100 000 22.3 ms)
+                int per_cu = 0, cus = 0, dev = 0;
+                TOPN_TRY(hipGetDevice(&dev));
+                TOPN_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+                TOPN_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_topn_mfma, 256, 0));
+                const int slots = per_cu * cus;
+                const char *et = getenv("MFX_TOPN_TAIL");                    // "0": one launch (A/B, tests)
+                int full = groups, rem = 0, tsplits = 1;
+                if (slots > 0 && groups > slots && !(et && et[0] == '0')) {
+                    rem = groups % slots;
+                    tsplits = rem ? slots / rem : 1;
+                    if (tsplits > 64) tsplits = 64;
+                    if (tsplits > n_blk) tsplits = n_blk;
+                    if (rem && tsplits >= 2) full = groups - rem; else rem = 0;
+                }
+                k_topn_mfma<<<dim3(full, 1), 256, 0, st>>>(kind, dim, S.dU, dv, S.dib, dubs, S.mu, d_label, n_sel, n_pad, ni, n_cand,
+                                                          N, d_lo, d_lo ? d_lo + n_sel : nullptr, S.d_rated, d_un2, a_items, a_scores, a_drop, 0);
+                if (rem) {
+                    const int jb = full * 32, n_tail = n_sel - jb;           // (> 0: only the last group may be padded)
+                    int32_t *t_items;
+                    double *t_scores, *t_drop;
+                    TOPN_TRY(B.get(&t_items, (size_t)rem * 32 * tsplits * N)); TOPN_TRY(B.get(&t_scores, (size_t)rem * 32 * tsplits * N));
+                    TOPN_TRY(B.get(&t_drop, (size_t)rem * 32 * tsplits));
+                    k_topn_mfma<<<dim3(rem, tsplits), 256, 0, st>>>(kind, dim, S.dU, dv, S.dib, dubs, S.mu, d_label, n_sel, n_pad, ni, n_cand,
+                                                                    N, d_lo, d_lo ? d_lo + n_sel : nullptr, S.d_rated, d_un2, t_items, t_scores, t_drop, full);
+                    k_topn_merge<<<n_tail, 64, 0, st>>>(t_items, t_scores, t_drop, tsplits, N, force, a_items + (size_t)jb * N,
+                                                        a_scores + (size_t)jb * N, d_unsafe + jb, a_drop + jb);
+                }
             }
             k_topn_exactify<<<n_sel, 64, 0, st>>>(kind, dim, S.dU, dv, S.dib, dubs, S.mu, n_sel, n_pad, ni, N, a_items, a_drop, d_un2, force,
                                                   d_items, d_scores, d_unsafe);

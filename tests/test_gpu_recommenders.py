@@ -685,3 +685,31 @@ def test_matrix_core_top_n_odd_catalogue_and_the_pad_behind_u(monkeypatch):
             monkeypatch.delenv("MFX_TOPN_FUSED")
             assert np.array_equal(fi, si) and np.array_equal(fs, ss), (ni, splits)
             assert np.all(fi[:, 0] == ni - 1) and np.all(fi[1:, 1] == 0)        # (item 0 is user 0's own index: mf.py skips it)
+
+
+def test_matrix_core_top_n_partial_last_round_with_split_candidates(monkeypatch):
+    """More user groups than the chip has workgroup slots (2 per CU): whole rounds of workgroups go first, the partial last round's groups
+    get their candidates split over the idle slots and merged (100 000 users: 3 125 groups on 512 slots used to cost 7 rounds for 6.1).
+    The rows must be those of the single launch and of the sort path, the padded last group included."""
+    from mfrec_amd.recommendation import KMFRecommender
+    nu, ni, k = 512 * 32 + 41 * 32 + 5, 1500, 6
+    rs = np.random.RandomState(31)
+    R = KMFRecommender(nu, ni, {"nbr_features": k})
+    R.set_ratings(np.stack([rs.randint(0, nu, 60000), rs.randint(0, ni, 60000)], 1), rs.randint(1, 6, 60000).astype(float))
+    R.svd_u, R.svd_v = rs.normal(0, 0.3, (k, ni)), rs.normal(0, 0.3, (k, nu))
+    R.items_bias, R.users_bias, R.overall_bias = rs.normal(0, 0.1, ni), rs.normal(0, 0.1, nu), 3.0
+    R.neighborhood = ni
+    users = list(range(nu))
+    fi, fs = R.find_recommended_items_batch(users, 5, "predict_linear")
+    monkeypatch.setenv("MFX_TOPN_TAIL", "0")
+    oi, os_ = R.find_recommended_items_batch(users, 5, "predict_linear")
+    monkeypatch.delenv("MFX_TOPN_TAIL")
+    assert np.array_equal(fi, oi) and np.array_equal(fs, os_)
+    monkeypatch.setenv("MFX_TOPN_FUSED", "0")
+    tail = list(range(512 * 32 - 40, nu))                                   # the sort path on the users around and in the tail
+    si, ss = R.find_recommended_items_batch(tail, 5, "predict_linear")
+    monkeypatch.delenv("MFX_TOPN_FUSED")
+    assert np.array_equal(fi[tail], si) and np.array_equal(fs[tail], ss)
+    for user in (0, 512 * 32 - 1, 512 * 32, nu - 1):
+        wi, ws = R.find_recommended_items(user_index=user, nbr_recommendations=5, predictor="predict_linear")
+        assert [int(x) for x in fi[user] if x >= 0] == wi and np.array_equal(fs[user, :len(ws)], np.array(ws))

@@ -683,7 +683,7 @@ __global__ __launch_bounds__(256, 2) void k_topn_mfma(int kind, int k, const dou
     for (int q = wid; q < 32; q += 4) {                                      // a wave copies a user's list
         const int j = j0 + q;
         int n = -1;                                                          // -1: no lists at all / list too long -> global search
-        if (off && j < n_sel) {
+        if (off && j < n_sel && !TOPN_KO(32)) {
             const int64_t lo = off[j], hi = off_hi[j];
             if (hi - lo <= kRL) {
                 n = (int)(hi - lo);
@@ -727,7 +727,7 @@ __global__ __launch_bounds__(256, 2) void k_topn_mfma(int kind, int k, const dou
         for (int m = 0; m < kTM; ++m) { ks[s][m] = -INFINITY; ki[s][m] = 0x7fffffff; }
     }
     __syncthreads();
-    if (tid < 32) {
+    if (tid < 32 && !TOPN_KO(128)) {
         double vn2 = 0.0;
         for (int f = 0; f < k; ++f) vn2 += vt[f][tid] * vt[f][tid];
         const int j = j0 + tid;
@@ -914,6 +914,7 @@ __global__ __launch_bounds__(256, 2) void k_topn_mfma(int kind, int k, const dou
     int *m_i = reinterpret_cast<int *>(m_d + kMergeU * 64);                  // [16][64][kTM]
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
+        if (TOPN_KO(64)) break;
         __syncthreads();                                                     // the user tile / the previous half has been read
 #pragma unroll
         for (int s = 0; s < 8; ++s) {

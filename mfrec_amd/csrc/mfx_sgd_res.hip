@@ -371,7 +371,11 @@ __device__ __forceinline__ void res_step(const ResParams &P, unsigned long long 
 
 // Diagnostic builds only (-DMFX_BURST_STATS): what the burst walk covers and how it ends (tools/burst_stats.py)
 #ifdef MFX_BURST_STATS
+#ifdef MFX_BURST_STATS_WAVE0          // the counters of wave 0 alone: the wave that holds entity 0 (the hottest item of the synthetic shapes)
+#define BST(i, n) do { if (lane == 0 && blockIdx.x == 0) atomicAdd(&g_burst_stats[i], (unsigned long long)(n)); } while (0)
+#else
 #define BST(i, n) do { if (lane == 0) atomicAdd(&g_burst_stats[i], (unsigned long long)(n)); } while (0)
+#endif
 #else
 #define BST(i, n) do { } while (0)
 #endif
@@ -449,14 +453,10 @@ __device__ __forceinline__ int res_burst(const ResParams &P, int s, int &pos, in
                 double grad = 0.0;
                 if (lane == s) {
                     double sum = P.res_item ? (0.0 + rbv + tbv) : (0.0 + tbv + rbv);      // kmf_train.pyx:92
-                    const double *row = prod + s * stride;
-                    int f = 0;
-                    for (; f + 8 <= k; f += 8) {
-                        const d2 a = *reinterpret_cast<const d2 *>(row + f), b = *reinterpret_cast<const d2 *>(row + f + 2);
-                        const d2 c = *reinterpret_cast<const d2 *>(row + f + 4), d = *reinterpret_cast<const d2 *>(row + f + 6);
-                        sum += a.x; sum += a.y; sum += b.x; sum += b.y; sum += c.x; sum += c.y; sum += d.x; sum += d.y;
-                    }
-                    for (; f < k; ++f) sum += row[f];
+                    // (round 5: the step's ordered_sum -- the next eight products' reads issued before the current eight are added -- was
+                    //  never brought into the burst walk: its loop waited for LDS in every iteration, 0.65 us of a rating's 0.83; the counters
+                    //  of the hottest item's wave showed FULL windows, i.e. a chain bound by exactly this arithmetic)
+                    sum = ordered_sum(sum, prod + s * stride, k);
                     double err;
                     if constexpr (MODE == 0) {
                         err = rr - sum;
